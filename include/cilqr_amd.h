@@ -1,0 +1,201 @@
+/*
+ * cilqr_amd.h — C-ABI of the MI355X-native batched CILQR solver (libcilqr_amd.so).
+ *
+ * The reference has no FFI: its boundary is the C++ class CILQRSolver
+ * (/root/reference/include/cilqr_solver.hpp:31-148) whose only public method is
+ *   std::tuple<MatrixX2d, MatrixX4d> solve(x0, ref_waypoints, ref_velo, obs_preds, road_boaders)
+ * (hpp:37-41), called once per planning tick from /root/reference/src/motion_planning.cpp:194-196.
+ * This header is what a binding for that path would bind: plain pointers and sizes, no C++/torch
+ * types, error codes instead of exceptions.  Every entry point cites the reference member it
+ * replaces.  All floating-point data is IEEE binary64; arrays are time-major and row-major:
+ *   u[B][N][2] = (acc, steer),  x[B][N+1][4] = (px, py, v, yaw),
+ *   K[B][N][2][4], d[B][N][2], l_x[B][N+1][4], l_u[B][N][2], l_xx[B][N+1][4][4], l_uu[B][N][2][2],
+ *   A[B][N][4][4], Bm[B][N][4][2].
+ *
+ * Threading: a handle is not thread-safe (the reference instance is not re-entrant either); use
+ * one handle per host thread / per GPU.  Calls are synchronous unless the name ends in _async.
+ * Functions ending in _device take DEVICE pointers for the bulk arrays and a hipStream_t (as
+ * void*); everything else takes HOST pointers and stages through the handle's own buffers.
+ */
+#ifndef CILQR_AMD_H
+#define CILQR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CILQR_OK 0
+#define CILQR_ERR_BAD_ARG (-1)
+#define CILQR_ERR_OBSTACLE_HORIZON (-2) /* an obstacle route is shorter than tick+N+1 (upstream: std::out_of_range, src/utils.cpp:52-58) */
+#define CILQR_ERR_DEVICE (-3)           /* HIP runtime error; see cilqr_last_error() */
+#define CILQR_ERR_UNSUPPORTED (-4)
+#define CILQR_ERR_NO_DEVICE (-5)
+
+#define CILQR_MAX_HORIZON 128
+#define CILQR_MAX_ALPHA_TRIALS 20 /* alpha = 1, 1/2, ... while > 1e-6 (src/cilqr_solver.cpp:354) */
+
+/* The scalars CILQRSolver::CILQRSolver copies out of GlobalConfig (src/cilqr_solver.cpp:17-83);
+ * field names are the config keys. */
+typedef struct cilqr_params {
+    int32_t N;               /* lqr/N */
+    int32_t max_iter;        /* iteration/max_iter */
+    int32_t solve_type;      /* lqr/slove_type: 0 = "barrier", 1 = "alm" */
+    int32_t reference_point; /* vehicle/reference_point: 0 = "rear_center", 1 = "gravity_center" */
+    int32_t use_last_solution;
+    int32_t reserved0;
+    double dt; /* delta_t */
+    double w_pos, w_vel, w_yaw, w_acc, w_stl;
+    double obstacle_exp_q1, obstacle_exp_q2, state_exp_q1, state_exp_q2;
+    double alm_rho_init, alm_gamma, max_rho, max_mu;
+    double init_lamb, lamb_decay, lamb_amplify, max_lamb;
+    double convergence_threshold, accept_step_threshold;
+    double wheelbase, width, length, velo_max, velo_min, yaw_lim, acc_max, acc_min, stl_lim, d_safe;
+} cilqr_params;
+
+/* LQRSolveStatus (include/cilqr_solver.hpp:23-29) */
+enum {
+    CILQR_RUNNING = 0,
+    CILQR_CONVERGED = 1,
+    CILQR_BACKWARD_PASS_FAIL = 2,
+    CILQR_FORWARD_PASS_FAIL = 3,
+    CILQR_FORWARD_PASS_SMALL_STEP = 4
+};
+
+/* why solve() left its loop (src/cilqr_solver.cpp:127-148) */
+enum { CILQR_END_CONVERGED = 0, CILQR_END_MAX_LAMB = 1, CILQR_END_MAX_ITER = 2 };
+
+/* The non-ego arguments of one solve() call, shared by many trajectories of a batch:
+ * ref_waypoints (.x/.y/.yaw of a ReferenceLine, include/utils.hpp:32-51), the full obstacle
+ * routes (RoutingLine, include/utils.hpp:53-68; obs_preds[j][k] == obs[j][tick + k] as in
+ * utils::get_sub_routing_lines, src/utils.cpp:88-103), road_boaders and ref_velo. */
+typedef struct cilqr_scenario_desc {
+    const double* lane_x;
+    const double* lane_y;
+    const double* lane_yaw;
+    int32_t L; /* lane samples, 1 <= L <= 65535 (uint16_t indices upstream, cs:291-295) */
+    int32_t M; /* obstacles */
+    const double* obs; /* [M][T][3] = (x, y, yaw) */
+    int32_t T;
+    int32_t reserved0;
+    double road_borders[2]; /* (max border offset, min border offset), motion_planning.cpp:101-103 */
+    double ref_velo;        /* vehicle/target_velocity */
+} cilqr_scenario_desc;
+
+/* one record per executed trip of the loop at src/cilqr_solver.cpp:110 */
+typedef struct cilqr_trace_rec {
+    int32_t status;    /* current_solve_status after iter_step */
+    int32_t trials;    /* forward_pass+get_total_cost evaluations the reference would have made */
+    int32_t accepted;  /* effective_flag */
+    int32_t alpha_idx; /* accepted / converged alpha = 2^-idx, -1 if none */
+    double lamb;       /* after the update at :118-125 */
+    double new_J;      /* cost returned by iter_step */
+} cilqr_trace_rec;
+
+typedef struct cilqr_result {
+    double J_init;  /* cost of the initial trajectory — the value the reference logs as "final cost" */
+    double J_final; /* get_total_cost(u_ret, x_ret) */
+    int32_t iters;
+    int32_t end_reason;
+    int32_t final_status;
+    int32_t ls_trials;
+    int32_t cost_evals; /* get_total_cost calls the reference would have made inside solve() */
+    int32_t trace_len;
+} cilqr_result;
+
+typedef struct cilqr_handle cilqr_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* device = HIP device ordinal.  Fails with CILQR_ERR_NO_DEVICE when no GPU is visible: there
+ * is no CPU fallback in this library. */
+int cilqr_create(int device, cilqr_handle** out);
+int cilqr_destroy(cilqr_handle* h);
+const char* cilqr_last_error(void);
+const char* cilqr_version(void);
+
+/* Replaces CILQRSolver::CILQRSolver(config) (cs:17-83).  A table of parameter sets so that a
+ * batch can sweep settings (BASELINE config 5); all entries must share N. */
+int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int32_t n_params);
+/* Uploads the scenario tables to HBM (copied; the caller's arrays are not retained). */
+int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* scen, int32_t n_scen);
+
+/* ---- the path: CILQRSolver::solve for a batch (cs:85-153) --------------------------------- */
+/* x0[B][4]; scenario_id/param_id/tick [B] (NULL = all zeros).  last_u: NULL for a cold start
+ * (get_init_traj, cs:155-161) or [B][N][2] = the previous solution of each trajectory for a
+ * warm start (get_init_traj_increment, cs:163-180: shifted by one step, last row repeated).
+ * trace: NULL or [B][trace_cap].  Returns when the host buffers are filled. */
+int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0, const int32_t* scenario_id,
+                      const int32_t* param_id, const int32_t* tick, const double* last_u,
+                      double* u_out, double* x_out, cilqr_result* res_out,
+                      cilqr_trace_rec* trace_out, int32_t trace_cap);
+
+/* Same with every array already resident in HBM; enqueues on `stream` (hipStream_t) and returns
+ * without synchronising. */
+int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
+                             const int32_t* d_scenario_id, const int32_t* d_param_id,
+                             const int32_t* d_tick, const double* d_last_u, double* d_u_out,
+                             double* d_x_out, cilqr_result* d_res_out, cilqr_trace_rec* d_trace_out,
+                             int32_t trace_cap, void* stream);
+
+/* Wall time of the most recent solve kernel measured with HIP events on its own stream (ms). */
+int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
+/* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */
+int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
+
+/* ---- the pieces of the path, exported so each can be parity-checked on its own -------------- */
+/* get_init_traj / const_velo_prediction (cs:155-161,182-197): x_out[B][N+1][4] */
+int cilqr_init_traj_batch(cilqr_handle* h, int32_t B, const double* x0, const int32_t* param_id,
+                          double* x_out);
+/* get_ref_exact_points (cs:289-314): ref_out[B][N+1][3], idx_out[B][N+1] */
+int cilqr_ref_points_batch(cilqr_handle* h, int32_t B, const double* x, const int32_t* scenario_id,
+                           const int32_t* param_id, double* ref_out, int32_t* idx_out);
+/* get_total_cost (cs:199-287): J_out[B] */
+int cilqr_total_cost_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                           const int32_t* scenario_id, const int32_t* param_id, const int32_t* tick,
+                           double* J_out);
+/* forward_pass (cs:442-461) for every trial step size at once: alpha_idx a -> alpha = 2^-a.
+ * new_u[B][n_alpha][N][2], new_x[B][n_alpha][N+1][4], J_out[B][n_alpha] (get_total_cost of each) */
+int cilqr_forward_pass_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                             const double* d, const double* K, const int32_t* scenario_id,
+                             const int32_t* param_id, const int32_t* tick, int32_t n_alpha,
+                             double* new_u, double* new_x, double* J_out);
+/* get_total_cost_derivatives_and_Hessians (cs:463-690) + utils::get_kinematic_model_derivatives
+ * (utils.cpp:285-342); any output may be NULL */
+int cilqr_cost_derivatives_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                                 const int32_t* scenario_id, const int32_t* param_id,
+                                 const int32_t* tick, double* l_x, double* l_u, double* l_xx,
+                                 double* l_uu, double* A, double* Bm);
+/* backward_pass (cs:383-440): lamb[B] -> d, K, dV[B][2], status[B] (RUNNING or BACKWARD_PASS_FAIL;
+ * on failure d/K hold the rows computed before the failing step, zeros elsewhere) */
+int cilqr_backward_pass_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                              const double* lamb, const int32_t* scenario_id,
+                              const int32_t* param_id, const int32_t* tick, double* d, double* K,
+                              double* dV, int32_t* status);
+/* elementary functions as evaluated on the device (csrc/detmath.h):
+ * func 0 exp, 1 sin, 2 cos, 3 tan, 4 atan, 5 hypot(x,y), 6 x/y, 7 sqrt(|x|) */
+int cilqr_detmath_eval(cilqr_handle* h, int32_t func, const double* x, const double* y, int32_t n,
+                       double* out);
+
+/* ---- scenario construction on the host (no GPU needed) -------------------------------------- */
+/* ReferenceLine::ReferenceLine(_x, _y, width, accuracy) (src/utils.cpp:21-35) on top of
+ * CubicSpline2D (src/cubic_spline.cpp:130-157).  Writes up to cap samples of x/y/yaw/longitude
+ * and the total count to *count. */
+int cilqr_reference_line_build(const double* wx, const double* wy, int32_t n, double width,
+                               double accuracy, double* x, double* y, double* yaw, double* s,
+                               int32_t cap, int32_t* count);
+/* ReferenceLine::calc_position (src/utils.cpp:60-67): out = (x, y, yaw) */
+int cilqr_reference_line_position(const double* wx, const double* wy, int32_t n, double width,
+                                  double cur_s, double out[3]);
+/* The route fabrication of main() (src/motion_planning.cpp:121-173) without the random noise:
+ * init_cond[V][4] = (x, y, v, yaw); center_widths[n_center]; routes[V][T_cap][3]; *T_out = samples
+ * per route ( t = 0; t < max_simulation_time + 10; t += delta_t ).  line_num/start_s may be NULL. */
+int cilqr_build_routes(const double* wx, const double* wy, int32_t n, const double* center_widths,
+                       int32_t n_center, double accuracy, const double* init_cond, int32_t V,
+                       double max_simulation_time, double delta_t, double* routes, int32_t T_cap,
+                       int32_t* T_out, int32_t* line_num, double* start_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CILQR_AMD_H */

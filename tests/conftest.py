@@ -1,0 +1,66 @@
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build the native pieces once per session (hipcc cross-compiles without a GPU)."""
+    import importlib
+    build = importlib.import_module("toy-example-of-ilqr_amd.build")
+    build.build_all()
+    return True
+
+
+@pytest.fixture(scope="session")
+def pkg(built):
+    import cilqr_amd
+    return cilqr_amd
+
+
+@pytest.fixture(scope="session")
+def orc_det(built):
+    from oracle import Oracle
+    return Oracle("det")
+
+
+@pytest.fixture(scope="session")
+def orc_libm(built):
+    from oracle import Oracle
+    return Oracle("libm")
+
+
+def oracle_scene(sc, tick=0):
+    """oracle.Scene from a package Scenario (same arrays for both sides)."""
+    from oracle import Scene
+    return Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, tick)
+
+
+@pytest.fixture(scope="session")
+def scenarios(pkg):
+    out = {}
+    for name in ("two_straight", "two_borrow", "three_straight", "three_bend"):
+        cfg = pkg.GlobalConfig.get_instance(name)
+        out[name] = (cfg, pkg.build_scenario(cfg, name))
+    return out
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

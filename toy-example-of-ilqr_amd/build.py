@@ -1,0 +1,53 @@
+"""In-tree build of the native pieces: libcilqr_amd.so (hipcc, gfx950) and, for the tests,
+the CPU oracle (gcc).  Everything is compiled with -ffp-contract=off — parity depends on it."""
+import os
+import pathlib
+import shutil
+import subprocess
+
+PKG = pathlib.Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libcilqr_amd.so"
+ORACLE = ROOT / "oracle"
+
+HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
+             "-Wno-unused-result"]
+
+
+def _newer(target, sources):
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(pathlib.Path(s).stat().st_mtime <= t for s in sources)
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_library(force=False, verbose=False):
+    srcs = [CSRC / "cilqr_amd.hip", CSRC / "scenario.cpp"]
+    deps = srcs + [CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h"]
+    if not force and _newer(LIB, deps):
+        return LIB
+    cmd = [hipcc_path()] + HIP_FLAGS + [str(s) for s in srcs] + ["-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return LIB
+
+
+def build_oracle(force=False):
+    if force:
+        subprocess.run(["make", "-C", str(ORACLE), "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", str(ORACLE), "all"], check=True, stdout=subprocess.DEVNULL)
+    return ORACLE / "liboracle_libm.so", ORACLE / "liboracle_det.so"
+
+
+def build_all(force=False, verbose=False):
+    build_library(force, verbose)
+    build_oracle(force)

@@ -1,0 +1,848 @@
+// cilqr_amd.hip — kernels and C-ABI of libcilqr_amd.so (see include/cilqr_amd.h).
+//
+// One block = one wavefront = one trajectory.  The fused kernel runs the whole of
+// CILQRSolver::solve (/root/reference/src/cilqr_solver.cpp:85-153) for its trajectory; the
+// piecewise kernels expose the same device functions (cilqr_device.hpp) one at a time so that
+// every stage can be compared with the oracle in isolation.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cilqr_device.hpp"
+
+using namespace cilqr;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+extern __shared__ double g_lds[];
+
+struct BatchArgs {
+    const cilqr_params* params;
+    const DevScene* scenes;
+    const int32_t* scenario_id; // may be null
+    const int32_t* param_id;    // may be null
+    const int32_t* tick;        // may be null
+    double* scratch;            // [grid][scratch_doubles(N)]
+    int B;
+    int N;
+};
+
+__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
+    int pid = a.param_id ? a.param_id[b] : 0;
+    int sid = a.scenario_id ? a.scenario_id[b] : 0;
+    int tk = a.tick ? a.tick[b] : 0;
+    make_cst(c, a.params[pid], a.scenes[sid], tk);
+}
+
+// CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
+        double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
+        cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (b >= a.B) return;
+    Cst c;
+    load_cst(c, a, b);
+    const int N = c.N;
+    Lds l;
+    carve(l, g_lds, N);
+    double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+
+    const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
+    int idx0;
+    init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0);
+    double J_cur = total_cost_lds(c, l, lane);
+    const double J_init = J_cur;
+
+    double lamb = c.init_lamb;
+    int status = CILQR_RUNNING;
+    int iters = 0, ls_trials = 0, cost_evals = 1, tl = 0;
+    int end_reason = CILQR_END_MAX_ITER;
+    int flag = 0;
+    for (int itr = 0; itr < c.max_iter; ++itr) {
+        // ---- iter_step ----
+        cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
+        // cs:469-475: after a failed pass the expansion of the unchanged trajectory is kept
+        if (status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
+            cost_and_model_derivatives(c, l, lane);
+        }
+        status = CILQR_RUNNING;
+        double dV[2];
+        bool ok = backward_sweep(c, l, lamb, lane, dV);
+        __syncthreads();
+        double new_J = J_cur;
+        int trials = 0, alpha_idx = -1;
+        if (!ok) {
+            status = CILQR_BACKWARD_PASS_FAIL;
+        } else {
+            flag = 0;
+            rollout_trials(c, l, scr, lane, idx0, CILQR_MAX_ALPHA_TRIALS);
+            bool done = false;
+            for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
+                const double alpha = dm_pow2i(-t);
+                new_J = total_cost_trial(c, l, scr, t, lane);
+                trials++;
+                const double decay = J_cur - new_J;
+                const double adecay = (decay < 0) ? -decay : decay;
+                if (t == 0 && adecay < c.conv_thr) {
+                    status = CILQR_CONVERGED;
+                    alpha_idx = t;
+                    done = true;
+                } else {
+                    const double approx = -(alpha * alpha * dV[0] + alpha * dV[1]);
+                    if (decay > 0.0 && (approx < 0.0 || decay / approx > c.accept_thr)) {
+                        if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
+                        flag = 1;
+                        alpha_idx = t;
+                        accept_trial(c, l, scr, t, lane);
+                        J_cur = new_J;
+                        done = true;
+                    }
+                }
+            }
+            if (!done) status = CILQR_FORWARD_PASS_FAIL;
+        }
+        // ---- back in solve (cs:113-141) ----
+        iters++;
+        ls_trials += trials;
+        cost_evals += trials;
+        if (status == CILQR_BACKWARD_PASS_FAIL || status == CILQR_FORWARD_PASS_FAIL) {
+            double la = lamb * c.lamb_amplify;
+            lamb = (c.lamb_amplify < la) ? la : c.lamb_amplify;
+        } else if (status == CILQR_RUNNING) {
+            lamb *= c.lamb_decay;
+        }
+        if (trace_out && tl < trace_cap && lane == 0) {
+            cilqr_trace_rec r;
+            r.status = status; r.trials = trials; r.accepted = flag; r.alpha_idx = alpha_idx;
+            r.lamb = lamb; r.new_J = new_J;
+            trace_out[(size_t)b * trace_cap + tl] = r;
+        }
+        tl++;
+        if (lamb > c.max_lamb) { end_reason = CILQR_END_MAX_LAMB; break; }
+        if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; break; }
+    }
+    // results: u, x of the last accepted trajectory
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        double* xo = x_out + ((size_t)b * (N + 1) + k) * 4;
+        xo[0] = l.x[4 * k]; xo[1] = l.x[4 * k + 1]; xo[2] = l.x[4 * k + 2]; xo[3] = l.x[4 * k + 3];
+        if (k < N) {
+            double* uo = u_out + ((size_t)b * N + k) * 2;
+            uo[0] = l.u[2 * k]; uo[1] = l.u[2 * k + 1];
+        }
+    }
+    if (lane == 0 && res_out) {
+        cilqr_result r;
+        r.J_init = J_init; r.J_final = J_cur; r.iters = iters; r.end_reason = end_reason;
+        r.final_status = status; r.ls_trials = ls_trials; r.cost_evals = cost_evals;
+        r.trace_len = (trace_out && tl > trace_cap) ? trace_cap : tl;
+        res_out[b] = r;
+    }
+}
+
+__device__ inline void stage_xu(const Lds& l, int N, const double* x, const double* u, int lane) {
+    for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) l.x[e] = x[e];
+    if (u)
+        for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.u[e] = u[e];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_init_traj(BatchArgs a, const double* __restrict__ x0, double* __restrict__ x_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    Lds l; carve(l, g_lds, N);
+    const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
+    int idx0;
+    init_trajectory(c, l, xs, nullptr, lane, idx0);
+    for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = l.x[e];
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref_out,
+             int32_t* __restrict__ idx_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    Lds l; carve(l, g_lds, N);
+    stage_xu(l, N, x + (size_t)b * 4 * (N + 1), nullptr, lane);
+    int idx0;
+    ref_indices_lds(c, l, lane, idx0);
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        int j = l.ridx[k];
+        if (idx_out) idx_out[(size_t)b * (N + 1) + k] = j;
+        double* r = ref_out + ((size_t)b * (N + 1) + k) * 3;
+        r[0] = c.lane_xy[2 * j]; r[1] = c.lane_xy[2 * j + 1]; r[2] = c.lane_yaw[j];
+    }
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_total_cost(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
+             double* __restrict__ J_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    Lds l; carve(l, g_lds, N);
+    stage_xu(l, N, x + (size_t)b * 4 * (N + 1), u + (size_t)b * 2 * N, lane);
+    int idx0;
+    ref_indices_lds(c, l, lane, idx0);
+    double J = total_cost_lds(c, l, lane);
+    if (lane == 0) J_out[b] = J;
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
+               const double* __restrict__ d, const double* __restrict__ K, int n_alpha,
+               double* __restrict__ new_u, double* __restrict__ new_x, double* __restrict__ J_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    const int R = N + 1;
+    Lds l; carve(l, g_lds, N);
+    stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
+    for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = K[(size_t)b * 8 * N + e];
+    for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = d[(size_t)b * 2 * N + e];
+    __syncthreads();
+    int idx0 = ref_scan_row0(c, l.x[0], l.x[1], lane);
+    double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    rollout_trials(c, l, scr, lane, idx0, n_alpha);
+    for (int t = 0; t < n_alpha; ++t) {
+        const double* tr = scr + (size_t)t * 7 * R;
+        for (int k = lane; k <= N; k += CILQR_WAVE) {
+            double* xo = new_x + (((size_t)b * n_alpha + t) * R + k) * 4;
+            xo[0] = tr[k]; xo[1] = tr[R + k]; xo[2] = tr[2 * R + k]; xo[3] = tr[3 * R + k];
+            if (k < N) {
+                double* uo = new_u + (((size_t)b * n_alpha + t) * N + k) * 2;
+                uo[0] = tr[4 * R + k]; uo[1] = tr[5 * R + k];
+            }
+        }
+        double J = total_cost_trial(c, l, scr, t, lane);
+        if (lane == 0 && J_out) J_out[(size_t)b * n_alpha + t] = J;
+    }
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
+                   double* __restrict__ o_lx, double* __restrict__ o_lu, double* __restrict__ o_lxx,
+                   double* __restrict__ o_luu, double* __restrict__ o_A, double* __restrict__ o_B) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    const int R = N + 1;
+    Lds l; carve(l, g_lds, N);
+    stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
+    int idx0;
+    ref_indices_lds(c, l, lane, idx0);
+    cost_and_model_derivatives(c, l, lane);
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        if (o_lx) for (int e = 0; e < 4; ++e) o_lx[((size_t)b * R + k) * 4 + e] = l.lx[4 * k + e];
+        if (o_lxx) {
+            const double* hx = l.lxx + 7 * k;
+            const double dn[16] = {hx[0], hx[1], 0.0, hx[2], hx[1], hx[3], 0.0, hx[4],
+                                   0.0, 0.0, hx[6], 0.0, hx[2], hx[4], 0.0, hx[5]};
+            for (int e = 0; e < 16; ++e) o_lxx[((size_t)b * R + k) * 16 + e] = dn[e];
+        }
+        if (k < N) {
+            if (o_lu) for (int e = 0; e < 2; ++e) o_lu[((size_t)b * N + k) * 2 + e] = l.lu[2 * k + e];
+            if (o_luu) {
+                double* q = o_luu + ((size_t)b * N + k) * 4;
+                q[0] = l.luu[2 * k]; q[1] = 0.0; q[2] = 0.0; q[3] = l.luu[2 * k + 1];
+            }
+            if (o_A) {
+                const double* A = l.A5 + 5 * k;
+                const double dn[16] = {1, 0, A[0], A[1], 0, 1, A[2], A[3], 0, 0, 1, 0, 0, 0, A[4], 1};
+                for (int e = 0; e < 16; ++e) o_A[((size_t)b * N + k) * 16 + e] = dn[e];
+            }
+            if (o_B) {
+                const double* Bq = l.B3 + 3 * k;
+                const double dn[8] = {0, Bq[0], 0, Bq[1], c.dt, 0, 0, Bq[2]};
+                for (int e = 0; e < 8; ++e) o_B[((size_t)b * N + k) * 8 + e] = dn[e];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CILQR_WAVE)
+k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
+                const double* __restrict__ lamb, double* __restrict__ o_d, double* __restrict__ o_K,
+                double* __restrict__ o_dV, int32_t* __restrict__ o_status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Cst c; load_cst(c, a, b);
+    const int N = c.N;
+    const int R = N + 1;
+    Lds l; carve(l, g_lds, N);
+    stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
+    for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = 0.0;
+    for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = 0.0;
+    int idx0;
+    ref_indices_lds(c, l, lane, idx0);
+    cost_and_model_derivatives(c, l, lane);
+    double dV[2];
+    bool ok = backward_sweep(c, l, lamb[b], lane, dV);
+    __syncthreads();
+    for (int e = lane; e < 8 * N; e += CILQR_WAVE) o_K[(size_t)b * 8 * N + e] = l.K[e];
+    for (int e = lane; e < 2 * N; e += CILQR_WAVE) o_d[(size_t)b * 2 * N + e] = l.d[e];
+    if (lane == 0) {
+        o_dV[2 * b] = dV[0];
+        o_dV[2 * b + 1] = dV[1];
+        o_status[b] = ok ? CILQR_RUNNING : CILQR_BACKWARD_PASS_FAIL;
+    }
+}
+
+__global__ void k_detmath(int f, const double* __restrict__ x, const double* __restrict__ y,
+                          double* __restrict__ o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i], b = y ? y[i] : 0.0, r = 0.0;
+    switch (f) {
+        case 0: r = dm_exp(a); break;
+        case 1: r = dm_sin(a); break;
+        case 2: r = dm_cos(a); break;
+        case 3: r = dm_tan(a); break;
+        case 4: r = dm_atan(a); break;
+        case 5: r = dm_hypot(a, b); break;
+        case 6: r = a / b; break;
+        case 7: r = dm_sqrt(a < 0 ? -a : a); break;
+        default: break;
+    }
+    o[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(CILQR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct cilqr_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    bool timed_pending = false;
+    float last_ms = 0.f;
+    // tables
+    std::vector<cilqr_params> params;
+    DevBuf d_params;
+    std::vector<DevScene> scenes;     // device pointers inside
+    std::vector<int> scene_T, scene_M; // for validation
+    std::vector<void*> scene_allocs;
+    DevBuf d_scenes;
+    // scratch + staging
+    DevBuf scratch;
+    DevBuf st[16];
+};
+
+static int check_ready(cilqr_handle* h) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    if (h->params.empty()) return fail(CILQR_ERR_BAD_ARG, "cilqr_set_params has not been called");
+    if (h->scenes.empty()) return fail(CILQR_ERR_BAD_ARG, "cilqr_set_scenarios has not been called");
+    return CILQR_OK;
+}
+
+extern "C" const char* cilqr_last_error(void) { return g_err.c_str(); }
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.1 (gfx950, wave64, fp64)"; }
+
+extern "C" int cilqr_create(int device, cilqr_handle** out) {
+    if (!out) return fail(CILQR_ERR_BAD_ARG, "out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(CILQR_ERR_NO_DEVICE, "no HIP device visible (there is no CPU fallback)");
+    if (device < 0 || device >= n) return fail(CILQR_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    cilqr_handle* h = new cilqr_handle();
+    h->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    *out = h;
+    return CILQR_OK;
+}
+
+static void free_scenes(cilqr_handle* h) {
+    for (void* p : h->scene_allocs) (void)hipFree(p);
+    h->scene_allocs.clear();
+    h->scenes.clear();
+    h->scene_T.clear();
+    h->scene_M.clear();
+}
+
+extern "C" int cilqr_destroy(cilqr_handle* h) {
+    if (!h) return CILQR_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_scenes(h);
+    h->d_params.release();
+    h->d_scenes.release();
+    h->scratch.release();
+    for (auto& s : h->st) s.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_timing(cilqr_handle* h, int32_t enabled) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    h->timing = enabled != 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_last_kernel_ms(cilqr_handle* h, float* ms) {
+    if (!h || !ms) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    if (h->timed_pending) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+        h->timed_pending = false;
+    }
+    *ms = h->last_ms;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int32_t n_params) {
+    if (!h || !params || n_params < 1) return fail(CILQR_ERR_BAD_ARG, "bad params table");
+    for (int i = 0; i < n_params; ++i) {
+        const cilqr_params& p = params[i];
+        if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 128]");
+        if (p.N != params[0].N) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share N");
+        if (p.solve_type != 0) return fail(CILQR_ERR_UNSUPPORTED, "solve_type alm is not implemented on the device yet");
+        if (p.reference_point != 0 && p.reference_point != 1) return fail(CILQR_ERR_BAD_ARG, "reference_point must be 0 or 1");
+        if (p.max_iter < 0) return fail(CILQR_ERR_BAD_ARG, "max_iter < 0");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    h->params.assign(params, params + n_params);
+    if (h->d_params.ensure(sizeof(cilqr_params) * n_params)) return fail(CILQR_ERR_DEVICE, "hipMalloc params");
+    HIP_TRY(hipMemcpy(h->d_params.p, params, sizeof(cilqr_params) * n_params, hipMemcpyHostToDevice));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* scen, int32_t n_scen) {
+    if (!h || !scen || n_scen < 1) return fail(CILQR_ERR_BAD_ARG, "bad scenario table");
+    for (int i = 0; i < n_scen; ++i) {
+        const cilqr_scenario_desc& s = scen[i];
+        if (!s.lane_x || !s.lane_y || !s.lane_yaw || s.L < 1 || s.L > 65535)
+            return fail(CILQR_ERR_BAD_ARG, "lane table missing or L outside [1, 65535]");
+        if (s.M < 0 || (s.M > 0 && (!s.obs || s.T < 1))) return fail(CILQR_ERR_BAD_ARG, "bad obstacle block");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    free_scenes(h);
+    for (int i = 0; i < n_scen; ++i) {
+        const cilqr_scenario_desc& s = scen[i];
+        std::vector<double> xy(2 * (size_t)s.L);
+        for (int j = 0; j < s.L; ++j) {
+            xy[2 * j] = s.lane_x[j];
+            xy[2 * j + 1] = s.lane_y[j];
+        }
+        DevScene d;
+        std::memset(&d, 0, sizeof(d));
+        void* p_xy = nullptr;
+        void* p_yaw = nullptr;
+        void* p_obs = nullptr;
+        HIP_TRY(hipMalloc(&p_xy, sizeof(double) * xy.size()));
+        h->scene_allocs.push_back(p_xy);
+        HIP_TRY(hipMalloc(&p_yaw, sizeof(double) * s.L));
+        h->scene_allocs.push_back(p_yaw);
+        HIP_TRY(hipMemcpy(p_xy, xy.data(), sizeof(double) * xy.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p_yaw, s.lane_yaw, sizeof(double) * s.L, hipMemcpyHostToDevice));
+        if (s.M > 0) {
+            size_t nb = sizeof(double) * 3 * (size_t)s.M * (size_t)s.T;
+            HIP_TRY(hipMalloc(&p_obs, nb));
+            h->scene_allocs.push_back(p_obs);
+            HIP_TRY(hipMemcpy(p_obs, s.obs, nb, hipMemcpyHostToDevice));
+        }
+        d.lane_xy = static_cast<const double*>(p_xy);
+        d.lane_yaw = static_cast<const double*>(p_yaw);
+        d.obs = static_cast<const double*>(p_obs);
+        d.L = s.L; d.M = s.M; d.T = s.T;
+        d.border_hi = s.road_borders[0];
+        d.border_lo = s.road_borders[1];
+        d.ref_velo = s.ref_velo;
+        h->scenes.push_back(d);
+        h->scene_T.push_back(s.T);
+        h->scene_M.push_back(s.M);
+    }
+    if (h->d_scenes.ensure(sizeof(DevScene) * n_scen)) return fail(CILQR_ERR_DEVICE, "hipMalloc scenes");
+    HIP_TRY(hipMemcpy(h->d_scenes.p, h->scenes.data(), sizeof(DevScene) * n_scen, hipMemcpyHostToDevice));
+    return CILQR_OK;
+}
+
+// host-side validation of the index arrays (the device trusts them)
+static int validate_ids(cilqr_handle* h, int B, const int32_t* scenario_id, const int32_t* param_id,
+                        const int32_t* tick) {
+    const int N = h->params[0].N;
+    const int ns = (int)h->scenes.size(), np = (int)h->params.size();
+    for (int b = 0; b < B; ++b) {
+        int sid = scenario_id ? scenario_id[b] : 0;
+        int pid = param_id ? param_id[b] : 0;
+        int tk = tick ? tick[b] : 0;
+        if (sid < 0 || sid >= ns) return fail(CILQR_ERR_BAD_ARG, "scenario_id out of range");
+        if (pid < 0 || pid >= np) return fail(CILQR_ERR_BAD_ARG, "param_id out of range");
+        if (tk < 0) return fail(CILQR_ERR_BAD_ARG, "tick < 0");
+        if (h->scene_M[sid] > 0 && tk + N + 1 > h->scene_T[sid])
+            return fail(CILQR_ERR_OBSTACLE_HORIZON, "obstacle route shorter than tick + N + 1");
+    }
+    return CILQR_OK;
+}
+
+struct Staged {
+    const int32_t* sid = nullptr;
+    const int32_t* pid = nullptr;
+    const int32_t* tick = nullptr;
+};
+
+// upload the optional id arrays into staging buffers 0..2
+static int stage_ids(cilqr_handle* h, int B, const int32_t* scenario_id, const int32_t* param_id,
+                     const int32_t* tick, Staged& out) {
+    const int32_t* src[3] = {scenario_id, param_id, tick};
+    const int32_t** dst[3] = {&out.sid, &out.pid, &out.tick};
+    for (int i = 0; i < 3; ++i) {
+        if (!src[i]) continue;
+        if (h->st[i].ensure(sizeof(int32_t) * B)) return fail(CILQR_ERR_DEVICE, "hipMalloc ids");
+        HIP_TRY(hipMemcpyAsync(h->st[i].p, src[i], sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+        *dst[i] = static_cast<const int32_t*>(h->st[i].p);
+    }
+    return CILQR_OK;
+}
+
+static int up(cilqr_handle* h, int slot, const void* src, size_t bytes, const double** out) {
+    if (h->st[slot].ensure(bytes)) return fail(CILQR_ERR_DEVICE, "hipMalloc staging");
+    HIP_TRY(hipMemcpyAsync(h->st[slot].p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = static_cast<const double*>(h->st[slot].p);
+    return CILQR_OK;
+}
+
+static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
+    if (h->st[slot].ensure(bytes)) return fail(CILQR_ERR_DEVICE, "hipMalloc staging");
+    *out = h->st[slot].p;
+    return CILQR_OK;
+}
+
+static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
+    BatchArgs a;
+    a.params = static_cast<const cilqr_params*>(h->d_params.p);
+    a.scenes = static_cast<const DevScene*>(h->d_scenes.p);
+    a.scenario_id = ids.sid;
+    a.param_id = ids.pid;
+    a.tick = ids.tick;
+    a.scratch = static_cast<double*>(h->scratch.p);
+    a.B = B;
+    a.N = h->params[0].N;
+    return a;
+}
+
+static int ensure_scratch(cilqr_handle* h, int B) {
+    const int N = h->params[0].N;
+    if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
+        return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
+    return CILQR_OK;
+}
+
+#define DL(slot, ptr, bytes) \
+    HIP_TRY(hipMemcpyAsync((ptr), h->st[slot].p, (bytes), hipMemcpyDeviceToHost, h->stream))
+
+extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
+                                        const int32_t* d_scenario_id, const int32_t* d_param_id,
+                                        const int32_t* d_tick, const double* d_last_u,
+                                        double* d_u_out, double* d_x_out, cilqr_result* d_res_out,
+                                        cilqr_trace_rec* d_trace_out, int32_t trace_cap, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (B < 1 || !d_x0 || !d_u_out || !d_x_out) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    rc = ensure_scratch(h, B);
+    if (rc) return rc;
+    Staged ids;
+    ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
+    BatchArgs a = make_args(h, B, ids);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t shm = lds_bytes(a.N);
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(k_solve, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
+                       d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+    HIP_TRY(hipGetLastError());
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed_pending = true;
+    }
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
+                                 const int32_t* scenario_id, const int32_t* param_id,
+                                 const int32_t* tick, const double* last_u, double* u_out,
+                                 double* x_out, cilqr_result* res_out, cilqr_trace_rec* trace_out,
+                                 int32_t trace_cap) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (B < 1 || !x0 || !u_out || !x_out) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
+    rc = validate_ids(h, B, scenario_id, param_id, tick);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->params[0].N;
+    Staged ids;
+    rc = stage_ids(h, B, scenario_id, param_id, tick, ids);
+    if (rc) return rc;
+    const double *d_x0 = nullptr, *d_last = nullptr;
+    rc = up(h, 3, x0, sizeof(double) * 4 * B, &d_x0);
+    if (rc) return rc;
+    if (last_u) {
+        rc = up(h, 4, last_u, sizeof(double) * 2 * N * (size_t)B, &d_last);
+        if (rc) return rc;
+    }
+    void *d_u, *d_x, *d_res, *d_tr = nullptr;
+    const size_t nb_u = sizeof(double) * 2 * N * (size_t)B, nb_x = sizeof(double) * 4 * (N + 1) * (size_t)B;
+    rc = alloc_out(h, 5, nb_u, &d_u); if (rc) return rc;
+    rc = alloc_out(h, 6, nb_x, &d_x); if (rc) return rc;
+    rc = alloc_out(h, 7, sizeof(cilqr_result) * B, &d_res); if (rc) return rc;
+    if (trace_out && trace_cap > 0) {
+        rc = alloc_out(h, 8, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap, &d_tr);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_tr, 0, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap, h->stream));
+    }
+    rc = cilqr_solve_batch_device(h, B, d_x0, ids.sid, ids.pid, ids.tick, d_last,
+                                  static_cast<double*>(d_u), static_cast<double*>(d_x),
+                                  static_cast<cilqr_result*>(d_res),
+                                  static_cast<cilqr_trace_rec*>(d_tr), trace_cap, h->stream);
+    if (rc) return rc;
+    DL(5, u_out, nb_u);
+    DL(6, x_out, nb_x);
+    if (res_out) DL(7, res_out, sizeof(cilqr_result) * B);
+    if (d_tr) DL(8, trace_out, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+// common prologue of the piecewise host-pointer entry points
+struct Piece {
+    Staged ids;
+    BatchArgs a;
+    int N = 0;
+    size_t shm = 0;
+};
+
+static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const int32_t* param_id,
+                       const int32_t* tick, Piece& pc) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (B < 1) return fail(CILQR_ERR_BAD_ARG, "B < 1");
+    rc = validate_ids(h, B, scenario_id, param_id, tick);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    rc = ensure_scratch(h, B);
+    if (rc) return rc;
+    rc = stage_ids(h, B, scenario_id, param_id, tick, pc.ids);
+    if (rc) return rc;
+    pc.a = make_args(h, B, pc.ids);
+    pc.N = pc.a.N;
+    pc.shm = lds_bytes(pc.N);
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_init_traj_batch(cilqr_handle* h, int32_t B, const double* x0,
+                                     const int32_t* param_id, double* x_out) {
+    Piece pc;
+    int rc = piece_begin(h, B, nullptr, param_id, nullptr, pc);
+    if (rc) return rc;
+    if (!x0 || !x_out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    const double* d_x0;
+    rc = up(h, 3, x0, sizeof(double) * 4 * B, &d_x0); if (rc) return rc;
+    void* d_x;
+    const size_t nb_x = sizeof(double) * 4 * (pc.N + 1) * (size_t)B;
+    rc = alloc_out(h, 6, nb_x, &d_x); if (rc) return rc;
+    hipLaunchKernelGGL(k_init_traj, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_x0, static_cast<double*>(d_x));
+    HIP_TRY(hipGetLastError());
+    DL(6, x_out, nb_x);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_ref_points_batch(cilqr_handle* h, int32_t B, const double* x,
+                                      const int32_t* scenario_id, const int32_t* param_id,
+                                      double* ref_out, int32_t* idx_out) {
+    Piece pc;
+    int rc = piece_begin(h, B, scenario_id, param_id, nullptr, pc);
+    if (rc) return rc;
+    if (!x || !ref_out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    const int R = pc.N + 1;
+    const double* d_x;
+    rc = up(h, 3, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
+    void *d_ref, *d_idx;
+    rc = alloc_out(h, 5, sizeof(double) * 3 * R * (size_t)B, &d_ref); if (rc) return rc;
+    rc = alloc_out(h, 6, sizeof(int32_t) * R * (size_t)B, &d_idx); if (rc) return rc;
+    hipLaunchKernelGGL(k_ref_points, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_x,
+                       static_cast<double*>(d_ref), static_cast<int32_t*>(d_idx));
+    HIP_TRY(hipGetLastError());
+    DL(5, ref_out, sizeof(double) * 3 * R * (size_t)B);
+    if (idx_out) DL(6, idx_out, sizeof(int32_t) * R * (size_t)B);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_total_cost_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                                      const int32_t* scenario_id, const int32_t* param_id,
+                                      const int32_t* tick, double* J_out) {
+    Piece pc;
+    int rc = piece_begin(h, B, scenario_id, param_id, tick, pc);
+    if (rc) return rc;
+    if (!u || !x || !J_out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    const int N = pc.N, R = N + 1;
+    const double *d_u, *d_x;
+    rc = up(h, 3, u, sizeof(double) * 2 * N * (size_t)B, &d_u); if (rc) return rc;
+    rc = up(h, 4, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
+    void* d_J;
+    rc = alloc_out(h, 5, sizeof(double) * B, &d_J); if (rc) return rc;
+    hipLaunchKernelGGL(k_total_cost, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, static_cast<double*>(d_J));
+    HIP_TRY(hipGetLastError());
+    DL(5, J_out, sizeof(double) * B);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_forward_pass_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                                        const double* d, const double* K, const int32_t* scenario_id,
+                                        const int32_t* param_id, const int32_t* tick, int32_t n_alpha,
+                                        double* new_u, double* new_x, double* J_out) {
+    Piece pc;
+    int rc = piece_begin(h, B, scenario_id, param_id, tick, pc);
+    if (rc) return rc;
+    if (!u || !x || !d || !K || !new_u || !new_x) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    if (n_alpha < 1 || n_alpha > CILQR_MAX_ALPHA_TRIALS) return fail(CILQR_ERR_BAD_ARG, "n_alpha outside [1, 20]");
+    const int N = pc.N, R = N + 1;
+    const double *d_u, *d_x, *d_d, *d_K;
+    rc = up(h, 3, u, sizeof(double) * 2 * N * (size_t)B, &d_u); if (rc) return rc;
+    rc = up(h, 4, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
+    rc = up(h, 5, d, sizeof(double) * 2 * N * (size_t)B, &d_d); if (rc) return rc;
+    rc = up(h, 6, K, sizeof(double) * 8 * N * (size_t)B, &d_K); if (rc) return rc;
+    void *d_nu, *d_nx, *d_J;
+    const size_t nb_u = sizeof(double) * 2 * N * (size_t)B * n_alpha, nb_x = sizeof(double) * 4 * R * (size_t)B * n_alpha;
+    rc = alloc_out(h, 7, nb_u, &d_nu); if (rc) return rc;
+    rc = alloc_out(h, 8, nb_x, &d_nx); if (rc) return rc;
+    rc = alloc_out(h, 9, sizeof(double) * (size_t)B * n_alpha, &d_J); if (rc) return rc;
+    hipLaunchKernelGGL(k_forward_pass, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_d, d_K,
+                       n_alpha, static_cast<double*>(d_nu), static_cast<double*>(d_nx), static_cast<double*>(d_J));
+    HIP_TRY(hipGetLastError());
+    DL(7, new_u, nb_u);
+    DL(8, new_x, nb_x);
+    if (J_out) DL(9, J_out, sizeof(double) * (size_t)B * n_alpha);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_cost_derivatives_batch(cilqr_handle* h, int32_t B, const double* u,
+                                            const double* x, const int32_t* scenario_id,
+                                            const int32_t* param_id, const int32_t* tick,
+                                            double* l_x, double* l_u, double* l_xx, double* l_uu,
+                                            double* A, double* Bm) {
+    Piece pc;
+    int rc = piece_begin(h, B, scenario_id, param_id, tick, pc);
+    if (rc) return rc;
+    if (!u || !x) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    const int N = pc.N, R = N + 1;
+    const double *d_u, *d_x;
+    rc = up(h, 3, u, sizeof(double) * 2 * N * (size_t)B, &d_u); if (rc) return rc;
+    rc = up(h, 4, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
+    double* host[6] = {l_x, l_u, l_xx, l_uu, A, Bm};
+    const size_t nb[6] = {sizeof(double) * 4 * R * (size_t)B, sizeof(double) * 2 * N * (size_t)B,
+                          sizeof(double) * 16 * R * (size_t)B, sizeof(double) * 4 * N * (size_t)B,
+                          sizeof(double) * 16 * N * (size_t)B, sizeof(double) * 8 * N * (size_t)B};
+    void* dev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 6; ++i) {
+        if (!host[i]) continue;
+        rc = alloc_out(h, 5 + i, nb[i], &dev[i]);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_cost_derivatives, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x,
+                       static_cast<double*>(dev[0]), static_cast<double*>(dev[1]), static_cast<double*>(dev[2]),
+                       static_cast<double*>(dev[3]), static_cast<double*>(dev[4]), static_cast<double*>(dev[5]));
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 6; ++i)
+        if (host[i]) DL(5 + i, host[i], nb[i]);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_backward_pass_batch(cilqr_handle* h, int32_t B, const double* u, const double* x,
+                                         const double* lamb, const int32_t* scenario_id,
+                                         const int32_t* param_id, const int32_t* tick, double* d,
+                                         double* K, double* dV, int32_t* status) {
+    Piece pc;
+    int rc = piece_begin(h, B, scenario_id, param_id, tick, pc);
+    if (rc) return rc;
+    if (!u || !x || !lamb || !d || !K || !dV || !status) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    const int N = pc.N, R = N + 1;
+    const double *d_u, *d_x, *d_l;
+    rc = up(h, 3, u, sizeof(double) * 2 * N * (size_t)B, &d_u); if (rc) return rc;
+    rc = up(h, 4, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
+    rc = up(h, 5, lamb, sizeof(double) * B, &d_l); if (rc) return rc;
+    void *o_d, *o_K, *o_dV, *o_st;
+    rc = alloc_out(h, 6, sizeof(double) * 2 * N * (size_t)B, &o_d); if (rc) return rc;
+    rc = alloc_out(h, 7, sizeof(double) * 8 * N * (size_t)B, &o_K); if (rc) return rc;
+    rc = alloc_out(h, 8, sizeof(double) * 2 * B, &o_dV); if (rc) return rc;
+    rc = alloc_out(h, 9, sizeof(int32_t) * B, &o_st); if (rc) return rc;
+    hipLaunchKernelGGL(k_backward_pass, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_l,
+                       static_cast<double*>(o_d), static_cast<double*>(o_K), static_cast<double*>(o_dV),
+                       static_cast<int32_t*>(o_st));
+    HIP_TRY(hipGetLastError());
+    DL(6, d, sizeof(double) * 2 * N * (size_t)B);
+    DL(7, K, sizeof(double) * 8 * N * (size_t)B);
+    DL(8, dV, sizeof(double) * 2 * B);
+    DL(9, status, sizeof(int32_t) * B);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_detmath_eval(cilqr_handle* h, int32_t func, const double* x, const double* y,
+                                  int32_t n, double* out) {
+    if (!h || !x || !out || n < 1 || func < 0 || func > 7) return fail(CILQR_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const double *d_x, *d_y = nullptr;
+    int rc = up(h, 3, x, sizeof(double) * n, &d_x); if (rc) return rc;
+    if (y) { rc = up(h, 4, y, sizeof(double) * n, &d_y); if (rc) return rc; }
+    void* d_o;
+    rc = alloc_out(h, 5, sizeof(double) * n, &d_o); if (rc) return rc;
+    hipLaunchKernelGGL(k_detmath, dim3((n + 255) / 256), dim3(256), 0, h->stream, func, d_x, d_y, static_cast<double*>(d_o), n);
+    HIP_TRY(hipGetLastError());
+    DL(5, out, sizeof(double) * n);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CILQR_OK;
+}

@@ -1,0 +1,243 @@
+/*
+ * detmath.h — deterministic FP64 elementary functions for the CILQR hot path.
+ *
+ * Why this exists: the CILQR solve loop (reference src/cilqr_solver.cpp:85-153) takes discrete
+ * decisions (line-search accept, convergence, PD test, nearest-sample scan) on quantities that
+ * differ at the 1e-12 level, so "matches the CPU solver to 1e-5" is only robust when host and
+ * device evaluate exp/sin/cos/tan/atan/hypot to the SAME BITS.  libm (glibc) and the ROCm device
+ * library (OCML) are each < 1 ulp but not bit-identical to each other.  This header is one
+ * implementation, compiled by gcc for the CPU oracle ("detmath" build) and by hipcc for gfx950:
+ *
+ *   - only IEEE-754 binary64 +,-,*,/,sqrt and EXPLICIT fma() are used;
+ *   - both compilers must be run with -ffp-contract=off (no implicit fusing) and no fast-math;
+ *   - no tables, no data-dependent branches in the fast paths (selects only) — wave-friendly.
+ *
+ * Accuracy (checked in tests/test_detmath.py against libm): exp, sin, cos, atan <= 2 ulp,
+ * tan <= 4 ulp on the solver's working ranges.  Domain: |x| <= 2^30 for the trigonometric
+ * functions (beyond that, and for non-finite input, they return NaN on both sides).
+ *
+ * The polynomial kernels use the classic fdlibm minimax coefficient sets (public constants).
+ */
+#ifndef CILQR_DETMATH_H
+#define CILQR_DETMATH_H
+
+#if defined(__HIPCC__)
+#define DM_FN __host__ __device__ static inline
+#else
+#define DM_FN static inline
+#endif
+
+#define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+DM_FN double dm_from_bits(unsigned long long u) {
+    double d;
+    __builtin_memcpy(&d, &u, sizeof(d));
+    return d;
+}
+
+DM_FN unsigned long long dm_to_bits(double d) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &d, sizeof(u));
+    return u;
+}
+
+DM_FN double dm_nan(void) { return dm_from_bits(0x7ff8000000000000ULL); }
+DM_FN double dm_inf(void) { return dm_from_bits(0x7ff0000000000000ULL); }
+
+/* 2^k for k in [-1022, 1023] */
+DM_FN double dm_pow2i(int k) { return dm_from_bits((unsigned long long)(k + 1023) << 52); }
+
+DM_FN double dm_sqrt(double x) { return __builtin_sqrt(x); }
+
+/* reference call sites use hypot() from libm (src/cilqr_solver.cpp:237,299,509,528);
+ * magnitudes here are metres, so the naive form neither overflows nor underflows. */
+DM_FN double dm_hypot(double x, double y) { return dm_sqrt(x * x + y * y); }
+
+DM_FN double dm_exp(double x) {
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2HI = 6.93147180369123816490e-01; /* 32 trailing zero bits */
+    const double LN2LO = 1.90821492927058770002e-10;
+    const double MAGIC = 6755399441055744.0; /* 1.5 * 2^52: round-to-nearest-even integer */
+    /* clamp so the integer part stays small; results for clamped inputs are fixed up below */
+    double xc = x;
+    xc = (xc > 720.0) ? 720.0 : xc;
+    xc = (xc < -760.0) ? -760.0 : xc;
+    double kd = (xc * LOG2E + MAGIC) - MAGIC;
+    double r = DM_FMA(-kd, LN2HI, xc);
+    r = DM_FMA(-kd, LN2LO, r);
+    /* exp(r), |r| <= 0.3466: Taylor to r^13 (remainder < 5e-18 relative) */
+    double p = 1.6059043836821613e-10;            /* 1/13! */
+    p = DM_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
+    p = DM_FMA(p, r, 2.505210838544172e-08);      /* 1/11! */
+    p = DM_FMA(p, r, 2.755731922398589e-07);      /* 1/10! */
+    p = DM_FMA(p, r, 2.7557319223985893e-06);     /* 1/9!  */
+    p = DM_FMA(p, r, 2.48015873015873e-05);       /* 1/8!  */
+    p = DM_FMA(p, r, 1.984126984126984e-04);      /* 1/7!  */
+    p = DM_FMA(p, r, 1.388888888888889e-03);      /* 1/6!  */
+    p = DM_FMA(p, r, 8.333333333333333e-03);      /* 1/5!  */
+    p = DM_FMA(p, r, 4.1666666666666664e-02);     /* 1/4!  */
+    p = DM_FMA(p, r, 1.6666666666666666e-01);     /* 1/3!  */
+    p = DM_FMA(p, r, 0.5);
+    p = DM_FMA(p, r, 1.0);
+    p = DM_FMA(p, r, 1.0);
+    int k = (int)kd;
+    int k1 = k >> 1;
+    int k2 = k - k1;
+    double res = (p * dm_pow2i(k1)) * dm_pow2i(k2);
+    res = (x > 709.782712893384) ? dm_inf() : res;
+    res = (x < -745.1332191019412) ? 0.0 : res;
+    res = (x != x) ? x : res;
+    return res;
+}
+
+/* ---- trigonometric range reduction: x = n*(pi/2) + r, |r| <= pi/4 (+eps) ---- */
+DM_FN double dm_trig_reduce(double x, int* quadrant, int* valid) {
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+    const double P2 = 6.07710050630396597660e-11;  /* next 33 bits */
+    const double P3 = 2.02226624871116645580e-21;  /* next 33 bits */
+    const double P4 = 8.47842766036889956997e-32;  /* remainder */
+    const double MAGIC = 6755399441055744.0;
+    double ax = (x < 0.0) ? -x : x;
+    int ok = (ax <= 1073741824.0); /* false for NaN and inf too */
+    double xs = ok ? x : 0.0;
+    double nd = (xs * INV_PIO2 + MAGIC) - MAGIC;
+    double r = DM_FMA(-nd, P1, xs);
+    r = DM_FMA(-nd, P2, r);
+    r = DM_FMA(-nd, P3, r);
+    r = DM_FMA(-nd, P4, r);
+    *quadrant = (int)((long long)nd & 3LL);
+    *valid = ok;
+    return r;
+}
+
+DM_FN double dm_ksin(double r) {
+    const double S1 = -1.66666666666666324348e-01;
+    const double S2 = 8.33333333332248946124e-03;
+    const double S3 = -1.98412698298579493134e-04;
+    const double S4 = 2.75573137070700676789e-06;
+    const double S5 = -2.50507602534068634195e-08;
+    const double S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = DM_FMA(z, S6, S5);
+    p = DM_FMA(z, p, S4);
+    p = DM_FMA(z, p, S3);
+    p = DM_FMA(z, p, S2);
+    p = DM_FMA(z, p, S1);
+    double v = z * r;
+    return DM_FMA(v, p, r);
+}
+
+DM_FN double dm_kcos(double r) {
+    const double C1 = 4.16666666666666019037e-02;
+    const double C2 = -1.38888888888741095749e-03;
+    const double C3 = 2.48015872894767294178e-05;
+    const double C4 = -2.75573143513906633035e-07;
+    const double C5 = 2.08757232129817482790e-09;
+    const double C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = DM_FMA(z, C6, C5);
+    p = DM_FMA(z, p, C4);
+    p = DM_FMA(z, p, C3);
+    p = DM_FMA(z, p, C2);
+    p = DM_FMA(z, p, C1);
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    double t = z * p;
+    return w + (((1.0 - w) - hz) + z * t);
+}
+
+DM_FN void dm_sincos(double x, double* s_out, double* c_out) {
+    int q, ok;
+    double r = dm_trig_reduce(x, &q, &ok);
+    double s = dm_ksin(r);
+    double c = dm_kcos(r);
+    double ss = (q & 1) ? c : s;
+    double cc = (q & 1) ? s : c;
+    ss = (q & 2) ? -ss : ss;
+    cc = ((q + 1) & 2) ? -cc : cc;
+    *s_out = ok ? ss : dm_nan();
+    *c_out = ok ? cc : dm_nan();
+}
+
+DM_FN double dm_sin(double x) {
+    double s, c;
+    dm_sincos(x, &s, &c);
+    return s;
+}
+
+DM_FN double dm_cos(double x) {
+    double s, c;
+    dm_sincos(x, &s, &c);
+    return c;
+}
+
+DM_FN double dm_tan(double x) {
+    int q, ok;
+    double r = dm_trig_reduce(x, &q, &ok);
+    double s = dm_ksin(r);
+    double c = dm_kcos(r);
+    double num = (q & 1) ? -c : s;
+    double den = (q & 1) ? s : c;
+    double t = num / den;
+    return ok ? t : dm_nan();
+}
+
+DM_FN double dm_atan(double x) {
+    const double aT0 = 3.33333333333329318027e-01;
+    const double aT1 = -1.99999999998764832476e-01;
+    const double aT2 = 1.42857142725034663711e-01;
+    const double aT3 = -1.11111104054623557880e-01;
+    const double aT4 = 9.09088713343650656196e-02;
+    const double aT5 = -7.69187620504482999495e-02;
+    const double aT6 = 6.66107313738753120669e-02;
+    const double aT7 = -5.83357013379057348645e-02;
+    const double aT8 = 4.97687799461593236017e-02;
+    const double aT9 = -3.65315727442169155270e-02;
+    const double aT10 = 1.62858201153657823623e-02;
+    double ax = (x < 0.0) ? -x : x;
+    /* interval selection (fdlibm s_atan.c): 7/16, 11/16, 19/16, 39/16 */
+    int id = -1;
+    id = (ax >= 0.4375) ? 0 : id;
+    id = (ax >= 0.6875) ? 1 : id;
+    id = (ax >= 1.1875) ? 2 : id;
+    id = (ax >= 2.4375) ? 3 : id;
+    double num = ax, den = 1.0, hi = 0.0, lo = 0.0;
+    num = (id == 0) ? (2.0 * ax - 1.0) : num;
+    den = (id == 0) ? (2.0 + ax) : den;
+    hi = (id == 0) ? 4.63647609000806093515e-01 : hi;
+    lo = (id == 0) ? 2.26987774529616870924e-17 : lo;
+    num = (id == 1) ? (ax - 1.0) : num;
+    den = (id == 1) ? (ax + 1.0) : den;
+    hi = (id == 1) ? 7.85398163397448278999e-01 : hi;
+    lo = (id == 1) ? 3.06161699786838301793e-17 : lo;
+    num = (id == 2) ? (ax - 1.5) : num;
+    den = (id == 2) ? (1.0 + 1.5 * ax) : den;
+    hi = (id == 2) ? 9.82793723247329054082e-01 : hi;
+    lo = (id == 2) ? 1.39033110312309984516e-17 : lo;
+    num = (id == 3) ? -1.0 : num;
+    den = (id == 3) ? ax : den;
+    hi = (id == 3) ? 1.57079632679489655800e+00 : hi;
+    lo = (id == 3) ? 6.12323399573676603587e-17 : lo;
+    double t = num / den; /* for id == -1 this is ax / 1.0 == ax exactly */
+    double z = t * t;
+    double w = z * z;
+    double s1 = DM_FMA(w, aT10, aT8);
+    s1 = DM_FMA(w, s1, aT6);
+    s1 = DM_FMA(w, s1, aT4);
+    s1 = DM_FMA(w, s1, aT2);
+    s1 = DM_FMA(w, s1, aT0);
+    s1 = z * s1;
+    double s2 = DM_FMA(w, aT9, aT7);
+    s2 = DM_FMA(w, s2, aT5);
+    s2 = DM_FMA(w, s2, aT3);
+    s2 = DM_FMA(w, s2, aT1);
+    s2 = w * s2;
+    double corr = t * (s1 + s2);
+    double res = (id < 0) ? (t - corr) : (hi - ((corr - lo) - t));
+    res = (ax > 1.0e300) ? 1.57079632679489655800e+00 : res; /* incl. +-inf: 1/inf -> 0 handled too */
+    res = (x < 0.0) ? -res : res;
+    return (x != x) ? x : res;
+}
+
+#endif /* CILQR_DETMATH_H */

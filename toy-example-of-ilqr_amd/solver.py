@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's solver interface on top of the C-ABI.
+
+``CILQRSolver`` keeps the call shape of the reference class
+(/root/reference/include/cilqr_solver.hpp:31-41: ctor from a config, ``solve(x0, ref_waypoints,
+ref_velo, obs_preds, road_boaders) -> (u, x)``) for one ego vehicle; ``BatchedCILQR`` is the batch
+form of the same call that the HIP kernels are built for.  All compute happens in
+libcilqr_amd.so on the GPU — there is no CPU fallback here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CilqrParams, CilqrScenarioDesc, RESULT_DTYPE, TRACE_DTYPE, check)
+from .config import copy_params, params_from_config
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SceneTable:
+    """Host arrays of one solve() argument set: lane samples, obstacle routes, borders, ref_velo."""
+
+    def __init__(self, lane_x, lane_y, lane_yaw, obstacles, road_borders, ref_velo):
+        self.lane_x = _f64(lane_x)
+        self.lane_y = _f64(lane_y)
+        self.lane_yaw = _f64(lane_yaw)
+        obs = np.zeros((0, 1, 3)) if obstacles is None else _f64(obstacles)
+        if obs.ndim != 3 or obs.shape[2] != 3:
+            raise ValueError("obstacles must be [M][T][3]")
+        self.obs = obs
+        self.road_borders = _f64(road_borders)
+        self.ref_velo = float(ref_velo)
+
+    @classmethod
+    def from_scenario(cls, sc):
+        ln = sc.lane
+        return cls(ln.x, ln.y, ln.yaw, sc.obstacles, sc.road_borders, sc.target_velocity)
+
+    def desc(self):
+        d = CilqrScenarioDesc()
+        dp = C.POINTER(C.c_double)
+        d.lane_x = self.lane_x.ctypes.data_as(dp)
+        d.lane_y = self.lane_y.ctypes.data_as(dp)
+        d.lane_yaw = self.lane_yaw.ctypes.data_as(dp)
+        d.L = self.lane_x.shape[0]
+        d.M = self.obs.shape[0]
+        d.obs = self.obs.ctypes.data_as(dp) if self.obs.shape[0] else None
+        d.T = self.obs.shape[1] if self.obs.shape[0] else 0
+        d.road_borders[0] = float(self.road_borders[0])
+        d.road_borders[1] = float(self.road_borders[1])
+        d.ref_velo = self.ref_velo
+        return d
+
+
+class BatchedCILQR:
+    """A device handle with its parameter table and scenario tables; batch entry points."""
+
+    def __init__(self, params, scenes, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.cilqr_create(int(device), C.byref(self._h)), "cilqr_create")
+        self.device = int(device)
+        self.set_params(params)
+        self.set_scenarios(scenes)
+
+    # -- tables -------------------------------------------------------------------------------
+    def set_params(self, params):
+        plist = list(params) if isinstance(params, (list, tuple)) else [params]
+        arr = (CilqrParams * len(plist))(*[copy_params(p) for p in plist])
+        check(self._lib.cilqr_set_params(self._h, arr, len(plist)), "cilqr_set_params")
+        self.params = plist
+        self.N = int(plist[0].N)
+
+    def set_scenarios(self, scenes):
+        slist = list(scenes) if isinstance(scenes, (list, tuple)) else [scenes]
+        self._scenes = slist  # keep host arrays alive during the upload
+        arr = (CilqrScenarioDesc * len(slist))(*[s.desc() for s in slist])
+        check(self._lib.cilqr_set_scenarios(self._h, arr, len(slist)), "cilqr_set_scenarios")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.cilqr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the path ------------------------------------------------------------------------------
+    def solve_batch(self, x0, scenario_id=None, param_id=None, tick=None, last_u=None, trace_cap=0):
+        """CILQRSolver::solve for B trajectories.  Returns dict(u, x, res[, trace])."""
+        x0 = _f64(x0).reshape(-1, 4)
+        B, N = x0.shape[0], self.N
+        sid, pid, tk = _i32(scenario_id), _i32(param_id), _i32(tick)
+        lu = None if last_u is None else _f64(last_u).reshape(B, N, 2)
+        u = np.empty((B, N, 2))
+        x = np.empty((B, N + 1, 4))
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        trace = np.zeros((B, trace_cap), dtype=TRACE_DTYPE) if trace_cap > 0 else None
+        check(self._lib.cilqr_solve_batch(self._h, B, _p(x0), _p(sid), _p(pid), _p(tk), _p(lu), _p(u), _p(x),
+                                          _p(res), _p(trace), int(trace_cap)), "cilqr_solve_batch")
+        out = {"u": u, "x": x, "res": res}
+        if trace is not None:
+            out["trace"] = trace
+        return out
+
+    def solve_batch_device(self, B, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u, d_x, d_res,
+                           d_trace=0, trace_cap=0, stream=0):
+        """Raw device-pointer form (ints): enqueue on `stream`, no synchronisation."""
+        check(self._lib.cilqr_solve_batch_device(self._h, int(B), d_x0, d_scenario_id or None, d_param_id or None,
+                                                 d_tick or None, d_last_u or None, d_u, d_x, d_res or None,
+                                                 d_trace or None, int(trace_cap), stream or None),
+              "cilqr_solve_batch_device")
+
+    def set_timing(self, on=True):
+        check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        check(self._lib.cilqr_last_kernel_ms(self._h, C.byref(ms)), "cilqr_last_kernel_ms")
+        return float(ms.value)
+
+    # -- pieces --------------------------------------------------------------------------------
+    def init_traj(self, x0, param_id=None):
+        x0 = _f64(x0).reshape(-1, 4)
+        B = x0.shape[0]
+        x = np.empty((B, self.N + 1, 4))
+        check(self._lib.cilqr_init_traj_batch(self._h, B, _p(x0), _p(_i32(param_id)), _p(x)), "cilqr_init_traj_batch")
+        return x
+
+    def ref_points(self, x, scenario_id=None, param_id=None):
+        x = _f64(x).reshape(-1, self.N + 1, 4)
+        B = x.shape[0]
+        ref = np.empty((B, self.N + 1, 3))
+        idx = np.empty((B, self.N + 1), dtype=np.int32)
+        check(self._lib.cilqr_ref_points_batch(self._h, B, _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
+                                               _p(ref), _p(idx)), "cilqr_ref_points_batch")
+        return ref, idx
+
+    def total_cost(self, u, x, scenario_id=None, param_id=None, tick=None):
+        u = _f64(u).reshape(-1, self.N, 2)
+        x = _f64(x).reshape(-1, self.N + 1, 4)
+        B = x.shape[0]
+        J = np.empty(B)
+        check(self._lib.cilqr_total_cost_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
+                                               _p(_i32(tick)), _p(J)), "cilqr_total_cost_batch")
+        return J
+
+    def forward_pass(self, u, x, d, K, scenario_id=None, param_id=None, tick=None, n_alpha=_lib.MAX_ALPHA_TRIALS):
+        N = self.N
+        u = _f64(u).reshape(-1, N, 2)
+        x = _f64(x).reshape(-1, N + 1, 4)
+        d = _f64(d).reshape(-1, N, 2)
+        K = _f64(K).reshape(-1, N, 2, 4)
+        B = x.shape[0]
+        nu = np.empty((B, n_alpha, N, 2))
+        nx = np.empty((B, n_alpha, N + 1, 4))
+        J = np.empty((B, n_alpha))
+        check(self._lib.cilqr_forward_pass_batch(self._h, B, _p(u), _p(x), _p(d), _p(K), _p(_i32(scenario_id)),
+                                                 _p(_i32(param_id)), _p(_i32(tick)), int(n_alpha), _p(nu), _p(nx),
+                                                 _p(J)), "cilqr_forward_pass_batch")
+        return nu, nx, J
+
+    def cost_derivatives(self, u, x, scenario_id=None, param_id=None, tick=None):
+        N = self.N
+        u = _f64(u).reshape(-1, N, 2)
+        x = _f64(x).reshape(-1, N + 1, 4)
+        B = x.shape[0]
+        out = {"l_x": np.empty((B, N + 1, 4)), "l_u": np.empty((B, N, 2)), "l_xx": np.empty((B, N + 1, 4, 4)),
+               "l_uu": np.empty((B, N, 2, 2)), "A": np.empty((B, N, 4, 4)), "B": np.empty((B, N, 4, 2))}
+        check(self._lib.cilqr_cost_derivatives_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)),
+                                                     _p(_i32(param_id)), _p(_i32(tick)), _p(out["l_x"]),
+                                                     _p(out["l_u"]), _p(out["l_xx"]), _p(out["l_uu"]), _p(out["A"]),
+                                                     _p(out["B"])), "cilqr_cost_derivatives_batch")
+        return out
+
+    def backward_pass(self, u, x, lamb, scenario_id=None, param_id=None, tick=None):
+        N = self.N
+        u = _f64(u).reshape(-1, N, 2)
+        x = _f64(x).reshape(-1, N + 1, 4)
+        B = x.shape[0]
+        lamb = _f64(np.broadcast_to(np.asarray(lamb, dtype=np.float64), (B,)))
+        d = np.empty((B, N, 2))
+        K = np.empty((B, N, 2, 4))
+        dV = np.empty((B, 2))
+        status = np.empty(B, dtype=np.int32)
+        check(self._lib.cilqr_backward_pass_batch(self._h, B, _p(u), _p(x), _p(lamb), _p(_i32(scenario_id)),
+                                                  _p(_i32(param_id)), _p(_i32(tick)), _p(d), _p(K), _p(dV),
+                                                  _p(status)), "cilqr_backward_pass_batch")
+        return d, K, dV, status
+
+    def detmath(self, func, x, y=None):
+        x = _f64(x).ravel()
+        y = None if y is None else _f64(y).ravel()
+        out = np.empty_like(x)
+        check(self._lib.cilqr_detmath_eval(self._h, int(func), _p(x), _p(y), x.shape[0], _p(out)), "cilqr_detmath_eval")
+        return out
+
+
+class CILQRSolver:
+    """Drop-in counterpart of the reference class for ONE ego vehicle (B = 1 per call).
+
+    ``CILQRSolver(config)`` then ``solve(x0, ref_waypoints, ref_velo, obs_preds, road_boaders)``
+    returning ``(u[N][2], x[N+1][4])`` as in include/cilqr_solver.hpp:34-41.  State carried across
+    calls as upstream: ``is_first_solve`` / ``last_solve_u`` for ``use_last_solution`` (cs:97-102,144).
+    ``obs_preds`` is a list of objects with x/y/yaw arrays, or an array [M][>=N+1][3], holding the
+    obstacle predictions from the current tick on (what utils::get_sub_routing_lines returns).
+    """
+
+    def __init__(self, config, device=0, **param_overrides):
+        self.params = params_from_config(config, **param_overrides)
+        self.device = device
+        self.is_first_solve = True
+        self.last_solve_u = None
+        self.last_result = None
+        self._engine = None
+
+    def solve(self, x0, ref_waypoints, ref_velo, obs_preds, road_boaders):
+        if isinstance(obs_preds, np.ndarray):
+            obs = obs_preds
+        elif len(obs_preds) == 0:
+            obs = None
+        else:
+            obs = np.stack([np.stack([np.asarray(r.x), np.asarray(r.y), np.asarray(r.yaw)], axis=1)
+                            for r in obs_preds])
+        scene = SceneTable(ref_waypoints.x, ref_waypoints.y, ref_waypoints.yaw, obs, road_boaders, ref_velo)
+        if self._engine is None:
+            self._engine = BatchedCILQR(self.params, scene, self.device)
+        else:
+            self._engine.set_scenarios(scene)
+        warm = (not self.is_first_solve) and bool(self.params.use_last_solution)
+        out = self._engine.solve_batch(np.asarray(x0, dtype=np.float64).reshape(1, 4),
+                                       last_u=self.last_solve_u[None] if warm else None)
+        self.is_first_solve = False
+        self.last_solve_u = out["u"][0].copy()
+        self.last_result = out["res"][0]
+        return out["u"][0], out["x"][0]
