@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched CILQR solve path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path — one cilqr_solve_batch_device call, i.e. CILQRSolver::solve
+for every trajectory of the batch — over one batch of synthetic input that is already resident in
+HBM.  Workload at N = 1: BASELINE.json configs[1] (batch = 1024 synthetic straight-lane scenarios,
+horizon 50).  With N GPUs every rank solves its own 1024-trajectory shard of a 1024*N batch (weak
+scaling, no data-path collective; RCCL only reduces the statistics afterwards).
+
+metric = iLQR iterations/s = (sum over trajectories of executed iterations of the loop at
+/root/reference/src/cilqr_solver.cpp:110) * steps / wall time, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration (default 2 = configs[1], the headline)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the configuration's own)")
+    ap.add_argument("--horizon", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank, world):
+    wl = pkg.workloads
+    if cfg_id == 2:
+        B = per_gpu_batch or 1024
+        return wl.config2(B=B, N=horizon or 50, first=rank * B), B
+    if cfg_id == 3:
+        B = per_gpu_batch or 8192
+        return wl.config3(B=B, N=horizon or 50, first=rank * B), B
+    if cfg_id == 4:
+        B = per_gpu_batch or 8192
+        return wl.config4(B=B, N=horizon or 100, first=rank * B), B
+    Bb = per_gpu_batch or 4096
+    return wl.config5(B_base=Bb, N=horizon or 50, first=rank * Bb), Bb * 16
+
+
+def cpu_baseline(pkg, wl, threads):
+    """The oracle (CPU restatement of the reference path, glibc libm build, -O3 -ffp-contract=off)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle, Scene
+    orc = Oracle("libm")
+    scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
+    nb = min(wl.B, 1024)
+    x0, sid, pid, tk = wl.x0[:nb], wl.scenario_id[:nb], wl.param_id[:nb], wl.tick[:nb]
+    # single thread on a 128-trajectory sub-sample
+    n1 = min(nb, 128)
+    t = time.perf_counter()
+    r1 = orc.solve_batch(wl.params, scenes, x0[:n1], sid[:n1], pid[:n1], tk[:n1], n_threads=1)
+    t1 = time.perf_counter() - t
+    one_core = float(r1["res"]["iters"].sum()) / t1
+    # all threads: repeat the sample until ~10-30 s of CPU work have been spent
+    reps, best = 0, None
+    cpu_work, t_all0 = 0.0, time.perf_counter()
+    while reps < 3 or (cpu_work < 12.0 and time.perf_counter() - t_all0 < 20.0):
+        t = time.perf_counter()
+        r = orc.solve_batch(wl.params, scenes, x0, sid, pid, tk, n_threads=threads)
+        dt = time.perf_counter() - t
+        cpu_work += float(r["res"]["iters"].sum()) / one_core
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    its = float(r["res"]["iters"].sum())
+    return {"value": its / best, "unit": "iLQR iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{nb} trajectories of {wl.name}, cold-start solves, OpenMP over trajectories, "
+                      f"best of {reps} passes (~{cpu_work:.0f} s of single-core work)",
+            "one_core_value": one_core, "math": "glibc libm", "flags": "-O3 -ffp-contract=off"}, r
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the CILQR solve path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    import cilqr_amd as pkg
+
+    wl, B = make_workload(pkg, args.config, args.batch, args.horizon, rank, world)
+    N = wl.N
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes, device=local_rank)
+    dev = torch.device("cuda", local_rank)
+    d_x0 = torch.from_numpy(wl.x0).to(dev)
+    d_sid = torch.from_numpy(wl.scenario_id).to(dev)
+    d_pid = torch.from_numpy(wl.param_id).to(dev)
+    d_tick = torch.from_numpy(wl.tick).to(dev)
+    d_u = torch.empty((B, N, 2), dtype=torch.float64, device=dev)
+    d_x = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
+    d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        eng.solve_batch_device(B, d_x0.data_ptr(), d_sid.data_ptr(), d_pid.data_ptr(), d_tick.data_ptr(), 0,
+                               d_u.data_ptr(), d_x.data_ptr(), d_res.data_ptr(), 0, 0, stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record(stream)
+        step()
+        ev1[i].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+    M_of = wl.M_of
+    stats = np.array([res["iters"].sum(), res["ls_trials"].sum(), (res["end_reason"] == 0).sum(),
+                      (res["end_reason"] == 1).sum(), (res["end_reason"] == 2).sum(),
+                      np.nansum(res["J_final"]), np.isnan(res["J_final"]).sum(),
+                      float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum()), B], dtype=np.float64)
+    tmax = elapsed
+    if dist is not None:
+        ts = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        tmax = float(ts.item())
+        st = torch.from_numpy(stats).to(dev)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        stats = st.cpu().numpy()
+    total_iters, total_trials = stats[0], stats[1]
+    value = total_iters * args.steps / tmax
+
+    if rank == 0:
+        my_iters = float(res["iters"].sum())
+        alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
+        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "iLQR iterations/sec (batch x horizon)", "value": value, "unit": "iLQR iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name, "baseline_config": args.config, "batch_per_gpu": B,
+                       "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
+                       "parallelism": f"trajectory-sharded x{world}, one wavefront per trajectory"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_solve", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"},
+            "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
+                      "line_search_trials_per_step": float(total_trials),
+                      "solves_per_s": stats[8] * args.steps / tmax,
+                      "step_updates_per_s": value * N,
+                      "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
+                      "nan_costs": int(stats[6]), "sum_J_final": float(stats[5])},
+        }
+        if not args.no_cpu_baseline:
+            threads = args.cpu_threads or (os.cpu_count() or 1)
+            cb, r = cpu_baseline(pkg, wl, threads)
+            out["cpu_baseline"] = cb
+            # parity of the run that was just timed (the oracle is only the checker here)
+            nb = r["res"].shape[0]
+            out["extra"]["cpu_check"] = {
+                "trajectories": nb,
+                "same_iterations": int((r["res"]["iters"] == res["iters"][:nb]).sum()),
+                "max_abs_dJ_final": float(np.nanmax(np.abs(r["res"]["J_final"] - res["J_final"][:nb]))),
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
