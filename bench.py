@@ -143,18 +143,9 @@ def main():
 
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
     M_of = wl.M_of
-    stats = np.array([res["iters"].sum(), res["ls_trials"].sum(), (res["end_reason"] == 0).sum(),
-                      (res["end_reason"] == 1).sum(), (res["end_reason"] == 2).sum(),
-                      np.nansum(res["J_final"]), np.isnan(res["J_final"]).sum(),
-                      float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum()), B], dtype=np.float64)
-    tmax = elapsed
-    if dist is not None:
-        ts = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        tmax = float(ts.item())
-        st = torch.from_numpy(stats).to(dev)
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        stats = st.cpu().numpy()
+    from importlib import import_module
+    st_mod = import_module("toy-example-of-ilqr_amd.stats")
+    stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, M_of), elapsed, dist, dev if dist is not None else None)
     total_iters, total_trials = stats[0], stats[1]
     value = total_iters * args.steps / tmax
 

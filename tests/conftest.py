@@ -21,6 +21,8 @@ def built():
     import importlib
     build = importlib.import_module("toy-example-of-ilqr_amd.build")
     build.build_all()
+    import oracle
+    oracle.ensure_built()
     return True
 
 

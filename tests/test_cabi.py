@@ -1,0 +1,91 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/cilqr_amd.h declares
+(no compute calls here); the product path fails loudly without a GPU / without the library."""
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "cilqr_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cilqr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(pkg):
+    lib = ctypes.CDLL(str(pkg._lib.LIB_PATH))
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cilqr_amd.h but not exported"
+    assert set(names) == set(pkg._lib.SIGNATURES), set(names) ^ set(pkg._lib.SIGNATURES)
+
+
+def test_struct_layouts_match_header(pkg, built):
+    """ctypes mirrors vs the C compiler's view of the structs."""
+    import subprocess, tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "cilqr_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(cilqr_params), offsetof(cilqr_params, dt), offsetof(cilqr_params, d_safe),
+         sizeof(cilqr_scenario_desc), offsetof(cilqr_scenario_desc, road_borders), sizeof(cilqr_result), sizeof(cilqr_trace_rec));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        c = pathlib.Path(td) / "t.c"
+        c.write_text(src)
+        exe = pathlib.Path(td) / "t"
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
+        got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    L = pkg._lib
+    want = [ctypes.sizeof(L.CilqrParams), L.CilqrParams.dt.offset, L.CilqrParams.d_safe.offset,
+            ctypes.sizeof(L.CilqrScenarioDesc), L.CilqrScenarioDesc.road_borders.offset,
+            ctypes.sizeof(L.CilqrResult), ctypes.sizeof(L.CilqrTraceRec)]
+    assert got == want
+
+
+def test_oracle_params_layout_matches(pkg, built):
+    from oracle import OrcParams
+    assert ctypes.sizeof(OrcParams) == ctypes.sizeof(pkg.CilqrParams)
+    assert [f[0] for f in OrcParams._fields_] == [f[0] for f in pkg.CilqrParams._fields_]
+
+
+def test_no_gpu_is_a_loud_error(pkg, gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is visible")
+    h = ctypes.c_void_p()
+    rc = pkg._lib.load().cilqr_create(0, ctypes.byref(h))
+    assert rc == pkg._lib.ERR_NO_DEVICE
+    cfg = pkg.GlobalConfig.get_instance("two_straight")
+    sc = pkg.build_scenario(cfg)
+    with pytest.raises(pkg.CilqrError):
+        pkg.BatchedCILQR(pkg.params_from_config(cfg), pkg.SceneTable.from_scenario(sc))
+
+
+def test_product_never_imports_the_oracle():
+    """the shipped path may mention the oracle in comments, but never include / import / load it"""
+    pkg_dir = ROOT / "toy-example-of-ilqr_amd"
+    for path in list(pkg_dir.rglob("*.h*")) + list(pkg_dir.rglob("*.cpp")) + list(pkg_dir.rglob("*.hip")):
+        for line in path.read_text().splitlines():
+            if line.lstrip().startswith("#include"):
+                assert "oracle" not in line, (path, line)
+    for path in list(pkg_dir.rglob("*.py")) + [ROOT / "cilqr_amd.py"]:
+        text = path.read_text()
+        for needle in ("liboracle", "from oracle", "import oracle", "oracle."):
+            assert needle not in text, (path, needle)
+
+
+def test_config_mirror(pkg):
+    cfg = pkg.GlobalConfig.get_instance("three_straight")
+    assert cfg.get_config("lqr/N", int) == 30 and cfg.has_key("vehicle/wheelbase")
+    assert cfg.get_config("vehicle/reference_point", str) == "gravity_center"  # default of global_config.cpp:54-55
+    assert cfg.get_config("no/such/key", float) == 0.0  # typed getter returns T() on a miss
+    p = pkg.params_from_config(cfg, N=50)
+    assert p.N == 50 and p.use_last_solution == 1 and p.reference_point == 1 and p.solve_type == 0
+    p2 = pkg.params_from_config(pkg.GlobalConfig.get_instance("two_straight"))
+    assert p2.reference_point == 0 and p2.stl_lim == 0.12 and p2.w_stl == 20.0

@@ -1,0 +1,154 @@
+"""Self-consistency of the CPU oracle: analytic gradients vs finite differences of its own cost,
+solve-level numbers against the survey's independent NumPy reading of the C++,
+libm vs detmath builds, and algorithmic invariants."""
+import numpy as np
+import pytest
+
+from conftest import oracle_scene
+
+
+def rollout(orc, p, x0, u):
+    x = np.zeros((p.N + 1, 4))
+    x[0] = x0
+    for i in range(p.N):
+        x[i + 1] = orc.propagate(x[i], u[i], p.dt, p.wheelbase, p.reference_point)
+    return x
+
+
+@pytest.mark.parametrize("name", ["two_straight", "three_bend"])
+def test_cost_gradients_match_finite_differences(pkg, orc_libm, scenarios, name):
+    cfg, sc = scenarios[name]
+    p = pkg.params_from_config(cfg, N=20)
+    scene = oracle_scene(sc)
+    s = orc_libm.solver(p)
+    rng = np.random.default_rng(4)
+    x0 = sc.ego_state + np.array([1.3, 0.4, 0.2, 0.01])
+    u = np.stack([rng.normal(0, 0.5, p.N), rng.normal(0, 0.02, p.N)], axis=1)
+    x = rollout(orc_libm, p, x0, u)
+    d = s.cost_derivatives(u, x, scene)
+    h = 1e-6
+    # nearest-sample reference points are piecewise constant, so central differences see the same ones
+    for k in (1, 7, p.N):
+        for j in range(4):
+            xp, xm = x.copy(), x.copy()
+            xp[k, j] += h
+            xm[k, j] -= h
+            fd = (s.total_cost(u, xp, scene) - s.total_cost(u, xm, scene)) / (2 * h)
+            assert abs(fd - d["l_x"][k, j]) <= 1e-5 * max(1.0, abs(fd)), (k, j, fd, d["l_x"][k, j])
+    for k in (0, 5, p.N - 1):
+        for j in range(2):
+            up, um = u.copy(), u.copy()
+            up[k, j] += h
+            um[k, j] -= h
+            fd = (s.total_cost(up, x, scene) - s.total_cost(um, x, scene)) / (2 * h)
+            assert abs(fd - d["l_u"][k, j]) <= 1e-5 * max(1.0, abs(fd)), (k, j)
+    # Hessians are Gauss-Newton style: symmetric positive semi-definite
+    for k in range(p.N + 1):
+        H = d["l_xx"][k]
+        np.testing.assert_array_equal(H, H.T)
+        assert np.linalg.eigvalsh(H).min() >= -1e-9
+
+
+def test_model_jacobian_quirk(orc_libm):
+    """df/dx matches finite differences; df/d(steer) of the CoG model deliberately does NOT exactly
+    (ut:291 uses atan(tan(delta/2)), the dynamics atan(tan(delta)/2)) — SURVEY quirk 1."""
+    dt, wb = 0.1, 2.8
+    x = np.array([3.0, 1.0, 7.0, 0.3])
+    u = np.array([0.5, 0.15])
+    for rp in (0, 1):
+        A, B = orc_libm.model_derivatives(np.stack([x, x]), u[None], dt, wb, 1, rp)
+        h = 1e-6
+        for j in range(4):
+            xp, xm = x.copy(), x.copy()
+            xp[j] += h
+            xm[j] -= h
+            fd = (orc_libm.propagate(xp, u, dt, wb, rp) - orc_libm.propagate(xm, u, dt, wb, rp)) / (2 * h)
+            if not (rp == 1 and j in (2, 3)):
+                np.testing.assert_allclose(A[0][:, j], fd, atol=2e-6)
+        up, um = u.copy(), u.copy()
+        up[0] += h
+        um[0] -= h
+        fd = (orc_libm.propagate(x, up, dt, wb, rp) - orc_libm.propagate(x, um, dt, wb, rp)) / (2 * h)
+        np.testing.assert_allclose(B[0][:, 0], fd, atol=1e-8)
+
+
+SURVEY_NUMBERS = [  # (scenario, N) -> iters, end_reason, J_init, J_final  (SURVEY.md §8(c) sanity ranges)
+    ("two_straight", 30, 21, 1, 133.12, 130.32),
+    ("two_straight", 50, 17, 0, 6777.36, 341.08),
+    ("three_bend", 30, 33, 1, 595.15, 237.92),
+    ("three_bend", 50, 15, 0, 986.46, 393.82),
+]
+
+
+@pytest.mark.parametrize("name,N,iters,end,J0,J1", SURVEY_NUMBERS)
+def test_yaml_start_solves_match_survey_probe(pkg, orc_libm, orc_det, scenarios, name, N, iters, end, J0, J1):
+    cfg, sc = scenarios[name]
+    p = pkg.params_from_config(cfg, N=N)
+    for orc in (orc_libm, orc_det):
+        r = orc.solver(p).solve(sc.ego_state, oracle_scene(sc))
+        assert r["res"]["iters"] == iters and r["res"]["end_reason"] == end
+        assert abs(r["res"]["J_init"] - J0) < 0.01 and abs(r["res"]["J_final"] - J1) < 0.01
+    if (name, N) == ("two_straight", 50):
+        np.testing.assert_allclose(r["u"][0], [-1.836, 0.0228], atol=1e-3)
+        assert (r["trace"]["alpha_idx"][:-1] == 0).all()  # "all alpha = 1"
+
+
+def test_decision_trace_invariants(pkg, orc_det, scenarios):
+    cfg, sc = scenarios["three_bend"]
+    p = pkg.params_from_config(cfg, N=30)
+    scene = oracle_scene(sc)
+    x0s = pkg.workloads.perturbed_starts(sc.ego_state, 24, 99)
+    s = orc_det.solver(p)
+    ends = set()
+    for x0 in x0s:
+        s.reset()
+        r = s.solve(x0, scene)
+        tr, res = r["trace"], r["res"]
+        ends.add(int(res["end_reason"]))
+        assert len(tr) == res["iters"] and res["ls_trials"] == tr["trials"].sum()
+        assert res["cost_evals"] == 1 + res["iters"] + res["ls_trials"]
+        J = res["J_init"]
+        lamb = p.init_lamb
+        for rec in tr:
+            if rec["accepted"] and rec["status"] in (0, 4):
+                assert rec["new_J"] < J  # cost is monotone on accepted steps
+                J = rec["new_J"]
+            if rec["status"] in (2, 3):
+                lamb = max(p.lamb_amplify, lamb * p.lamb_amplify)
+                assert rec["trials"] in (0, 20)
+            elif rec["status"] == 0:
+                lamb *= p.lamb_decay
+            assert rec["lamb"] == lamb
+        assert abs(res["J_final"] - J) < 1e-9 * max(1.0, abs(J))
+        assert res["J_final"] == s.total_cost(r["u"], r["x"], scene)
+        if res["end_reason"] == 1:
+            assert tr["lamb"][-1] > p.max_lamb
+    assert ends >= {0, 1}
+
+
+def test_libm_and_detmath_builds_agree_on_conditioned_starts(pkg, orc_libm, orc_det, scenarios):
+    cfg, sc = scenarios["two_straight"]
+    p = pkg.params_from_config(cfg, N=50)
+    scene = oracle_scene(sc)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 64, 0xC11A0002)
+    a = orc_libm.solve_batch(p, scene, x0, n_threads=4)
+    b = orc_det.solve_batch(p, scene, x0, n_threads=4)
+    same = a["res"]["iters"] == b["res"]["iters"]
+    assert same.mean() >= 0.9
+    assert np.abs(a["x"][same] - b["x"][same]).max() < 1e-5
+    assert np.abs(a["res"]["J_final"][same] - b["res"]["J_final"][same]).max() < 1e-5
+
+
+def test_warm_start_and_obstacle_horizon(pkg, orc_det, scenarios):
+    cfg, sc = scenarios["three_straight"]
+    p = pkg.params_from_config(cfg)
+    assert p.use_last_solution == 1
+    s = orc_det.solver(p)
+    r0 = s.solve(sc.ego_state, oracle_scene(sc, 0))
+    r1 = s.solve(r0["x"][1], oracle_scene(sc, 1))
+    s2 = orc_det.solver(p)
+    cold = s2.solve(r0["x"][1], oracle_scene(sc, 1))
+    assert r1["res"]["J_init"] != cold["res"]["J_init"]  # warm start: shifted previous controls
+    T = sc.routes.shape[1]
+    with pytest.raises(RuntimeError):
+        s.solve(sc.ego_state, oracle_scene(sc, T - 10))  # route shorter than tick + N + 1

@@ -1,5 +1,5 @@
-"""In-tree build of the native pieces: libcilqr_amd.so (hipcc, gfx950) and, for the tests,
-the CPU oracle (gcc).  Everything is compiled with -ffp-contract=off — parity depends on it."""
+"""In-tree build of libcilqr_amd.so (hipcc, gfx950).  Compiled with -ffp-contract=off — parity
+with the CPU restatement depends on it."""
 import os
 import pathlib
 import shutil
@@ -9,7 +9,6 @@ PKG = pathlib.Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcilqr_amd.so"
-ORACLE = ROOT / "oracle"
 
 HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
              "-Wno-unused-result"]
@@ -41,13 +40,5 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
-def build_oracle(force=False):
-    if force:
-        subprocess.run(["make", "-C", str(ORACLE), "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", str(ORACLE), "all"], check=True, stdout=subprocess.DEVNULL)
-    return ORACLE / "liboracle_libm.so", ORACLE / "liboracle_det.so"
-
-
 def build_all(force=False, verbose=False):
-    build_library(force, verbose)
-    build_oracle(force)
+    return build_library(force, verbose)
