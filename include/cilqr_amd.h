@@ -143,6 +143,13 @@ int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
 /* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */
 int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
 
+/* Optional in-kernel cycle accounting of the fused solve (development aid): when enabled, the next
+ * solve records, per trajectory, shader-clock cycles spent in
+ * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,
+ * [4] trial cost evaluations, [5] accepting a trial, [6] whole solve, [7] iterations.  out[B][8]. */
+int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
+int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B);
+
 /* ---- the pieces of the path, exported so each can be parity-checked on its own -------------- */
 /* get_init_traj / const_velo_prediction (cs:155-161,182-197): x_out[B][N+1][4] */
 int cilqr_init_traj_batch(cilqr_handle* h, int32_t B, const double* x0, const int32_t* param_id,

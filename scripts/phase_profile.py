@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the fused solve kernel (in-kernel cycle counters), for DESIGN.md/profiles."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cilqr_amd as pkg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--horizon", type=int, default=50)
+args = ap.parse_args()
+wl = {2: pkg.workloads.config2, 3: pkg.workloads.config3}[args.config](B=args.batch, N=args.horizon)
+eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+eng.solve_batch(wl.x0)
+eng.set_phase_profiling(True)
+eng.set_timing(True)
+out = eng.solve_batch(wl.x0)
+ms = eng.last_kernel_ms()
+cyc = eng.phase_cycles(wl.B)
+names = ["init", "derivs", "backward", "rollout", "trial_cost", "accept", "total", "iters"]
+res = out["res"]
+tot = cyc[:, 6].astype(float)
+rep = {"workload": wl.name, "kernel_ms": ms, "iters_sum": int(res["iters"].sum()), "iters_max": int(res["iters"].max()),
+       "iters_mean": float(res["iters"].mean()), "trials_sum": int(res["ls_trials"].sum()),
+       "cycles_total_max": float(tot.max()), "cycles_total_mean": float(tot.mean()),
+       "clock_GHz_est": float(tot.max() / (ms * 1e-3) / 1e9),
+       "share_of_mean_total": {n: float(cyc[:, i].mean() / tot.mean()) for i, n in enumerate(names[:6])},
+       "cycles_per_iteration": {n: float(cyc[:, i].sum() / res["iters"].sum()) for i, n in enumerate(names[1:6], start=1)},
+       "cycles_per_trial_cost": float(cyc[:, 4].sum() / max(1, res["ls_trials"].sum())),
+       "slowest": {"iters": int(res["iters"][tot.argmax()]), "trials": int(res["ls_trials"][tot.argmax()]),
+                   "phases": {n: int(cyc[tot.argmax(), i]) for i, n in enumerate(names[:6])}}}
+print(json.dumps(rep, indent=1))

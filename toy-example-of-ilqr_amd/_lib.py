@@ -96,6 +96,8 @@ SIGNATURES = {
     "cilqr_solve_batch_device": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cilqr_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "cilqr_set_timing": (C.c_int, [_P, _I]),
+    "cilqr_set_phase_profiling": (C.c_int, [_P, _I]),
+    "cilqr_get_phase_cycles": (C.c_int, [_P, _P, _I]),
     "cilqr_init_traj_batch": (C.c_int, [_P, _I, _P, _P, _P]),
     "cilqr_ref_points_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "cilqr_total_cost_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),

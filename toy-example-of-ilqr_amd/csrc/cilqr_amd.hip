@@ -27,9 +27,22 @@ struct BatchArgs {
     const int32_t* param_id;    // may be null
     const int32_t* tick;        // may be null
     double* scratch;            // [grid][scratch_doubles(N)]
+    long long* prof;            // optional [B][8] shader-clock cycles per phase (null = off)
     int B;
     int N;
 };
+
+// phase ids of the optional in-kernel cycle accounting
+enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7 };
+#define PROF_T0() long long t_ph_ = a.prof ? (long long)__builtin_readcyclecounter() : 0
+#define PROF_ADD(ph)                                                  \
+    do {                                                              \
+        if (a.prof) {                                                 \
+            long long t_now_ = (long long)__builtin_readcyclecounter(); \
+            ph_acc[ph] += t_now_ - t_ph_;                             \
+            t_ph_ = t_now_;                                           \
+        }                                                             \
+    } while (0)
 
 __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
     int pid = a.param_id ? a.param_id[b] : 0;
@@ -53,11 +66,15 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     carve(l, g_lds, N);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
 
+    long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
     init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0);
     double J_cur = total_cost_lds(c, l, lane);
     const double J_init = J_cur;
+    PROF_ADD(PH_INIT);
 
     double lamb = c.init_lamb;
     int status = CILQR_RUNNING;
@@ -71,10 +88,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         if (status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
             cost_and_model_derivatives(c, l, lane);
         }
+        PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
         bool ok = backward_sweep(c, l, lamb, lane, dV);
         __syncthreads();
+        PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
         int trials = 0, alpha_idx = -1;
         if (!ok) {
@@ -82,10 +101,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         } else {
             flag = 0;
             rollout_trials(c, l, scr, lane, idx0, CILQR_MAX_ALPHA_TRIALS);
+            PROF_ADD(PH_ROLLOUT);
             bool done = false;
             for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
                 const double alpha = dm_pow2i(-t);
                 new_J = total_cost_trial(c, l, scr, t, lane);
+                PROF_ADD(PH_TRIAL_COST);
                 trials++;
                 const double decay = J_cur - new_J;
                 const double adecay = (decay < 0) ? -decay : decay;
@@ -100,6 +121,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                         flag = 1;
                         alpha_idx = t;
                         accept_trial(c, l, scr, t, lane);
+                        PROF_ADD(PH_ACCEPT);
                         J_cur = new_J;
                         done = true;
                     }
@@ -135,6 +157,11 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             double* uo = u_out + ((size_t)b * N + k) * 2;
             uo[0] = l.u[2 * k]; uo[1] = l.u[2 * k + 1];
         }
+    }
+    if (a.prof && lane == 0) {
+        ph_acc[PH_TOTAL] = (long long)__builtin_readcyclecounter() - t_begin;
+        ph_acc[PH_ITERS] = iters;
+        for (int e = 0; e < 8; ++e) a.prof[(size_t)b * 8 + e] = ph_acc[e];
     }
     if (lane == 0 && res_out) {
         cilqr_result r;
@@ -368,6 +395,9 @@ struct cilqr_handle {
     DevBuf d_scenes;
     // scratch + staging
     DevBuf scratch;
+    DevBuf prof;      // [B][8] int64, filled when profiling is on
+    bool profiling = false;
+    int prof_B = 0;
     DevBuf st[16];
 };
 
@@ -413,6 +443,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     h->d_params.release();
     h->d_scenes.release();
     h->scratch.release();
+    h->prof.release();
     for (auto& s : h->st) s.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -424,6 +455,20 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
 extern "C" int cilqr_set_timing(cilqr_handle* h, int32_t enabled) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     h->timing = enabled != 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    h->profiling = enabled != 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B) {
+    if (!h || !out || B < 1 || B > h->prof_B || !h->prof.p) return fail(CILQR_ERR_BAD_ARG, "no phase profile available");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->prof.p, sizeof(long long) * 8 * (size_t)B, hipMemcpyDeviceToHost));
     return CILQR_OK;
 }
 
@@ -565,6 +610,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.param_id = ids.pid;
     a.tick = ids.tick;
     a.scratch = static_cast<double*>(h->scratch.p);
+    a.prof = nullptr;
     a.B = B;
     a.N = h->params[0].N;
     return a;
@@ -596,6 +642,11 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     BatchArgs a = make_args(h, B, ids);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t shm = lds_bytes(a.N);
+    if (h->profiling) {
+        if (h->prof.ensure(sizeof(long long) * 8 * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
+        a.prof = static_cast<long long*>(h->prof.p);
+        h->prof_B = B;
+    }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(k_solve, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
                        d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);

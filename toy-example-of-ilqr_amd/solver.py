@@ -127,6 +127,15 @@ class BatchedCILQR:
     def set_timing(self, on=True):
         check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
 
+    def set_phase_profiling(self, on=True):
+        check(self._lib.cilqr_set_phase_profiling(self._h, 1 if on else 0), "cilqr_set_phase_profiling")
+
+    def phase_cycles(self, B):
+        """[B][8] cycles: init, derivatives, backward, rollout, trial cost, accept, total, iterations"""
+        out = np.zeros((B, 8), dtype=np.int64)
+        check(self._lib.cilqr_get_phase_cycles(self._h, _p(out), int(B)), "cilqr_get_phase_cycles")
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         check(self._lib.cilqr_last_kernel_ms(self._h, C.byref(ms)), "cilqr_last_kernel_ms")
