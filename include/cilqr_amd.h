@@ -146,8 +146,15 @@ int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
 /* Optional in-kernel cycle accounting of the fused solve (development aid): when enabled, the next
  * solve records, per trajectory, shader-clock cycles spent in
  * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,
- * [4] trial cost evaluations, [5] accepting a trial, [6] whole solve, [7] iterations.  out[B][8]. */
+ * [4] trial cost evaluations, [5] accepting a trial, [6] whole solve, [7] iterations,
+ * [8] trial cost evaluations that fell back to the serial reference-point chain, [9] trials,
+ * [10..12] split of [4]: reference points, stage costs, ordered sum.  out[B][13]. */
+#define CILQR_PROF_SLOTS 13
 int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
+/* Testing aid.  bit 0: always use the serial reference-point chain (cs:289-314 as written) instead
+ * of the lane-parallel search + proof; bit 1: wave-uniform backward sweep instead of the
+ * lane-parallel one.  Results must be identical either way. */
+int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags);
 int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B);
 
 /* ---- the pieces of the path, exported so each can be parity-checked on its own -------------- */

@@ -287,3 +287,51 @@ def test_error_codes(pkg, engines):
     with pytest.raises(pkg.CilqrError) as e:
         eng.solve_batch(sc.ego_state[None], scenario_id=[3])
     assert e.value.code == -1
+
+
+def test_serial_and_parallel_reference_search_agree(pkg, orc_det, engines):
+    """the lane-parallel reference-point search (+ proof) and the serial chain of cs:289-314 give the
+    same solves; with wild gains the proof must fail sometimes and the fallback must take over."""
+    eng, p, sc = engines("three_bend", 50, use_last_solution=0)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 64, 4242)
+    a = eng.solve_batch(x0, trace_cap=64)
+    eng.set_debug_flags(pkg._lib.DBG_SERIAL_REF_SCAN)
+    b = eng.solve_batch(x0, trace_cap=64)
+    eng.set_debug_flags(0)
+    eq_bits(a["u"], b["u"], "u")
+    eq_bits(a["x"], b["x"], "x")
+    assert (a["res"] == b["res"]).all() and (a["trace"] == b["trace"]).all()
+    # forward passes with exaggerated gains: trial trajectories that double back / leave the lane
+    scene = oracle_scene(sc)
+    us, xs = random_trajectories(pkg, orc_det, p, sc, 12, seed=8)
+    d, K, dV, st = eng.backward_pass(us, xs, 0.0)
+    K2, d2 = K * 6.0, d * 25.0
+    nu, nx, Jt = eng.forward_pass(us, xs, d2, K2)
+    s = orc_det.solver(p)
+    checked = 0
+    for b_ in range(12):
+        for a_ in range(20):
+            ou, ox = orc_det.forward_pass(p, us[b_], xs[b_], d2[b_], K2[b_], 2.0 ** -a_)
+            eq_bits(nx[b_, a_], ox, "wild fw x")
+            if np.all(np.isfinite(ox)) and np.abs(ox).max() < 1e6:
+                eq_bits(Jt[b_, a_], s.total_cost(ou, ox, scene), "wild fw J")
+                checked += 1
+    assert checked > 100
+
+
+def test_uniform_and_lane_parallel_backward_agree(pkg, orc_det, engines):
+    """the two device formulations of backward_pass (wave-uniform / lane-parallel) are
+    interchangeable bit for bit, on success and on failure."""
+    for name, N, over in (("three_bend", 50, {}), ("two_straight", 30, {"w_acc": -40.0})):
+        eng, p, sc = engines(name, N, **over)
+        us, xs = random_trajectories(pkg, orc_det, p, sc, 16, seed=21, rough=0.01)
+        for lamb in (0.0, 8.0):
+            a = eng.backward_pass(us, xs, lamb)
+            eng.set_debug_flags(pkg._lib.DBG_UNIFORM_BACKWARD)
+            b = eng.backward_pass(us, xs, lamb)
+            eng.set_debug_flags(0)
+            assert (a[3] == b[3]).all()
+            eq_bits(a[0], b[0], "d")
+            eq_bits(a[1], b[1], "K")
+            ok = a[3] == 0
+            eq_bits(a[2][ok], b[2][ok], "dV")

@@ -19,6 +19,9 @@ ERR_NO_DEVICE = -5
 
 MAX_HORIZON = 128
 MAX_ALPHA_TRIALS = 20
+PROF_SLOTS = 13
+DBG_SERIAL_REF_SCAN = 1
+DBG_UNIFORM_BACKWARD = 2
 
 STATUS_NAMES = {0: "RUNNING", 1: "CONVERGED", 2: "BACKWARD_PASS_FAIL", 3: "FORWARD_PASS_FAIL",
                 4: "FORWARD_PASS_SMALL_STEP"}
@@ -98,6 +101,7 @@ SIGNATURES = {
     "cilqr_set_timing": (C.c_int, [_P, _I]),
     "cilqr_set_phase_profiling": (C.c_int, [_P, _I]),
     "cilqr_get_phase_cycles": (C.c_int, [_P, _P, _I]),
+    "cilqr_set_debug_flags": (C.c_int, [_P, _I]),
     "cilqr_init_traj_batch": (C.c_int, [_P, _I, _P, _P, _P]),
     "cilqr_ref_points_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     "cilqr_total_cost_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),

@@ -6,6 +6,7 @@
 // every stage can be compared with the oracle in isolation.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -27,13 +28,16 @@ struct BatchArgs {
     const int32_t* param_id;    // may be null
     const int32_t* tick;        // may be null
     double* scratch;            // [grid][scratch_doubles(N)]
-    long long* prof;            // optional [B][8] shader-clock cycles per phase (null = off)
+    long long* prof;            // optional [B][CILQR_PROF_SLOTS] cycles per phase + counters (null = off)
     int B;
     int N;
+    int W;                      // capacity (samples) of the per-trajectory LDS lane window
+    int flags;                  // CILQR_DBG_* (testing aids)
 };
 
 // phase ids of the optional in-kernel cycle accounting
-enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7 };
+#define CILQR_PROF_SLOTS 13
+enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12 };
 #define PROF_T0() long long t_ph_ = a.prof ? (long long)__builtin_readcyclecounter() : 0
 #define PROF_ADD(ph)                                                  \
     do {                                                              \
@@ -63,15 +67,15 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     load_cst(c, a, b);
     const int N = c.N;
     Lds l;
-    carve(l, g_lds, N);
+    carve(l, g_lds, N, a.W);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
 
-    long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
-    init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0);
+    init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
     double J_cur = total_cost_lds(c, l, lane);
     const double J_init = J_cur;
     PROF_ADD(PH_INIT);
@@ -81,6 +85,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     int iters = 0, ls_trials = 0, cost_evals = 1, tl = 0;
     int end_reason = CILQR_END_MAX_ITER;
     int flag = 0;
+    int n_fallback = 0;
     for (int itr = 0; itr < c.max_iter; ++itr) {
         // ---- iter_step ----
         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
@@ -91,7 +96,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
-        bool ok = backward_sweep(c, l, lamb, lane, dV);
+        bool ok = backward_sweep(c, l, lamb, lane, dV, a.flags);
         __syncthreads();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
@@ -100,12 +105,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             status = CILQR_BACKWARD_PASS_FAIL;
         } else {
             flag = 0;
-            rollout_trials(c, l, scr, lane, idx0, CILQR_MAX_ALPHA_TRIALS);
+            rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
             PROF_ADD(PH_ROLLOUT);
             bool done = false;
             for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
                 const double alpha = dm_pow2i(-t);
-                new_J = total_cost_trial(c, l, scr, t, lane);
+                new_J = total_cost_trial(c, l, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
                 PROF_ADD(PH_TRIAL_COST);
                 trials++;
                 const double decay = J_cur - new_J;
@@ -161,7 +166,9 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     if (a.prof && lane == 0) {
         ph_acc[PH_TOTAL] = (long long)__builtin_readcyclecounter() - t_begin;
         ph_acc[PH_ITERS] = iters;
-        for (int e = 0; e < 8; ++e) a.prof[(size_t)b * 8 + e] = ph_acc[e];
+        ph_acc[PH_REF_FALLBACKS] = n_fallback;
+        ph_acc[PH_TRIALS] = ls_trials;
+        for (int e = 0; e < CILQR_PROF_SLOTS; ++e) a.prof[(size_t)b * CILQR_PROF_SLOTS + e] = ph_acc[e];
     }
     if (lane == 0 && res_out) {
         cilqr_result r;
@@ -184,10 +191,10 @@ k_init_traj(BatchArgs a, const double* __restrict__ x0, double* __restrict__ x_o
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
-    init_trajectory(c, l, xs, nullptr, lane, idx0);
+    init_trajectory(c, l, xs, nullptr, lane, idx0, a.W);
     for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = l.x[e];
 }
 
@@ -197,15 +204,15 @@ k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), nullptr, lane);
     int idx0;
-    ref_indices_lds(c, l, lane, idx0);
+    ref_indices_lds(c, l, lane, idx0, a.W);
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         int j = l.ridx[k];
         if (idx_out) idx_out[(size_t)b * (N + 1) + k] = j;
         double* r = ref_out + ((size_t)b * (N + 1) + k) * 3;
-        r[0] = c.lane_xy[2 * j]; r[1] = c.lane_xy[2 * j + 1]; r[2] = c.lane_yaw[j];
+        r[0] = c.lane_xy[2 * j]; r[1] = c.lane_xy[2 * j + 1]; r[2] = c.lane_aux[(size_t)j * CILQR_AUX_STRIDE];
     }
 }
 
@@ -215,10 +222,10 @@ k_total_cost(BatchArgs a, const double* __restrict__ u, const double* __restrict
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), u + (size_t)b * 2 * N, lane);
     int idx0;
-    ref_indices_lds(c, l, lane, idx0);
+    ref_indices_lds(c, l, lane, idx0, a.W);
     double J = total_cost_lds(c, l, lane);
     if (lane == 0) J_out[b] = J;
 }
@@ -231,16 +238,17 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = K[(size_t)b * 8 * N + e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = d[(size_t)b * 2 * N + e];
     __syncthreads();
-    int idx0 = ref_scan_row0(c, l.x[0], l.x[1], lane);
+    int idx0;
+    ref_indices_lds(c, l, lane, idx0, a.W); // indices of the current trajectory: the guesses for its trials
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
-    rollout_trials(c, l, scr, lane, idx0, n_alpha);
+    rollout_trials(c, l, scr, lane, n_alpha);
     for (int t = 0; t < n_alpha; ++t) {
-        const double* tr = scr + (size_t)t * 7 * R;
+        const double* tr = scr + (size_t)t * CILQR_TRIAL_ROWS * R;
         for (int k = lane; k <= N; k += CILQR_WAVE) {
             double* xo = new_x + (((size_t)b * n_alpha + t) * R + k) * 4;
             xo[0] = tr[k]; xo[1] = tr[R + k]; xo[2] = tr[2 * R + k]; xo[3] = tr[3 * R + k];
@@ -249,7 +257,8 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
                 uo[0] = tr[4 * R + k]; uo[1] = tr[5 * R + k];
             }
         }
-        double J = total_cost_trial(c, l, scr, t, lane);
+        int nfb = 0;
+        double J = total_cost_trial(c, l, scr, t, lane, idx0, a.flags, &nfb);
         if (lane == 0 && J_out) J_out[(size_t)b * n_alpha + t] = J;
     }
 }
@@ -262,10 +271,10 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
-    ref_indices_lds(c, l, lane, idx0);
+    ref_indices_lds(c, l, lane, idx0, a.W);
     cost_and_model_derivatives(c, l, lane);
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         if (o_lx) for (int e = 0; e < 4; ++e) o_lx[((size_t)b * R + k) * 4 + e] = l.lx[4 * k + e];
@@ -303,15 +312,15 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N);
+    Lds l; carve(l, g_lds, N, a.W);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = 0.0;
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = 0.0;
     int idx0;
-    ref_indices_lds(c, l, lane, idx0);
+    ref_indices_lds(c, l, lane, idx0, a.W);
     cost_and_model_derivatives(c, l, lane);
     double dV[2];
-    bool ok = backward_sweep(c, l, lamb[b], lane, dV);
+    bool ok = backward_sweep(c, l, lamb[b], lane, dV, a.flags);
     __syncthreads();
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) o_K[(size_t)b * 8 * N + e] = l.K[e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) o_d[(size_t)b * 2 * N + e] = l.d[e];
@@ -319,6 +328,25 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
         o_dV[2 * b] = dV[0];
         o_dV[2 * b + 1] = dV[1];
         o_status[b] = ok ? CILQR_RUNNING : CILQR_BACKWARD_PASS_FAIL;
+    }
+}
+
+// fills sin/cos of the lane yaw and of the obstacle yaw with the device's own dm_sincos
+__global__ void k_prepare_tables(const double* __restrict__ yaw_in, double* __restrict__ lane_aux, int L,
+                                 const double* __restrict__ obs_in, double* __restrict__ obs_out, int MT) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) {
+        double y = yaw_in[i], sn, cs;
+        dm_sincos(y, &sn, &cs);
+        double* o = lane_aux + (size_t)i * CILQR_AUX_STRIDE;
+        o[0] = y; o[1] = sn; o[2] = cs; o[3] = 0.0;
+    }
+    if (i < MT) {
+        const double* r = obs_in + (size_t)i * 3;
+        double sn, cs;
+        dm_sincos(r[2], &sn, &cs);
+        double* o = obs_out + (size_t)i * CILQR_OBS_STRIDE;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = sn; o[4] = cs;
     }
 }
 
@@ -391,15 +419,33 @@ struct cilqr_handle {
     DevBuf d_params;
     std::vector<DevScene> scenes;     // device pointers inside
     std::vector<int> scene_T, scene_M; // for validation
+    std::vector<double> scene_spacing, scene_velo;
     std::vector<void*> scene_allocs;
     DevBuf d_scenes;
     // scratch + staging
+    int win = 0;      // LDS lane-window capacity in samples (derived from the tables)
     DevBuf scratch;
     DevBuf prof;      // [B][8] int64, filled when profiling is on
     bool profiling = false;
+    int debug_flags = 0;
     int prof_B = 0;
     DevBuf st[16];
 };
+
+// LDS lane window: enough samples for the horizon at 1.5x the target speed (anything beyond it is
+// still correct — lookups outside the window read global memory), a multiple of 64, <= 1024.
+static void update_window(cilqr_handle* h) {
+    if (h->params.empty() || h->scene_spacing.empty()) return;
+    double need = 128;
+    for (const auto& p : h->params)
+        for (size_t i = 0; i < h->scene_spacing.size(); ++i) {
+            double ds = h->scene_spacing[i] > 1e-6 ? h->scene_spacing[i] : 0.1;
+            double n = p.N * p.dt * h->scene_velo[i] / ds * 1.5 + 64;
+            if (n > need) need = n;
+        }
+    int w = ((int)need + 63) / 64 * 64;
+    h->win = w > 1024 ? 1024 : w;
+}
 
 static int check_ready(cilqr_handle* h) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
@@ -433,6 +479,8 @@ static void free_scenes(cilqr_handle* h) {
     h->scenes.clear();
     h->scene_T.clear();
     h->scene_M.clear();
+    h->scene_spacing.clear();
+    h->scene_velo.clear();
 }
 
 extern "C" int cilqr_destroy(cilqr_handle* h) {
@@ -464,11 +512,17 @@ extern "C" int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled) {
     return CILQR_OK;
 }
 
+extern "C" int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    h->debug_flags = flags;
+    return CILQR_OK;
+}
+
 extern "C" int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B) {
     if (!h || !out || B < 1 || B > h->prof_B || !h->prof.p) return fail(CILQR_ERR_BAD_ARG, "no phase profile available");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->prof.p, sizeof(long long) * 8 * (size_t)B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->prof.p, sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B, hipMemcpyDeviceToHost));
     return CILQR_OK;
 }
 
@@ -498,6 +552,7 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
     h->params.assign(params, params + n_params);
     if (h->d_params.ensure(sizeof(cilqr_params) * n_params)) return fail(CILQR_ERR_DEVICE, "hipMalloc params");
     HIP_TRY(hipMemcpy(h->d_params.p, params, sizeof(cilqr_params) * n_params, hipMemcpyHostToDevice));
+    update_window(h);
     return CILQR_OK;
 }
 
@@ -521,22 +576,36 @@ extern "C" int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* s
         DevScene d;
         std::memset(&d, 0, sizeof(d));
         void* p_xy = nullptr;
-        void* p_yaw = nullptr;
+        void* p_aux = nullptr;
         void* p_obs = nullptr;
+        void* p_tmp_yaw = nullptr;
+        void* p_tmp_obs = nullptr;
         HIP_TRY(hipMalloc(&p_xy, sizeof(double) * xy.size()));
         h->scene_allocs.push_back(p_xy);
-        HIP_TRY(hipMalloc(&p_yaw, sizeof(double) * s.L));
-        h->scene_allocs.push_back(p_yaw);
+        HIP_TRY(hipMalloc(&p_aux, sizeof(double) * CILQR_AUX_STRIDE * (size_t)s.L));
+        h->scene_allocs.push_back(p_aux);
+        HIP_TRY(hipMalloc(&p_tmp_yaw, sizeof(double) * s.L));
         HIP_TRY(hipMemcpy(p_xy, xy.data(), sizeof(double) * xy.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p_yaw, s.lane_yaw, sizeof(double) * s.L, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p_tmp_yaw, s.lane_yaw, sizeof(double) * s.L, hipMemcpyHostToDevice));
+        const size_t MT = (size_t)s.M * (size_t)(s.M > 0 ? s.T : 0);
         if (s.M > 0) {
-            size_t nb = sizeof(double) * 3 * (size_t)s.M * (size_t)s.T;
-            HIP_TRY(hipMalloc(&p_obs, nb));
+            HIP_TRY(hipMalloc(&p_obs, sizeof(double) * CILQR_OBS_STRIDE * MT));
             h->scene_allocs.push_back(p_obs);
-            HIP_TRY(hipMemcpy(p_obs, s.obs, nb, hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&p_tmp_obs, sizeof(double) * 3 * MT));
+            HIP_TRY(hipMemcpy(p_tmp_obs, s.obs, sizeof(double) * 3 * MT, hipMemcpyHostToDevice));
         }
+        {
+            const int n = (int)((size_t)s.L > MT ? (size_t)s.L : MT);
+            hipLaunchKernelGGL(k_prepare_tables, dim3((n + 255) / 256), dim3(256), 0, h->stream,
+                               static_cast<const double*>(p_tmp_yaw), static_cast<double*>(p_aux), s.L,
+                               static_cast<const double*>(p_tmp_obs), static_cast<double*>(p_obs), (int)MT);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        (void)hipFree(p_tmp_yaw);
+        if (p_tmp_obs) (void)hipFree(p_tmp_obs);
         d.lane_xy = static_cast<const double*>(p_xy);
-        d.lane_yaw = static_cast<const double*>(p_yaw);
+        d.lane_aux = static_cast<const double*>(p_aux);
         d.obs = static_cast<const double*>(p_obs);
         d.L = s.L; d.M = s.M; d.T = s.T;
         d.border_hi = s.road_borders[0];
@@ -545,9 +614,14 @@ extern "C" int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* s
         h->scenes.push_back(d);
         h->scene_T.push_back(s.T);
         h->scene_M.push_back(s.M);
+        double span = 0.0;
+        for (int j = 1; j < s.L; ++j) span += std::hypot(s.lane_x[j] - s.lane_x[j - 1], s.lane_y[j] - s.lane_y[j - 1]);
+        h->scene_spacing.push_back(s.L > 1 ? span / (s.L - 1) : 0.1);
+        h->scene_velo.push_back(std::fabs(s.ref_velo));
     }
     if (h->d_scenes.ensure(sizeof(DevScene) * n_scen)) return fail(CILQR_ERR_DEVICE, "hipMalloc scenes");
     HIP_TRY(hipMemcpy(h->d_scenes.p, h->scenes.data(), sizeof(DevScene) * n_scen, hipMemcpyHostToDevice));
+    update_window(h);
     return CILQR_OK;
 }
 
@@ -613,6 +687,8 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.prof = nullptr;
     a.B = B;
     a.N = h->params[0].N;
+    a.W = h->win;
+    a.flags = h->debug_flags;
     return a;
 }
 
@@ -641,9 +717,9 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
     BatchArgs a = make_args(h, B, ids);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t shm = lds_bytes(a.N);
+    const size_t shm = lds_bytes(a.N, a.W);
     if (h->profiling) {
-        if (h->prof.ensure(sizeof(long long) * 8 * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
+        if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
         a.prof = static_cast<long long*>(h->prof.p);
         h->prof_B = B;
     }
@@ -725,7 +801,7 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     if (rc) return rc;
     pc.a = make_args(h, B, pc.ids);
     pc.N = pc.a.N;
-    pc.shm = lds_bytes(pc.N);
+    pc.shm = lds_bytes(pc.N, pc.a.W);
     return CILQR_OK;
 }
 

@@ -27,13 +27,21 @@
 
 #define CILQR_WAVE 64
 #define CILQR_EPS 1e-5 /* include/utils.hpp:28 */
+#define CILQR_DBG_SERIAL_REF_SCAN 1 /* cilqr_set_debug_flags: always take the serial reference-point chain */
+#define CILQR_DBG_UNIFORM_BACKWARD 2 /* use the wave-uniform backward sweep instead of the lane-parallel one */
 
 namespace cilqr {
 
+// pointers into HBM are typed as address space 1 so that every access is a global_load (a generic
+// pointer would compile to flat_load, which also ties up the LDS counter)
+typedef const double __attribute__((address_space(1))) gdouble;
+#define CILQR_OBS_STRIDE 5  /* device obstacle record: x, y, yaw, sin(yaw), cos(yaw) */
+#define CILQR_AUX_STRIDE 4  /* device lane record: yaw, sin(yaw), cos(yaw), unused */
+
 struct DevScene {
     const double* lane_xy;  // [L][2]
-    const double* lane_yaw; // [L]
-    const double* obs;      // [M][T][3]
+    const double* lane_aux; // [L][4]  yaw, sin, cos (filled on the device with dm_sincos: same bits as in-kernel)
+    const double* obs;      // [M][T][5] x, y, yaw, sin, cos
     int L, M, T, pad;
     double border_hi, border_lo, ref_velo;
 };
@@ -49,9 +57,9 @@ struct Cst {
     double ell_a2, ell_b2;
     double ref_velo;
     double init_lamb, lamb_decay, lamb_amplify, max_lamb, conv_thr, accept_thr;
-    const double* lane_xy;
-    const double* lane_yaw;
-    const double* obs;
+    gdouble* lane_xy;
+    gdouble* lane_aux;
+    gdouble* obs;
 };
 
 __device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick) {
@@ -72,7 +80,7 @@ __device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s
     c.ref_velo = s.ref_velo;
     c.init_lamb = p.init_lamb; c.lamb_decay = p.lamb_decay; c.lamb_amplify = p.lamb_amplify;
     c.max_lamb = p.max_lamb; c.conv_thr = p.convergence_threshold; c.accept_thr = p.accept_step_threshold;
-    c.lane_xy = s.lane_xy; c.lane_yaw = s.lane_yaw; c.obs = s.obs;
+    c.lane_xy = (gdouble*)s.lane_xy; c.lane_aux = (gdouble*)s.lane_aux; c.obs = (gdouble*)s.obs;
 }
 
 // LDS carve-out for one trajectory (offsets in doubles).  l_xx keeps the 7 entries that can be
@@ -88,19 +96,32 @@ struct Lds {
     double* luu; // [N][2]
     double* A5;  // [N][5]  a02 a03 a12 a13 a32
     double* B3;  // [N][3]  b01 b11 b31
+    double* xch; // [CILQR_XCH] exchange buffers of the lane-parallel backward sweep (see backward_sweep_lanes)
     double* cs;  // [3][(N+1)] stage-cost scratch: state, ctrl, barrier
+    double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
+    int* tidx;   // [(N+1)] the same for the trial trajectory being costed
+    int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
+    int W;
 };
+
+// exchange area of the lane-parallel backward sweep: Wt[5][4] X[6][4] Q[6][8] qv[8] const[4]
+#define CILQR_XCH_WT 0
+#define CILQR_XCH_X 20
+#define CILQR_XCH_Q 44
+#define CILQR_XCH_QV 92
+#define CILQR_XCH_CONST 100
+#define CILQR_XCH 104
 
 __host__ __device__ inline int lds_doubles(int N) {
     return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + 7 * (N + 1) + 2 * N + 5 * N +
-           3 * N + 3 * (N + 1);
+           3 * N + CILQR_XCH + 3 * (N + 1);
 }
-__host__ __device__ inline size_t lds_bytes(int N) {
-    return sizeof(double) * (size_t)lds_doubles(N) + sizeof(int) * (size_t)(N + 2);
+__host__ __device__ inline size_t lds_bytes(int N, int W) {
+    return sizeof(double) * ((size_t)lds_doubles(N) + 2 * (size_t)W) + sizeof(int) * (size_t)(2 * N + 4);
 }
 
-__device__ inline void carve(Lds& l, double* base, int N) {
+__device__ inline void carve(Lds& l, double* base, int N, int W) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
@@ -112,14 +133,42 @@ __device__ inline void carve(Lds& l, double* base, int N) {
     l.luu = p; p += 2 * N;
     l.A5 = p; p += 5 * N;
     l.B3 = p; p += 3 * N;
+    l.xch = p; p += CILQR_XCH;
     l.cs = p; p += 3 * (N + 1);
+    l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
+    l.tidx = l.ridx + (N + 2);
+    l.w0 = 0;
+    l.W = 0; // nothing staged yet: every lookup goes to global memory
 }
 
-// scratch slab of the trial trajectories: [alpha][7][(N+1)] doubles
-// rows 0-3 = x' components, 4-5 = u' components, 6 = lane-sample index (stored as a double)
+// lane sample j: from the LDS window when it is inside, from global memory otherwise
+__device__ inline void lane_point(const Cst& c, const Lds& l, int j, double& px, double& py) {
+    unsigned o = (unsigned)(j - l.w0);
+    if (o < (unsigned)l.W) {
+        px = l.win[2 * o];
+        py = l.win[2 * o + 1];
+    } else {
+        px = c.lane_xy[2 * j];
+        py = c.lane_xy[2 * j + 1];
+    }
+}
+
+// stage lane_xy[w0 .. w0+Wcap) into LDS (clipped to the table); call with all lanes
+__device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int lane) {
+    int W = c.L - w0;
+    W = (W < Wcap) ? W : Wcap;
+    for (int e = lane; e < 2 * W; e += CILQR_WAVE) l.win[e] = c.lane_xy[2 * (size_t)w0 + e];
+    l.w0 = w0;
+    l.W = W;
+    __syncthreads();
+}
+
+// scratch slab of the trial trajectories: [alpha][6][(N+1)] doubles
+// rows 0-3 = x' components, 4-5 = u' components
+#define CILQR_TRIAL_ROWS 6
 __host__ __device__ inline size_t scratch_doubles(int N) {
-    return (size_t)CILQR_MAX_ALPHA_TRIALS * 7 * (size_t)(N + 1);
+    return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -171,19 +220,126 @@ __device__ inline bool dist_less(double cur2, double best2) {
     return dm_sqrt(cur2) < dm_sqrt(best2);                    // near tie (also the NaN path)
 }
 
-// cs:295-311 for one row, lane-private: first local minimum of the distance at or after s
-__device__ inline int ref_scan_from(const Cst& c, double px, double py, int s) {
+// cs:295-311 for one row, lane-private: first local minimum of the distance at or after s.
+// Four candidates are fetched and evaluated per trip (independent loads, one latency); candidate
+// t is compared with candidate t-1 exactly as the reference's running minimum would be.
+__device__ inline int ref_scan_from(const Cst& c, const Lds& l, double px, double py, int s) {
     int j = s;
-    double bx = px - c.lane_xy[2 * j], by = py - c.lane_xy[2 * j + 1];
+    double qx, qy;
+    lane_point(c, l, j, qx, qy);
+    double bx = px - qx, by = py - qy;
     double best2 = bx * bx + by * by;
-    while (j + 1 < c.L) {
-        double cx = px - c.lane_xy[2 * (j + 1)], cy = py - c.lane_xy[2 * (j + 1) + 1];
-        double cur2 = cx * cx + cy * cy;
-        if (!dist_less(cur2, best2)) break;
-        best2 = cur2;
-        ++j;
+    for (;;) {
+        double c2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int jj = j + 1 + t;
+            double v = dm_inf();
+            if (jj < c.L) {
+                double ax, ay;
+                lane_point(c, l, jj, ax, ay);
+                double ex = px - ax, ey = py - ay;
+                v = ex * ex + ey * ey;
+            }
+            c2[t] = v;
+        }
+        bool f0 = dist_less(c2[0], best2);
+        bool f1 = dist_less(c2[1], c2[0]);
+        bool f2 = dist_less(c2[2], c2[1]);
+        bool f3 = dist_less(c2[3], c2[2]);
+        int adv = f0 ? (f1 ? (f2 ? (f3 ? 4 : 3) : 2) : 1) : 0;
+        j += adv;
+        if (adv < 4) break;
+        best2 = c2[3];
     }
     return j;
+}
+
+// squared distance from (px, py) to lane sample j (+inf past the end of the table)
+__device__ inline double lane_d2(const Cst& c, const Lds& l, double px, double py, int j) {
+    if (j >= c.L) return dm_inf();
+    double ax, ay;
+    lane_point(c, l, j, ax, ay);
+    double ex = px - ax, ey = py - ay;
+    return ex * ex + ey * ey;
+}
+
+// A local minimum of the distance profile of one row near `guess` (>= lo): walk forward while the
+// distance strictly decreases, otherwise walk backward to where the strict decrease starts.  Only
+// a CANDIDATE for cs:295-311 — trial_ref_indices() proves or rejects it.
+__device__ inline int local_min_near(const Cst& c, const Lds& l, double px, double py, int guess, int lo) {
+    int j = guess;
+    double cur = lane_d2(c, l, px, py, j);
+    double nxt = lane_d2(c, l, px, py, j + 1);
+    if (dist_less(nxt, cur)) {
+        j += 1;
+        cur = nxt;
+        for (;;) {
+            double n1 = lane_d2(c, l, px, py, j + 1);
+            double n2 = lane_d2(c, l, px, py, j + 2);
+            bool f1 = dist_less(n1, cur);
+            bool f2 = dist_less(n2, n1);
+            int adv = f1 ? (f2 ? 2 : 1) : 0;
+            j += adv;
+            if (adv < 2) break;
+            cur = n2;
+        }
+    } else {
+        while (j > lo) {
+            double prv = lane_d2(c, l, px, py, j - 1);
+            if (dist_less(cur, prv)) break; // strictly decreasing into j: the reference would not stop at j-1
+            j -= 1;
+            cur = prv;
+        }
+    }
+    return j;
+}
+
+// get_ref_exact_points (cs:289-314) for a whole trajectory with lane = row.
+// The reference chains the rows: idx[k] = first j >= idx[k-1] with !(d_k(j+1) < d_k(j)).  Here every
+// row first finds a candidate m[k] near guess[k] independently, then row k checks, with the SAME
+// comparisons the reference makes, that d_k strictly decreases on [m[k-1], m[k]] and stops
+// decreasing at m[k]; if that holds for every row then idx == m by induction from idx[0] = idx0.
+// Otherwise (non-monotone candidates, a missed earlier minimum, ...) the caller falls back to the
+// serial chain.  xy(k, px, py) yields row k's position.  Returns true when l.tidx[0..N] is proven.
+template <class XY>
+__device__ inline bool parallel_ref_indices(const Cst& c, const Lds& l, int lane, int idx0, const int* guess,
+                                            XY xy) {
+    const int N = c.N;
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        int m = idx0;
+        if (k > 0) {
+            double px, py;
+            xy(k, px, py);
+            int g = guess[k];
+            g = (g < idx0) ? idx0 : g;
+            g = (g > c.L - 1) ? c.L - 1 : g;
+            m = local_min_near(c, l, px, py, g, idx0);
+        }
+        l.tidx[k] = m;
+    }
+    __syncthreads();
+    bool ok = true;
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        if (k == 0) continue;
+        int a = l.tidx[k - 1], b = l.tidx[k];
+        bool good = (a <= b);
+        if (good) {
+            double px, py;
+            xy(k, px, py);
+            double cur = lane_d2(c, l, px, py, a);
+            for (int j = a; j < b && good; ++j) {
+                double nx = lane_d2(c, l, px, py, j + 1);
+                good = dist_less(nx, cur);
+                cur = nx;
+            }
+            if (good) good = !dist_less(lane_d2(c, l, px, py, b + 1), cur);
+        }
+        ok = ok && good;
+    }
+    bool all_ok = (__ballot(!ok) == 0ULL);
+    __syncthreads();
+    return all_ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,7 +352,7 @@ struct ObsOut {
 
 template <bool GRAD>
 __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double sn_yaw, double cs_yaw,
-                                      const double* ob, ObsOut& o) {
+                                      gdouble* ob, ObsOut& o) {
     double wv0 = c.wb * cs_yaw, wv1 = c.wb * sn_yaw;
     double fx, fy, rx, ry;
     if (c.rp == 0) {
@@ -205,8 +361,7 @@ __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double s
         fx = xk[0] + 0.5 * wv0; fy = xk[1] + 0.5 * wv1;
         rx = xk[0] - 0.5 * wv0; ry = xk[1] - 0.5 * wv1;
     }
-    double so, co;
-    dm_sincos(ob[2], &so, &co);
+    const double so = ob[3], co = ob[4]; // dm_sincos(ob[2]) precomputed on the device at upload
     double dfx = fx - ob[0], dfy = fy - ob[1];
     double drx = rx - ob[0], dry = ry - ob[1];
     double fX = co * dfx + so * dfy, fY = (-so) * dfx + co * dfy;
@@ -230,16 +385,19 @@ __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double s
     }
 }
 
-__device__ inline const double* obs_at(const Cst& c, int j, int k) {
-    return c.obs + ((size_t)j * c.T + (size_t)(c.tick + k)) * 3;
+__device__ inline gdouble* obs_at(const Cst& c, int j, int k) {
+    return c.obs + ((size_t)j * c.T + (size_t)(c.tick + k)) * CILQR_OBS_STRIDE;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Stage cost of row k (cs:199-287).  xk = x[k], uk = u[k] (k < N), ukm1 = u[k-1] (k >= 1).
 // sd = k-th diagonal entry of (x-ref) W (x-ref)^T, ce = k-th of u R u^T, jb = J_barrier_k.
-__device__ inline void stage_cost(const Cst& c, int k, const double xk[4], const double uk[2],
+__device__ inline void stage_cost(const Cst& c, const Lds& l, int k, const double xk[4], const double uk[2],
                                   const double ukm1[2], int ridx, double& sd, double& ce, double& jb) {
-    double rx = c.lane_xy[2 * ridx], ry = c.lane_xy[2 * ridx + 1], ryaw = c.lane_yaw[ridx];
+    double rx, ry;
+    lane_point(c, l, ridx, rx, ry);
+    gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
+    const double ryaw = aux[0], sr = aux[1], cr = aux[2];
     double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.ref_velo, e3 = xk[3] - ryaw;
     sd = (((e0 * c.w_pos) * e0 + (e1 * c.w_pos) * e1) + (e2 * c.w_vel) * e2) + (e3 * c.w_yaw) * e3;
     ce = 0.0;
@@ -249,8 +407,6 @@ __device__ inline void stage_cost(const Cst& c, int k, const double xk[4], const
         double acc_up = ukm1[0] - c.acc_max, acc_lo = c.acc_min - ukm1[0];
         double stl_up = ukm1[1] - c.stl_lim, stl_lo = -c.stl_lim - ukm1[1];
         double vel_up = xk[2] - c.velo_max, vel_lo = c.velo_min - xk[2];
-        double sr, cr;
-        dm_sincos(ryaw, &sr, &cr);
         double d_sign = e1 * cr - e0 * sr;
         double hyp = dm_hypot(e0, e1);
         double cur_d = (d_sign < 0) ? -hyp : hyp;
@@ -276,16 +432,27 @@ __device__ inline void stage_cost(const Cst& c, int k, const double xk[4], const
 
 // J = (sum_k sd + sum_k ce) + sum_k jb, each sum sequential in k as Eigen's trace()/the loop at
 // cs:217 accumulate.  All lanes compute the same value from LDS broadcasts.
-__device__ inline double sum_stage_costs(const Lds& l, int N) {
-    const double* sdv = l.cs;
-    const double* cev = l.cs + (N + 1);
-    const double* jbv = l.cs + 2 * (N + 1);
-    double sd = sdv[0], ce = cev[0], jb = 0.0;
-    for (int k = 1; k <= N; ++k) {
-        sd = sd + sdv[k];
-        jb = jb + jbv[k];
-        if (k < N) ce = ce + cev[k];
+__device__ inline double sum_stage_costs(const Lds& l, int N, int lane) {
+    // lanes 0, 1, 2 each run one of the three sequential sums (state, control, barrier) over its own
+    // row of l.cs; one instruction stream, three chains.  Then J = (sd + ce) + jb on every lane.
+    const int R = N + 1;
+    const int row = (lane < 3) ? lane : 0;
+    const double* v = l.cs + row * R;
+    const int last = (row == 1) ? N - 1 : N;   // ctrl_energy has N terms
+    // state / control sums start from their k = 0 term, the barrier sum from 0.0 + J_barrier_1
+    double acc = (row == 2) ? 0.0 : v[0];
+    int k = 1;
+    for (; k + 7 <= last; k += 8) {
+        double a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = v[k + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = acc + a[t];
     }
+    for (; k <= last; ++k) acc = acc + v[k];
+    double sd = __shfl(acc, 0, CILQR_WAVE);
+    double ce = __shfl(acc, 1, CILQR_WAVE);
+    double jb = __shfl(acc, 2, CILQR_WAVE);
     return (sd + ce) + jb;
 }
 
@@ -298,45 +465,65 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
         if (k < N) { uk[0] = l.u[2 * k]; uk[1] = l.u[2 * k + 1]; }
         if (k >= 1) { um[0] = l.u[2 * k - 2]; um[1] = l.u[2 * k - 1]; }
         double sd, ce, jb;
-        stage_cost(c, k, xk, uk, um, l.ridx[k], sd, ce, jb);
+        stage_cost(c, l, k, xk, uk, um, l.ridx[k], sd, ce, jb);
         l.cs[k] = sd;
         l.cs[(N + 1) + k] = ce;
         l.cs[2 * (N + 1) + k] = jb;
     }
     __syncthreads();
-    double J = sum_stage_costs(l, N);
+    double J = sum_stage_costs(l, N, lane);
     __syncthreads();
     return J;
 }
 
-// get_total_cost of trial trajectory `a` held in the scratch slab
-__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane) {
+// get_total_cost of trial trajectory `a` held in the scratch slab.  Also leaves the trial's lane
+// indices in l.tidx (accept_trial copies them).
+__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane, int idx0,
+                                          int flags, int* n_fallback, long long* sub = nullptr) {
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + (size_t)a * 7 * R;
+    const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
+    long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
+    // reference points: lane-parallel with proof, serial chain as the fallback
+    bool proven = false;
+    if (!(flags & CILQR_DBG_SERIAL_REF_SCAN))
+        proven = parallel_ref_indices(c, l, lane, idx0, l.ridx,
+                                      [&](int k, double& px, double& py) { px = t[k]; py = t[R + k]; });
+    if (!proven) {
+        *n_fallback += 1;
+        int s = idx0;
+        if (lane == 0) l.tidx[0] = s;
+        for (int i = 1; i <= N; ++i) {
+            s = ref_scan_from(c, l, t[i], t[R + i], s);
+            if (lane == 0) l.tidx[i] = s;
+        }
+        __syncthreads();
+    }
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {t[k], t[R + k], t[2 * R + k], t[3 * R + k]};
         double uk[2] = {0, 0}, um[2] = {0, 0};
         if (k < N) { uk[0] = t[4 * R + k]; uk[1] = t[5 * R + k]; }
         if (k >= 1) { um[0] = t[4 * R + k - 1]; um[1] = t[5 * R + k - 1]; }
-        int ridx = (int)t[6 * R + k];
         double sd, ce, jb;
-        stage_cost(c, k, xk, uk, um, ridx, sd, ce, jb);
+        stage_cost(c, l, k, xk, uk, um, l.tidx[k], sd, ce, jb);
         l.cs[k] = sd;
         l.cs[R + k] = ce;
         l.cs[2 * R + k] = jb;
     }
     __syncthreads();
-    double J = sum_stage_costs(l, N);
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[1] += t1 - t0; t0 = t1; }
+    double J = sum_stage_costs(l, N, lane);
     __syncthreads();
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[2] += t1 - t0; }
     return J;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Initial trajectory (cs:155-197): cold start u = 0, or warm start from last_u shifted by one step;
 // fills LDS x, u, ridx.  Wave-uniform serial rollout.
-__device__ inline void init_trajectory(const Cst& c, const Lds& l, const double x0[4],
-                                       const double* last_u, int lane, int& idx0) {
+__device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4], const double* last_u,
+                                       int lane, int& idx0, int Wcap) {
     const int N = c.N;
     for (int k = lane; k < N; k += CILQR_WAVE) {
         double a = 0.0, b = 0.0;
@@ -350,6 +537,7 @@ __device__ inline void init_trajectory(const Cst& c, const Lds& l, const double 
     }
     __syncthreads();
     idx0 = ref_scan_row0(c, x0[0], x0[1], lane);
+    stage_window(c, l, idx0, Wcap, lane);
     double xc[4] = {x0[0], x0[1], x0[2], x0[3]};
     int s = idx0;
     if (lane == 0) {
@@ -360,7 +548,7 @@ __device__ inline void init_trajectory(const Cst& c, const Lds& l, const double 
         double ui[2] = {l.u[2 * i], l.u[2 * i + 1]};
         double xn[4];
         propagate(c, xc, ui, xn);
-        s = ref_scan_from(c, xn[0], xn[1], s);
+        s = ref_scan_from(c, l, xn[0], xn[1], s);
         if (lane == 0) {
             l.x[4 * (i + 1)] = xn[0]; l.x[4 * (i + 1) + 1] = xn[1];
             l.x[4 * (i + 1) + 2] = xn[2]; l.x[4 * (i + 1) + 3] = xn[3];
@@ -372,33 +560,31 @@ __device__ inline void init_trajectory(const Cst& c, const Lds& l, const double 
 }
 
 // ridx for a trajectory already staged in LDS x (used by the piecewise kernels)
-__device__ inline void ref_indices_lds(const Cst& c, const Lds& l, int lane, int& idx0) {
+__device__ inline void ref_indices_lds(const Cst& c, Lds& l, int lane, int& idx0, int Wcap) {
     const int N = c.N;
     idx0 = ref_scan_row0(c, l.x[0], l.x[1], lane);
+    stage_window(c, l, idx0, Wcap, lane);
     int s = idx0;
     if (lane == 0) l.ridx[0] = s;
     for (int i = 1; i <= N; ++i) {
-        s = ref_scan_from(c, l.x[4 * i], l.x[4 * i + 1], s);
+        s = ref_scan_from(c, l, l.x[4 * i], l.x[4 * i + 1], s);
         if (lane == 0) l.ridx[i] = s;
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward_pass (cs:442-461) for all trial step sizes: lane a < n_alpha uses alpha = 2^-a and also
-// tracks the lane-sample index of every new row (cs:289-314) so that the costs can be evaluated
-// afterwards without another serial scan.
-__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int idx0,
-                                      int n_alpha) {
+// forward_pass (cs:442-461) for all trial step sizes at once: lane a < n_alpha uses alpha = 2^-a.
+// The trial trajectories go to the scratch slab; their reference points are found later, only for
+// the trials whose cost is actually needed.
+__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
     const int N = c.N;
     const int R = N + 1;
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
-        double* t = scr + (size_t)lane * 7 * R;
+        double* t = scr + (size_t)lane * CILQR_TRIAL_ROWS * R;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
-        int s = idx0;
         t[0] = xc[0]; t[R] = xc[1]; t[2 * R] = xc[2]; t[3 * R] = xc[3];
-        t[6 * R] = (double)s;
         for (int i = 0; i < N; ++i) {
             const double* Ki = l.K + 8 * i;
             const double* xi = l.x + 4 * i;
@@ -410,31 +596,29 @@ __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, i
             un[1] = (l.u[2 * i + 1] + k1) + alpha * l.d[2 * i + 1];
             double xn[4];
             propagate(c, xc, un, xn);
-            s = ref_scan_from(c, xn[0], xn[1], s);
             t[4 * R + i] = un[0];
             t[5 * R + i] = un[1];
             t[i + 1] = xn[0];
             t[R + i + 1] = xn[1];
             t[2 * R + i + 1] = xn[2];
             t[3 * R + i + 1] = xn[3];
-            t[6 * R + i + 1] = (double)s;
             xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
         }
     }
     __syncthreads();
 }
 
-// copy trial `a` from the scratch slab into the current trajectory in LDS
+// copy trial `a` (whose cost was evaluated last, so l.tidx is its index row) into the current trajectory
 __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane) {
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + (size_t)a * 7 * R;
+    const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         l.x[4 * k] = t[k];
         l.x[4 * k + 1] = t[R + k];
         l.x[4 * k + 2] = t[2 * R + k];
         l.x[4 * k + 3] = t[3 * R + k];
-        l.ridx[k] = (int)t[6 * R + k];
+        l.ridx[k] = l.tidx[k];
         if (k < N) {
             l.u[2 * k] = t[4 * R + k];
             l.u[2 * k + 1] = t[5 * R + k];
@@ -453,7 +637,10 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, in
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
         int ridx = l.ridx[k];
-        double rx = c.lane_xy[2 * ridx], ry = c.lane_xy[2 * ridx + 1], ryaw = c.lane_yaw[ridx];
+        double rx, ry;
+        lane_point(c, l, ridx, rx, ry);
+        gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
+        const double ryaw = aux[0], sr = aux[1], cr = aux[2];
         double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.ref_velo, e3 = xk[3] - ryaw;
         // prime parts (cs:493-494)
         double lx0 = (2 * e0) * c.w_pos, lx1 = (2 * e1) * c.w_pos, lx2 = (2 * e2) * c.w_vel, lx3 = (2 * e3) * c.w_yaw;
@@ -481,8 +668,6 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, in
             // velocity bounds and road borders (cs:507-533, 560-580)
             double b_vu = c.sq1 * dm_exp(c.sq2 * (xk[2] - c.velo_max));
             double b_vl = c.sq1 * dm_exp(c.sq2 * (c.velo_min - xk[2]));
-            double sr, cr;
-            dm_sincos(ryaw, &sr, &cr);
             double d_sign = e1 * cr - e0 * sr;
             double hyp = dm_hypot(e0, e1);
             double cur_d = (d_sign < 0) ? -hyp : hyp;
@@ -575,7 +760,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, in
 // ---------------------------------------------------------------------------------------------
 // backward_pass (cs:383-440) after the expansion above.  Wave-uniform; V_x, V_xx in registers.
 // Returns true on success, false for a non-PD Q_uu (BACKWARD_PASS_FAIL); fills l.K, l.d, dV.
-__device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
+__device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
     const int N = c.N;
     double Vx[4], V[16];
     {
@@ -710,6 +895,185 @@ __device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, i
         dV[1] += dd[0] * Qu[0] + dd[1] * Qu[1];
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward_pass (cs:383-440), lane-parallel form.  One backward step is two small matrix products
+// and a rank-2 update; written with M = [A | B] (4x6) and W = [V_xx | V_x] (4x5) they become
+//   pass 1:  X = M^T W            (6x5)   rows 0-3: A^T V_xx | A^T V_x,  rows 4-5: B^T V_xx | B^T V_x
+//   pass 2:  Y = X[:, 0:4] M      (6x6)   (A^T V A, -, B^T V A, B^T V B)
+//   Q = l + Y (+ lamb on the Q_uu diagonal);  column 4 of X + (l_x, l_u) = (Q_x, Q_u)
+//   W' = [V_xx' | V_x'] = Q[0:4] + K^T Q_uu K_c + K^T Q_c + Q_ux^T K_c   with K_c = (K | d), Q_c = (Q_ux | Q_u)
+// so every output element is the same expression of 4 (or 2) products summed in index order —
+// the reference's dense Eigen evaluation order, zeros included.  Lane (r', c'') = (lane >> 3,
+// lane & 7) owns one element; operands travel through the small LDS exchange area l.xch, the
+// per-step coefficients come straight from the stage arrays through per-lane address maps.
+// ~170 wave instructions per step instead of ~540 for the wave-uniform form.
+struct LaneMap {
+    int m1[4];  // LDS double-offsets (at step 0) of M[k][r'], k = 0..3
+    int s1[4];  // their per-step strides
+    int m2[4];  // M[k][c'']
+    int s2[4];
+    int lq, slq;  // L[r'][c''] (l_xx / l_uu / zero)
+    int lv, slv;  // l[r'] (l_x / l_u)
+};
+
+__device__ inline void lane_map_M(const Lds& l, int k, int j, int& off, int& stride) {
+    // M = [A | B], A = I + {a02 a03 a12 a13 a32}, B = {b01 b11 dt b31}
+    const int A5 = (int)(l.A5 - l.x), B3 = (int)(l.B3 - l.x), CC = (int)(l.xch - l.x) + CILQR_XCH_CONST;
+    const int ZERO = CC, ONE = CC + 1, DT = CC + 2;
+    off = ZERO; stride = 0;
+    if (j < 4 && k == j) off = ONE;
+    if (j == 2 && k == 0) { off = A5 + 0; stride = 5; }
+    if (j == 2 && k == 1) { off = A5 + 2; stride = 5; }
+    if (j == 2 && k == 3) { off = A5 + 4; stride = 5; }
+    if (j == 3 && k == 0) { off = A5 + 1; stride = 5; }
+    if (j == 3 && k == 1) { off = A5 + 3; stride = 5; }
+    if (j == 4 && k == 2) off = DT;
+    if (j == 5 && k == 0) { off = B3 + 0; stride = 3; }
+    if (j == 5 && k == 1) { off = B3 + 1; stride = 3; }
+    if (j == 5 && k == 3) { off = B3 + 2; stride = 3; }
+}
+
+__device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
+    const int rp = (lane >> 3) % 6, cc = lane & 7;      // lanes >= 48 alias rows 0/1 (results unused)
+    const int ccm = (cc < 6) ? cc : 5;
+    const int CC = (int)(l.xch - l.x) + CILQR_XCH_CONST;
+    for (int k = 0; k < 4; ++k) {
+        lane_map_M(l, k, rp, m.m1[k], m.s1[k]);
+        lane_map_M(l, k, ccm, m.m2[k], m.s2[k]);
+    }
+    // L[r'][c'']: l_xx (7 packed entries 00 01 03 11 13 33 22), l_uu diagonal, zero elsewhere
+    const int LXX = (int)(l.lxx - l.x), LUU = (int)(l.luu - l.x);
+    m.lq = CC; m.slq = 0;
+    if (rp < 4 && cc < 4) {
+        int a = (rp < cc) ? rp : cc, b = (rp < cc) ? cc : rp, e = -1;
+        if (a == 0 && b == 0) e = 0;
+        if (a == 0 && b == 1) e = 1;
+        if (a == 0 && b == 3) e = 2;
+        if (a == 1 && b == 1) e = 3;
+        if (a == 1 && b == 3) e = 4;
+        if (a == 3 && b == 3) e = 5;
+        if (a == 2 && b == 2) e = 6;
+        if (e >= 0) { m.lq = LXX + e; m.slq = 7; }
+    } else if (rp >= 4 && cc == rp) {
+        m.lq = LUU + (rp - 4); m.slq = 2;
+    }
+    if (rp < 4) { m.lv = (int)(l.lx - l.x) + rp; m.slv = 4; }
+    else { m.lv = (int)(l.lu - l.x) + (rp - 4); m.slv = 2; }
+}
+
+__device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
+    const int N = c.N;
+    const int rp = (lane >> 3) % 6, cc = lane & 7;
+    const bool is_w = (lane < 32) && (cc <= 4);             // owns W'[r][c], r = rp < 4
+    double* const Wt = l.xch + CILQR_XCH_WT;
+    double* const Xs = l.xch + CILQR_XCH_X;
+    double* const Qs = l.xch + CILQR_XCH_Q;
+    double* const qv = l.xch + CILQR_XCH_QV;
+    const double* const base = l.x;
+    LaneMap mp;
+    make_lane_map(l, lane, mp);
+    if (lane == 0) {
+        l.xch[CILQR_XCH_CONST + 0] = 0.0;
+        l.xch[CILQR_XCH_CONST + 1] = 1.0;
+        l.xch[CILQR_XCH_CONST + 2] = c.dt;
+        l.xch[CILQR_XCH_CONST + 3] = 0.0;
+    }
+    __syncthreads();
+    // W = [l_xx[N] | l_x[N]]
+    if (is_w) {
+        double v = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
+        Wt[4 * cc + rp] = v;
+    }
+    __syncthreads();
+    dV[0] = 0.0;
+    dV[1] = 0.0;
+    const int wc = (cc <= 4) ? cc : 4;
+    const bool diag = (rp >= 4) && (cc == rp);
+    // addresses of the c-version / r-version operands of the rank-2 update
+    const int qc0 = (cc < 4) ? (CILQR_XCH_Q + 8 * 4 + cc) : (CILQR_XCH_QV + 4);
+    const int qc1 = (cc < 4) ? (CILQR_XCH_Q + 8 * 5 + cc) : (CILQR_XCH_QV + 5);
+    const int r4 = rp & 3;
+    for (int i = N - 1; i >= 0; --i) {
+        // per-lane coefficients of this step
+        double m1[4], m2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m1[k] = base[mp.m1[k] + mp.s1[k] * i];
+            m2[k] = base[mp.m2[k] + mp.s2[k] * i];
+        }
+        const double Lq = base[mp.lq + mp.slq * i];
+        const double lv = base[mp.lv + mp.slv * i];
+        // pass 1
+        const double w0 = Wt[4 * wc], w1 = Wt[4 * wc + 1], w2 = Wt[4 * wc + 2], w3 = Wt[4 * wc + 3];
+        const double X = ((m1[0] * w0 + m1[1] * w1) + m1[2] * w2) + m1[3] * w3;
+        const double Zv = lv + X; // (Q_x, Q_u) on the lanes of column 4
+        if (lane < 48) {
+            if (cc < 4) Xs[4 * rp + cc] = X;
+            if (cc == 4) qv[rp] = Zv;
+        }
+        __syncthreads();
+        // pass 2
+        const double x0 = Xs[4 * rp], x1 = Xs[4 * rp + 1], x2 = Xs[4 * rp + 2], x3 = Xs[4 * rp + 3];
+        const double Y = ((x0 * m2[0] + x1 * m2[1]) + x2 * m2[2]) + x3 * m2[3];
+        double Q = Lq + Y;
+        if (diag) Q = Q + lamb;
+        if (lane < 48 && cc < 6) Qs[8 * rp + cc] = Q;
+        __syncthreads();
+        // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
+        const double Quu0 = Qs[8 * 4 + 4], Quu1 = Qs[8 * 4 + 5], Quu2 = Qs[8 * 5 + 4], Quu3 = Qs[8 * 5 + 5];
+        const double Qu0 = qv[4], Qu1 = qv[5];
+        const double c0 = l.xch[qc0], c1 = l.xch[qc1];                 // (Q_ux | Q_u)[:, c]
+        const double r0 = Qs[8 * 4 + r4], r1 = Qs[8 * 5 + r4];         // Q_ux[:, r]
+        bool fail = false;
+        if (Quu0 <= 0.0) {
+            fail = true;
+        } else {
+            double l00 = dm_sqrt(Quu0);
+            double l10 = Quu2 / l00;
+            double piv1 = Quu3 - l10 * l10;
+            if (piv1 <= 0.0) fail = true;
+        }
+        if (fail) return false;
+        const double det = Quu0 * Quu3 - Quu2 * Quu1;
+        const double invdet = 1.0 / det;
+        const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
+        const double d0 = n00 * Qu0 + n01 * Qu1;
+        const double d1 = n10 * Qu0 + n11 * Qu1;
+        const double kc0 = n00 * c0 + n01 * c1, kc1 = n10 * c0 + n11 * c1; // (K | d)[:, c]
+        const double kr0 = n00 * r0 + n01 * r1, kr1 = n10 * r0 + n11 * r1; // K[:, r]
+        const double p0 = kr0 * Quu0 + kr1 * Quu2;                         // (K^T Q_uu)[r][:]
+        const double p1 = kr0 * Quu1 + kr1 * Quu3;
+        const double ta = p0 * kc0 + p1 * kc1;
+        const double tb = kr0 * c0 + kr1 * c1;
+        const double tc = r0 * kc0 + r1 * kc1;
+        const double own = (cc < 4) ? Q : Zv;
+        const double wn = ((own + ta) + tb) + tc;
+        if (is_w) Wt[4 * cc + rp] = wn;
+        if (lane < 5) { // row r' = 0 holds (K | d) column c
+            if (lane < 4) {
+                l.K[8 * i + lane] = kc0;
+                l.K[8 * i + 4 + lane] = kc1;
+            } else {
+                l.d[2 * i] = kc0;
+                l.d[2 * i + 1] = kc1;
+            }
+        }
+        // expected cost reduction (cs:435-436)
+        const double hd0 = 0.5 * d0, hd1 = 0.5 * d1;
+        const double g0 = hd0 * Quu0 + hd1 * Quu2;
+        const double g1 = hd0 * Quu1 + hd1 * Quu3;
+        dV[0] += g0 * d0 + g1 * d1;
+        dV[1] += d0 * Qu0 + d1 * Qu1;
+        __syncthreads();
+    }
+    return true;
+}
+
+__device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags) {
+    if (flags & CILQR_DBG_UNIFORM_BACKWARD) return backward_sweep_uniform(c, l, lamb, lane, dV);
+    return backward_sweep_lanes(c, l, lamb, lane, dV);
 }
 
 } // namespace cilqr

@@ -106,7 +106,7 @@ DM_FN double dm_trig_reduce(double x, int* quadrant, int* valid) {
     r = DM_FMA(-nd, P2, r);
     r = DM_FMA(-nd, P3, r);
     r = DM_FMA(-nd, P4, r);
-    *quadrant = (int)((long long)nd & 3LL);
+    *quadrant = ((int)nd) & 3; /* |nd| < 2^30 here */
     *valid = ok;
     return r;
 }

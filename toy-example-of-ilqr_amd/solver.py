@@ -131,10 +131,14 @@ class BatchedCILQR:
         check(self._lib.cilqr_set_phase_profiling(self._h, 1 if on else 0), "cilqr_set_phase_profiling")
 
     def phase_cycles(self, B):
-        """[B][8] cycles: init, derivatives, backward, rollout, trial cost, accept, total, iterations"""
-        out = np.zeros((B, 8), dtype=np.int64)
+        """[B][10]: cycles of init, derivatives, backward, rollout, trial cost, accept, total; then
+        iterations, serial-ref-scan fallbacks, trials"""
+        out = np.zeros((B, _lib.PROF_SLOTS), dtype=np.int64)
         check(self._lib.cilqr_get_phase_cycles(self._h, _p(out), int(B)), "cilqr_get_phase_cycles")
         return out
+
+    def set_debug_flags(self, flags):
+        check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
