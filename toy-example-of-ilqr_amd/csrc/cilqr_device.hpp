@@ -266,80 +266,86 @@ __device__ inline double lane_d2(const Cst& c, const Lds& l, double px, double p
 
 // A local minimum of the distance profile of one row near `guess` (>= lo): walk forward while the
 // distance strictly decreases, otherwise walk backward to where the strict decrease starts.  Only
-// a CANDIDATE for cs:295-311 — trial_ref_indices() proves or rejects it.
+// a CANDIDATE for cs:295-311 — verify_interval() proves or rejects it.
 __device__ inline int local_min_near(const Cst& c, const Lds& l, double px, double py, int guess, int lo) {
     int j = guess;
+    // the three neighbours are fetched together: when the guess is already right this is all it takes
     double cur = lane_d2(c, l, px, py, j);
     double nxt = lane_d2(c, l, px, py, j + 1);
+    double prv = lane_d2(c, l, px, py, (j > lo) ? j - 1 : j);
     if (dist_less(nxt, cur)) {
         j += 1;
         cur = nxt;
         for (;;) {
             double n1 = lane_d2(c, l, px, py, j + 1);
             double n2 = lane_d2(c, l, px, py, j + 2);
-            bool f1 = dist_less(n1, cur);
-            bool f2 = dist_less(n2, n1);
-            int adv = f1 ? (f2 ? 2 : 1) : 0;
+            double n3 = lane_d2(c, l, px, py, j + 3);
+            double n4 = lane_d2(c, l, px, py, j + 4);
+            bool f1 = dist_less(n1, cur), f2 = dist_less(n2, n1), f3 = dist_less(n3, n2), f4 = dist_less(n4, n3);
+            int adv = f1 ? (f2 ? (f3 ? (f4 ? 4 : 3) : 2) : 1) : 0;
             j += adv;
-            if (adv < 2) break;
-            cur = n2;
+            if (adv < 4) break;
+            cur = n4;
         }
     } else {
         while (j > lo) {
-            double prv = lane_d2(c, l, px, py, j - 1);
             if (dist_less(cur, prv)) break; // strictly decreasing into j: the reference would not stop at j-1
             j -= 1;
             cur = prv;
+            prv = lane_d2(c, l, px, py, (j > lo) ? j - 1 : j);
         }
     }
     return j;
 }
 
-// get_ref_exact_points (cs:289-314) for a whole trajectory with lane = row.
-// The reference chains the rows: idx[k] = first j >= idx[k-1] with !(d_k(j+1) < d_k(j)).  Here every
-// row first finds a candidate m[k] near guess[k] independently, then row k checks, with the SAME
-// comparisons the reference makes, that d_k strictly decreases on [m[k-1], m[k]] and stops
-// decreasing at m[k]; if that holds for every row then idx == m by induction from idx[0] = idx0.
-// Otherwise (non-monotone candidates, a missed earlier minimum, ...) the caller falls back to the
-// serial chain.  xy(k, px, py) yields row k's position.  Returns true when l.tidx[0..N] is proven.
-template <class XY>
-__device__ inline bool parallel_ref_indices(const Cst& c, const Lds& l, int lane, int idx0, const int* guess,
-                                            XY xy) {
-    const int N = c.N;
-    for (int k = lane; k <= N; k += CILQR_WAVE) {
-        int m = idx0;
-        if (k > 0) {
-            double px, py;
-            xy(k, px, py);
-            int g = guess[k];
-            g = (g < idx0) ? idx0 : g;
-            g = (g > c.L - 1) ? c.L - 1 : g;
-            m = local_min_near(c, l, px, py, g, idx0);
-        }
-        l.tidx[k] = m;
+// Cheap sufficient form of verify_interval() for an interval that lies inside the LDS window: every
+// interior comparison must hold with a safety factor (so that it also holds for the rounded
+// square roots the reference compares) and d(b+1) >= d(b) (then hypot(b+1) < hypot(b) is false).
+// A `false` only means "not proven this way".
+__device__ inline bool verify_window_fast(const Lds& l, double px, double py, int a, int b) {
+    const int o = a - l.w0, len = b - a;
+    if (o < 0 || len < 0 || o + len + 1 >= l.W) return false;
+    const double Ksafe = 0.99999999999999644729; // 1 - 2^-48
+    const double* w = l.win + 2 * o;
+    double ex = px - w[0], ey = py - w[1];
+    double prev = ex * ex + ey * ey;
+    bool good = true;
+    for (int t = 1; t <= len; ++t) {
+        ex = px - w[2 * t];
+        ey = py - w[2 * t + 1];
+        const double cur = ex * ex + ey * ey;
+        good = good && (cur < prev * Ksafe);
+        prev = cur;
     }
-    __syncthreads();
-    bool ok = true;
-    for (int k = lane; k <= N; k += CILQR_WAVE) {
-        if (k == 0) continue;
-        int a = l.tidx[k - 1], b = l.tidx[k];
-        bool good = (a <= b);
-        if (good) {
-            double px, py;
-            xy(k, px, py);
-            double cur = lane_d2(c, l, px, py, a);
-            for (int j = a; j < b && good; ++j) {
-                double nx = lane_d2(c, l, px, py, j + 1);
-                good = dist_less(nx, cur);
-                cur = nx;
+    ex = px - w[2 * (len + 1)];
+    ey = py - w[2 * (len + 1) + 1];
+    const double nxt = ex * ex + ey * ey;
+    return good && (nxt >= prev);
+}
+
+// With the comparisons the reference makes: does d strictly decrease on [a, b] (a <= b) and stop
+// decreasing at b?  Eight candidates per trip are fetched together.
+__device__ inline bool verify_interval(const Cst& c, const Lds& l, double px, double py, int a, int b) {
+    double prev = lane_d2(c, l, px, py, a);
+    int j = a;
+    for (;;) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = lane_d2(c, l, px, py, j + 1 + t);
+        bool good = true, done = false;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pos = j + 1 + t;
+            const bool f = dist_less(v[t], (t == 0) ? prev : v[t - 1]);
+            if (!done) {
+                if (pos <= b) { if (!f) { good = false; done = true; } }
+                else { good = !f; done = true; }   // pos == b + 1
             }
-            if (good) good = !dist_less(lane_d2(c, l, px, py, b + 1), cur);
         }
-        ok = ok && good;
+        if (done) return good;
+        j += 8;
+        prev = v[7];
     }
-    bool all_ok = (__ballot(!ok) == 0ULL);
-    __syncthreads();
-    return all_ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,17 +484,88 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
 
 // get_total_cost of trial trajectory `a` held in the scratch slab.  Also leaves the trial's lane
 // indices in l.tidx (accept_trial copies them).
+//
+// Reference points (cs:289-314), lane = row.  The reference chains the rows:
+// idx[k] = first j >= idx[k-1] with !(d_k(j+1) < d_k(j)).  Here every row first finds a candidate
+// m[k] near the index the CURRENT trajectory has on that row, then row k checks — with the same
+// comparisons the reference makes — that d_k strictly decreases on [m[k-1], m[k]] and stops
+// decreasing at m[k].  If that holds for every row, idx == m by induction from idx[0] = idx0;
+// otherwise (non-monotone candidates, an earlier minimum missed, ...) the serial chain runs.
+#define CILQR_CHUNKS 2 /* rows per lane: CILQR_MAX_HORIZON + 1 <= 2 * 64 + 1 is handled by row N+1==129 never occurring */
 __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane, int idx0,
                                           int flags, int* n_fallback, long long* sub = nullptr) {
     const int N = c.N;
     const int R = N + 1;
     const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
     long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
-    // reference points: lane-parallel with proof, serial chain as the fallback
+    // this lane's rows of the trial, fetched once
+    double xk[CILQR_CHUNKS][4], uk[CILQR_CHUNKS][2], um[CILQR_CHUNKS][2];
+    int guess[CILQR_CHUNKS];
+#pragma unroll
+    for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+        const int k = lane + CILQR_WAVE * ch;
+        xk[ch][0] = xk[ch][1] = xk[ch][2] = xk[ch][3] = 0.0;
+        uk[ch][0] = uk[ch][1] = um[ch][0] = um[ch][1] = 0.0;
+        guess[ch] = idx0;
+        if (k <= N) {
+            xk[ch][0] = t[k]; xk[ch][1] = t[R + k]; xk[ch][2] = t[2 * R + k]; xk[ch][3] = t[3 * R + k];
+            if (k < N) { uk[ch][0] = t[4 * R + k]; uk[ch][1] = t[5 * R + k]; }
+            if (k >= 1) { um[ch][0] = t[4 * R + k - 1]; um[ch][1] = t[5 * R + k - 1]; }
+            guess[ch] = l.ridx[k];
+        }
+    }
     bool proven = false;
-    if (!(flags & CILQR_DBG_SERIAL_REF_SCAN))
-        proven = parallel_ref_indices(c, l, lane, idx0, l.ridx,
-                                      [&](int k, double& px, double& py) { px = t[k]; py = t[R + k]; });
+    if (!(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
+        // level 0: the trial keeps the current trajectory's indices (small steps: the usual case of a
+        // failing line search) — one cheap check per row, no search, no exchange
+        bool ok0 = true;
+#pragma unroll
+        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+            const int k = lane + CILQR_WAVE * ch;
+            if (k >= 1 && k <= N) ok0 = ok0 && verify_window_fast(l, xk[ch][0], xk[ch][1], l.ridx[k - 1], guess[ch]);
+        }
+        if (__ballot(!ok0) == 0ULL) {
+#pragma unroll
+            for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+                const int k = lane + CILQR_WAVE * ch;
+                if (k <= N) l.tidx[k] = guess[ch];
+            }
+            proven = true;
+            __syncthreads();
+        }
+    }
+    if (!proven && !(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
+        // level 1: independent search for a candidate per row, then the proof
+#pragma unroll
+        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+            const int k = lane + CILQR_WAVE * ch;
+            if (k <= N) {
+                int m = idx0;
+                if (k > 0) {
+                    int g = guess[ch];
+                    g = (g < idx0) ? idx0 : g;
+                    g = (g > c.L - 1) ? c.L - 1 : g;
+                    m = local_min_near(c, l, xk[ch][0], xk[ch][1], g, idx0);
+                }
+                l.tidx[k] = m;
+            }
+        }
+        __syncthreads();
+        bool ok = true;
+#pragma unroll
+        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+            const int k = lane + CILQR_WAVE * ch;
+            if (k >= 1 && k <= N) {
+                const int lo = l.tidx[k - 1], hi = l.tidx[k];
+                bool good = (lo <= hi);
+                if (good && !verify_window_fast(l, xk[ch][0], xk[ch][1], lo, hi))
+                    good = verify_interval(c, l, xk[ch][0], xk[ch][1], lo, hi);
+                ok = ok && good;
+            }
+        }
+        proven = (__ballot(!ok) == 0ULL);
+        __syncthreads();
+    }
     if (!proven) {
         *n_fallback += 1;
         int s = idx0;
@@ -500,16 +577,16 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         __syncthreads();
     }
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
-    for (int k = lane; k <= N; k += CILQR_WAVE) {
-        double xk[4] = {t[k], t[R + k], t[2 * R + k], t[3 * R + k]};
-        double uk[2] = {0, 0}, um[2] = {0, 0};
-        if (k < N) { uk[0] = t[4 * R + k]; uk[1] = t[5 * R + k]; }
-        if (k >= 1) { um[0] = t[4 * R + k - 1]; um[1] = t[5 * R + k - 1]; }
-        double sd, ce, jb;
-        stage_cost(c, l, k, xk, uk, um, l.tidx[k], sd, ce, jb);
-        l.cs[k] = sd;
-        l.cs[R + k] = ce;
-        l.cs[2 * R + k] = jb;
+#pragma unroll
+    for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+        const int k = lane + CILQR_WAVE * ch;
+        if (k <= N) {
+            double sd, ce, jb;
+            stage_cost(c, l, k, xk[ch], uk[ch], um[ch], l.tidx[k], sd, ce, jb);
+            l.cs[k] = sd;
+            l.cs[R + k] = ce;
+            l.cs[2 * R + k] = jb;
+        }
     }
     __syncthreads();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[1] += t1 - t0; t0 = t1; }

@@ -13,8 +13,9 @@
  *   - no tables, no data-dependent branches in the fast paths (selects only) — wave-friendly.
  *
  * Accuracy (checked in tests/test_detmath.py against libm): exp, sin, cos, atan <= 2 ulp,
- * tan <= 4 ulp on the solver's working ranges.  Domain: |x| <= 2^30 for the trigonometric
- * functions (beyond that, and for non-finite input, they return NaN on both sides).
+ * tan <= 4 ulp on the solver's working ranges.  The trigonometric functions are accurate for
+ * |x| <~ 2^30; beyond that they return meaningless but still host/device-identical values, and
+ * NaN for non-finite input.
  *
  * The polynomial kernels use the classic fdlibm minimax coefficient sets (public constants).
  */
@@ -47,6 +48,31 @@ DM_FN double dm_inf(void) { return dm_from_bits(0x7ff0000000000000ULL); }
 /* 2^k for k in [-1022, 1023] */
 DM_FN double dm_pow2i(int k) { return dm_from_bits((unsigned long long)(k + 1023) << 52); }
 
+/* double -> int32 with the GPU's conversion semantics on both sides: saturating, NaN -> 0
+ * (v_cvt_i32_f64 does this natively; x86's cvttsd2si would return INT_MIN instead) */
+DM_FN int dm_f2i_sat(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)x;
+#else
+    if (x != x) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return (-2147483647 - 1);
+    return (int)x;
+#endif
+}
+
+/* p * 2^k, k in [-1100, 1100], |p| in [0.5, 2]: one correctly rounded scaling (v_ldexp_f64 on the
+ * device; on the host two multiplications, the first of which is exact) */
+DM_FN double dm_scale2(double p, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexp(p, k);
+#else
+    int k1 = k >> 1;
+    int k2 = k - k1;
+    return (p * dm_pow2i(k1)) * dm_pow2i(k2);
+#endif
+}
+
 DM_FN double dm_sqrt(double x) { return __builtin_sqrt(x); }
 
 /* reference call sites use hypot() from libm (src/cilqr_solver.cpp:237,299,509,528);
@@ -58,7 +84,8 @@ DM_FN double dm_exp(double x) {
     const double LN2HI = 6.93147180369123816490e-01; /* 32 trailing zero bits */
     const double LN2LO = 1.90821492927058770002e-10;
     const double MAGIC = 6755399441055744.0; /* 1.5 * 2^52: round-to-nearest-even integer */
-    /* clamp so the integer part stays small; results for clamped inputs are fixed up below */
+    /* clamp so that the scaling exponent stays in range: exp(720) overflows to +inf and exp(-760)
+     * underflows to +0 through the ordinary arithmetic below; NaN passes through the compares */
     double xc = x;
     xc = (xc > 720.0) ? 720.0 : xc;
     xc = (xc < -760.0) ? -760.0 : xc;
@@ -80,55 +107,36 @@ DM_FN double dm_exp(double x) {
     p = DM_FMA(p, r, 0.5);
     p = DM_FMA(p, r, 1.0);
     p = DM_FMA(p, r, 1.0);
-    int k = (int)kd;
-    int k1 = k >> 1;
-    int k2 = k - k1;
-    double res = (p * dm_pow2i(k1)) * dm_pow2i(k2);
-    res = (x > 709.782712893384) ? dm_inf() : res;
-    res = (x < -745.1332191019412) ? 0.0 : res;
-    res = (x != x) ? x : res;
-    return res;
+    return dm_scale2(p, dm_f2i_sat(kd)); /* NaN in -> NaN out (p is NaN) */
 }
 
 /* ---- trigonometric range reduction: x = n*(pi/2) + r, |r| <= pi/4 (+eps) ---- */
-DM_FN double dm_trig_reduce(double x, int* quadrant, int* valid) {
+DM_FN double dm_trig_reduce(double x, int* quadrant) {
     const double INV_PIO2 = 6.36619772367581382433e-01;
     const double P1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
     const double P2 = 6.07710050630396597660e-11;  /* next 33 bits */
     const double P3 = 2.02226624871116645580e-21;  /* next 33 bits */
     const double P4 = 8.47842766036889956997e-32;  /* remainder */
     const double MAGIC = 6755399441055744.0;
-    double ax = (x < 0.0) ? -x : x;
-    int ok = (ax <= 1073741824.0); /* false for NaN and inf too */
-    double xs = ok ? x : 0.0;
-    double nd = (xs * INV_PIO2 + MAGIC) - MAGIC;
-    double r = DM_FMA(-nd, P1, xs);
+    /* accurate for |x| <~ 2^30; beyond that the result is meaningless but still the same on host
+     * and device (saturating quadrant conversion), and +-inf / NaN give NaN through r */
+    double nd = (x * INV_PIO2 + MAGIC) - MAGIC;
+    double r = DM_FMA(-nd, P1, x);
     r = DM_FMA(-nd, P2, r);
     r = DM_FMA(-nd, P3, r);
     r = DM_FMA(-nd, P4, r);
-    *quadrant = ((int)nd) & 3; /* |nd| < 2^30 here */
-    *valid = ok;
+    *quadrant = dm_f2i_sat(nd) & 3;
     return r;
 }
 
-DM_FN double dm_ksin(double r) {
+/* sin and cos kernels on |r| <= pi/4 share z = r*r */
+DM_FN void dm_ksincos(double r, double* s_out, double* c_out) {
     const double S1 = -1.66666666666666324348e-01;
     const double S2 = 8.33333333332248946124e-03;
     const double S3 = -1.98412698298579493134e-04;
     const double S4 = 2.75573137070700676789e-06;
     const double S5 = -2.50507602534068634195e-08;
     const double S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = DM_FMA(z, S6, S5);
-    p = DM_FMA(z, p, S4);
-    p = DM_FMA(z, p, S3);
-    p = DM_FMA(z, p, S2);
-    p = DM_FMA(z, p, S1);
-    double v = z * r;
-    return DM_FMA(v, p, r);
-}
-
-DM_FN double dm_kcos(double r) {
     const double C1 = 4.16666666666666019037e-02;
     const double C2 = -1.38888888888741095749e-03;
     const double C3 = 2.48015872894767294178e-05;
@@ -136,28 +144,38 @@ DM_FN double dm_kcos(double r) {
     const double C5 = 2.08757232129817482790e-09;
     const double C6 = -1.13596475577881948265e-11;
     double z = r * r;
-    double p = DM_FMA(z, C6, C5);
-    p = DM_FMA(z, p, C4);
-    p = DM_FMA(z, p, C3);
-    p = DM_FMA(z, p, C2);
-    p = DM_FMA(z, p, C1);
+    double p = DM_FMA(z, S6, S5);
+    p = DM_FMA(z, p, S4);
+    p = DM_FMA(z, p, S3);
+    p = DM_FMA(z, p, S2);
+    p = DM_FMA(z, p, S1);
+    double v = z * r;
+    *s_out = DM_FMA(v, p, r);
+    double q = DM_FMA(z, C6, C5);
+    q = DM_FMA(z, q, C4);
+    q = DM_FMA(z, q, C3);
+    q = DM_FMA(z, q, C2);
+    q = DM_FMA(z, q, C1);
     double hz = 0.5 * z;
     double w = 1.0 - hz;
-    double t = z * p;
-    return w + (((1.0 - w) - hz) + z * t);
+    double t = z * q;
+    *c_out = w + (((1.0 - w) - hz) + z * t);
+}
+
+/* flip the sign of d when bit is non-zero (bit is 0 or any value with the wanted truth) */
+DM_FN double dm_negate_if(double d, int cond) {
+    return dm_from_bits(dm_to_bits(d) ^ ((unsigned long long)(cond != 0) << 63));
 }
 
 DM_FN void dm_sincos(double x, double* s_out, double* c_out) {
-    int q, ok;
-    double r = dm_trig_reduce(x, &q, &ok);
-    double s = dm_ksin(r);
-    double c = dm_kcos(r);
+    int q;
+    double r = dm_trig_reduce(x, &q);
+    double s, c;
+    dm_ksincos(r, &s, &c);
     double ss = (q & 1) ? c : s;
     double cc = (q & 1) ? s : c;
-    ss = (q & 2) ? -ss : ss;
-    cc = ((q + 1) & 2) ? -cc : cc;
-    *s_out = ok ? ss : dm_nan();
-    *c_out = ok ? cc : dm_nan();
+    *s_out = dm_negate_if(ss, q & 2);
+    *c_out = dm_negate_if(cc, (q + 1) & 2);
 }
 
 DM_FN double dm_sin(double x) {
@@ -173,14 +191,13 @@ DM_FN double dm_cos(double x) {
 }
 
 DM_FN double dm_tan(double x) {
-    int q, ok;
-    double r = dm_trig_reduce(x, &q, &ok);
-    double s = dm_ksin(r);
-    double c = dm_kcos(r);
-    double num = (q & 1) ? -c : s;
+    int q;
+    double r = dm_trig_reduce(x, &q);
+    double s, c;
+    dm_ksincos(r, &s, &c);
+    double num = (q & 1) ? c : s;
     double den = (q & 1) ? s : c;
-    double t = num / den;
-    return ok ? t : dm_nan();
+    return dm_negate_if(num, q & 1) / den;
 }
 
 DM_FN double dm_atan(double x) {
