@@ -33,7 +33,7 @@ extern "C" {
 #define CILQR_ERR_UNSUPPORTED (-4)
 #define CILQR_ERR_NO_DEVICE (-5)
 
-#define CILQR_MAX_HORIZON 128
+#define CILQR_MAX_HORIZON 127
 #define CILQR_MAX_ALPHA_TRIALS 20 /* alpha = 1, 1/2, ... while > 1e-6 (src/cilqr_solver.cpp:354) */
 
 /* The scalars CILQRSolver::CILQRSolver copies out of GlobalConfig (src/cilqr_solver.cpp:17-83);

@@ -17,7 +17,7 @@ ERR_DEVICE = -3
 ERR_UNSUPPORTED = -4
 ERR_NO_DEVICE = -5
 
-MAX_HORIZON = 128
+MAX_HORIZON = 127
 MAX_ALPHA_TRIALS = 20
 PROF_SLOTS = 13
 DBG_SERIAL_REF_SCAN = 1

@@ -21,6 +21,10 @@ using namespace cilqr;
 // ------------------------------------------------------------------------------------------------
 extern __shared__ double g_lds[];
 
+#ifndef CILQR_SOLVE_WAVES_PER_SIMD
+#define CILQR_SOLVE_WAVES_PER_SIMD 1
+#endif
+
 struct BatchArgs {
     const cilqr_params* params;
     const DevScene* scenes;
@@ -56,7 +60,10 @@ __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
 }
 
 // CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
-__global__ void __launch_bounds__(CILQR_WAVE)
+// DBG = true compiles the testing-aid paths in (cilqr_set_debug_flags); the production
+// instantiation carries neither their code nor their registers.
+template <bool DBG, int NCH>
+__global__ void __launch_bounds__(CILQR_WAVE, CILQR_SOLVE_WAVES_PER_SIMD)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
         cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
@@ -96,7 +103,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
-        bool ok = backward_sweep(c, l, lamb, lane, dV, a.flags);
+        bool ok = backward_sweep<DBG>(c, l, lamb, lane, dV, a.flags);
         __syncthreads();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
@@ -110,7 +117,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             bool done = false;
             for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
                 const double alpha = dm_pow2i(-t);
-                new_J = total_cost_trial(c, l, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                new_J = total_cost_trial<DBG, NCH>(c, l, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
                 PROF_ADD(PH_TRIAL_COST);
                 trials++;
                 const double decay = J_cur - new_J;
@@ -258,7 +265,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
             }
         }
         int nfb = 0;
-        double J = total_cost_trial(c, l, scr, t, lane, idx0, a.flags, &nfb);
+        double J = total_cost_trial<true, 2>(c, l, scr, t, lane, idx0, a.flags, &nfb);
         if (lane == 0 && J_out) J_out[(size_t)b * n_alpha + t] = J;
     }
 }
@@ -320,7 +327,7 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
     ref_indices_lds(c, l, lane, idx0, a.W);
     cost_and_model_derivatives(c, l, lane);
     double dV[2];
-    bool ok = backward_sweep(c, l, lamb[b], lane, dV, a.flags);
+    bool ok = backward_sweep<true>(c, l, lamb[b], lane, dV, a.flags);
     __syncthreads();
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) o_K[(size_t)b * 8 * N + e] = l.K[e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) o_d[(size_t)b * 2 * N + e] = l.d[e];
@@ -542,7 +549,7 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
     if (!h || !params || n_params < 1) return fail(CILQR_ERR_BAD_ARG, "bad params table");
     for (int i = 0; i < n_params; ++i) {
         const cilqr_params& p = params[i];
-        if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 128]");
+        if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 127]");
         if (p.N != params[0].N) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share N");
         if (p.solve_type != 0) return fail(CILQR_ERR_UNSUPPORTED, "solve_type alm is not implemented on the device yet");
         if (p.reference_point != 0 && p.reference_point != 1) return fail(CILQR_ERR_BAD_ARG, "reference_point must be 0 or 1");
@@ -724,8 +731,14 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         h->prof_B = B;
     }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(k_solve, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
-                       d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+    {
+        auto kern = k_solve<false, 1>;
+        const bool two = (a.N + 1 > CILQR_WAVE);
+        if (a.flags != 0) kern = two ? k_solve<true, 2> : k_solve<true, 1>;
+        else kern = two ? k_solve<false, 2> : k_solve<false, 1>;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
+                           d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+    }
     HIP_TRY(hipGetLastError());
     if (h->timing) {
         HIP_TRY(hipEventRecord(h->ev1, s));

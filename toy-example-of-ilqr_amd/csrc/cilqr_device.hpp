@@ -173,8 +173,9 @@ __host__ __device__ inline size_t scratch_doubles(int N) {
 
 // ---------------------------------------------------------------------------------------------
 // ut:262-283 kinematic_propagate
+template <int RP>
 __device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4]) {
-    if (c.rp == 0) {
+    if (RP == 0) {
         double sn, cs;
         dm_sincos(x[3], &sn, &cs);
         double tn = dm_tan(u[1]);
@@ -491,18 +492,20 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
 // comparisons the reference makes — that d_k strictly decreases on [m[k-1], m[k]] and stops
 // decreasing at m[k].  If that holds for every row, idx == m by induction from idx[0] = idx0;
 // otherwise (non-monotone candidates, an earlier minimum missed, ...) the serial chain runs.
-#define CILQR_CHUNKS 2 /* rows per lane: CILQR_MAX_HORIZON + 1 <= 2 * 64 + 1 is handled by row N+1==129 never occurring */
+// NCH = rows per lane: 1 when N + 1 <= 64, else 2 (N + 1 <= 128; cilqr_set_params caps N at 127)
+template <bool DBG, int NCH>
 __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane, int idx0,
-                                          int flags, int* n_fallback, long long* sub = nullptr) {
+                                          int flags_in, int* n_fallback, long long* sub = nullptr) {
+    const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
     const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
     long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
     // this lane's rows of the trial, fetched once
-    double xk[CILQR_CHUNKS][4], uk[CILQR_CHUNKS][2], um[CILQR_CHUNKS][2];
-    int guess[CILQR_CHUNKS];
+    double xk[NCH][4], uk[NCH][2], um[NCH][2];
+    int guess[NCH];
 #pragma unroll
-    for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int k = lane + CILQR_WAVE * ch;
         xk[ch][0] = xk[ch][1] = xk[ch][2] = xk[ch][3] = 0.0;
         uk[ch][0] = uk[ch][1] = um[ch][0] = um[ch][1] = 0.0;
@@ -520,13 +523,13 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         // failing line search) — one cheap check per row, no search, no exchange
         bool ok0 = true;
 #pragma unroll
-        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
             if (k >= 1 && k <= N) ok0 = ok0 && verify_window_fast(l, xk[ch][0], xk[ch][1], l.ridx[k - 1], guess[ch]);
         }
         if (__ballot(!ok0) == 0ULL) {
 #pragma unroll
-            for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+            for (int ch = 0; ch < NCH; ++ch) {
                 const int k = lane + CILQR_WAVE * ch;
                 if (k <= N) l.tidx[k] = guess[ch];
             }
@@ -537,7 +540,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
     if (!proven && !(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
         // level 1: independent search for a candidate per row, then the proof
 #pragma unroll
-        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
             if (k <= N) {
                 int m = idx0;
@@ -553,7 +556,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         __syncthreads();
         bool ok = true;
 #pragma unroll
-        for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+        for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
             if (k >= 1 && k <= N) {
                 const int lo = l.tidx[k - 1], hi = l.tidx[k];
@@ -578,7 +581,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
     }
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
 #pragma unroll
-    for (int ch = 0; ch < CILQR_CHUNKS; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int k = lane + CILQR_WAVE * ch;
         if (k <= N) {
             double sd, ce, jb;
@@ -624,7 +627,8 @@ __device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4],
     for (int i = 0; i < N; ++i) {
         double ui[2] = {l.u[2 * i], l.u[2 * i + 1]};
         double xn[4];
-        propagate(c, xc, ui, xn);
+        if (c.rp == 0) propagate<0>(c, xc, ui, xn);
+        else propagate<1>(c, xc, ui, xn);
         s = ref_scan_from(c, l, xn[0], xn[1], s);
         if (lane == 0) {
             l.x[4 * (i + 1)] = xn[0]; l.x[4 * (i + 1) + 1] = xn[1];
@@ -654,7 +658,8 @@ __device__ inline void ref_indices_lds(const Cst& c, Lds& l, int lane, int& idx0
 // forward_pass (cs:442-461) for all trial step sizes at once: lane a < n_alpha uses alpha = 2^-a.
 // The trial trajectories go to the scratch slab; their reference points are found later, only for
 // the trials whose cost is actually needed.
-__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
+template <int RP>
+__device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
     const int N = c.N;
     const int R = N + 1;
     if (lane < n_alpha) {
@@ -662,27 +667,38 @@ __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, i
         double* t = scr + (size_t)lane * CILQR_TRIAL_ROWS * R;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         t[0] = xc[0]; t[R] = xc[1]; t[2 * R] = xc[2]; t[3 * R] = xc[3];
+        const double* Ki = l.K;
+        const double* xi = l.x;
+        const double* ui = l.u;
+        const double* di = l.d;
+        double* tx = t + 1;          // x' rows 0..3 at strides R
+        double* tu = t + 4 * R;      // u' rows 0..1
         for (int i = 0; i < N; ++i) {
-            const double* Ki = l.K + 8 * i;
-            const double* xi = l.x + 4 * i;
             double dx0 = xc[0] - xi[0], dx1 = xc[1] - xi[1], dx2 = xc[2] - xi[2], dx3 = xc[3] - xi[3];
             double k0 = ((Ki[0] * dx0 + Ki[1] * dx1) + Ki[2] * dx2) + Ki[3] * dx3;
             double k1 = ((Ki[4] * dx0 + Ki[5] * dx1) + Ki[6] * dx2) + Ki[7] * dx3;
             double un[2];
-            un[0] = (l.u[2 * i] + k0) + alpha * l.d[2 * i];
-            un[1] = (l.u[2 * i + 1] + k1) + alpha * l.d[2 * i + 1];
+            un[0] = (ui[0] + k0) + alpha * di[0];
+            un[1] = (ui[1] + k1) + alpha * di[1];
             double xn[4];
-            propagate(c, xc, un, xn);
-            t[4 * R + i] = un[0];
-            t[5 * R + i] = un[1];
-            t[i + 1] = xn[0];
-            t[R + i + 1] = xn[1];
-            t[2 * R + i + 1] = xn[2];
-            t[3 * R + i + 1] = xn[3];
+            propagate<RP>(c, xc, un, xn);
+            tu[0] = un[0];
+            tu[R] = un[1];
+            tx[0] = xn[0];
+            tx[R] = xn[1];
+            tx[2 * R] = xn[2];
+            tx[3 * R] = xn[3];
             xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+            Ki += 8; xi += 4; ui += 2; di += 2; tx += 1; tu += 1;
         }
     }
     __syncthreads();
+}
+
+__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
+    // one loop per vehicle model: only that model's polynomial constants are live inside it
+    if (c.rp == 0) rollout_trials_rp<0>(c, l, scr, lane, n_alpha);
+    else rollout_trials_rp<1>(c, l, scr, lane, n_alpha);
 }
 
 // copy trial `a` (whose cost was evaluated last, so l.tidx is its index row) into the current trajectory
@@ -1148,8 +1164,9 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     return true;
 }
 
+template <bool DBG>
 __device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags) {
-    if (flags & CILQR_DBG_UNIFORM_BACKWARD) return backward_sweep_uniform(c, l, lamb, lane, dV);
+    if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV);
     return backward_sweep_lanes(c, l, lamb, lane, dV);
 }
 
