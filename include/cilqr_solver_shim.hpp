@@ -1,0 +1,151 @@
+// cilqr_solver_shim.hpp — source-level drop-in for the reference's CILQRSolver on top of the C-ABI.
+//
+// Mirrors /root/reference/include/cilqr_solver.hpp:31-41:
+//     explicit CILQRSolver(const GlobalConfig* config);
+//     std::tuple<Eigen::MatrixX2d, Eigen::MatrixX4d> solve(const Eigen::Vector4d& x0,
+//         const ReferenceLine& ref_waypoints, double ref_velo,
+//         const std::vector<RoutingLine>& obs_preds, const Eigen::Vector2d& road_boaders);
+// The Eigen-typed overload is compiled only when <Eigen/Core> is available (it is not in the build
+// container); the plain-array overload below it is what the overload forwards to.  The config type
+// is a template parameter: anything with `template<class T> T get_config(const std::string&) const`
+// (the reference's GlobalConfig, include/global_config.hpp:30-36) works unchanged.
+//
+// State carried across calls exactly as upstream: is_first_solve / last_solve_u for
+// use_last_solution (src/cilqr_solver.cpp:97-102,144).  One instance = one handle = one GPU stream;
+// like the reference class it is not re-entrant.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "cilqr_amd.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define CILQR_SHIM_HAS_EIGEN 1
+#endif
+#endif
+
+namespace cilqr_amd {
+
+template <class Config>
+inline cilqr_params params_from_config(const Config& cfg) {
+    cilqr_params p{};
+    p.N = cfg.template get_config<int>("lqr/N");
+    p.max_iter = cfg.template get_config<int>("iteration/max_iter");
+    p.solve_type = cfg.template get_config<std::string>("lqr/slove_type") == "alm" ? 1 : 0;
+    p.reference_point = cfg.template get_config<std::string>("vehicle/reference_point") == "rear_center" ? 0 : 1;
+    p.use_last_solution = cfg.template get_config<bool>("lqr/use_last_solution") ? 1 : 0;
+    p.dt = cfg.template get_config<double>("delta_t");
+    p.w_pos = cfg.template get_config<double>("lqr/w_pos");
+    p.w_vel = cfg.template get_config<double>("lqr/w_vel");
+    p.w_yaw = cfg.template get_config<double>("lqr/w_yaw");
+    p.w_acc = cfg.template get_config<double>("lqr/w_acc");
+    p.w_stl = cfg.template get_config<double>("lqr/w_stl");
+    p.obstacle_exp_q1 = cfg.template get_config<double>("lqr/obstacle_exp_q1");
+    p.obstacle_exp_q2 = cfg.template get_config<double>("lqr/obstacle_exp_q2");
+    p.state_exp_q1 = cfg.template get_config<double>("lqr/state_exp_q1");
+    p.state_exp_q2 = cfg.template get_config<double>("lqr/state_exp_q2");
+    p.alm_rho_init = cfg.template get_config<double>("lqr/alm_rho_init");
+    p.alm_gamma = cfg.template get_config<double>("lqr/alm_gamma");
+    p.max_rho = cfg.template get_config<double>("lqr/max_rho");
+    p.max_mu = cfg.template get_config<double>("lqr/max_mu");
+    p.init_lamb = cfg.template get_config<double>("iteration/init_lamb");
+    p.lamb_decay = cfg.template get_config<double>("iteration/lamb_decay");
+    p.lamb_amplify = cfg.template get_config<double>("iteration/lamb_amplify");
+    p.max_lamb = cfg.template get_config<double>("iteration/max_lamb");
+    p.convergence_threshold = cfg.template get_config<double>("iteration/convergence_threshold");
+    p.accept_step_threshold = cfg.template get_config<double>("iteration/accept_step_threshold");
+    p.wheelbase = cfg.template get_config<double>("vehicle/wheelbase");
+    p.width = cfg.template get_config<double>("vehicle/width");
+    p.length = cfg.template get_config<double>("vehicle/length");
+    p.velo_max = cfg.template get_config<double>("vehicle/velo_max");
+    p.velo_min = cfg.template get_config<double>("vehicle/velo_min");
+    p.yaw_lim = cfg.template get_config<double>("vehicle/yaw_lim");
+    p.acc_max = cfg.template get_config<double>("vehicle/acc_max");
+    p.acc_min = cfg.template get_config<double>("vehicle/acc_min");
+    p.stl_lim = cfg.template get_config<double>("vehicle/stl_lim");
+    p.d_safe = cfg.template get_config<double>("vehicle/d_safe");
+    return p;
+}
+
+class CILQRSolver {
+  public:
+    CILQRSolver() = delete;
+    template <class Config>
+    explicit CILQRSolver(const Config* config, int device = 0) : CILQRSolver(params_from_config(*config), device) {}
+    explicit CILQRSolver(const cilqr_params& p, int device = 0) : params_(p) {
+        check(cilqr_create(device, &h_), "cilqr_create");
+        check(cilqr_set_params(h_, &params_, 1), "cilqr_set_params");
+    }
+    ~CILQRSolver() { cilqr_destroy(h_); }
+    CILQRSolver(const CILQRSolver&) = delete;
+    CILQRSolver& operator=(const CILQRSolver&) = delete;
+
+    // Plain-array form.  lane_x/y/yaw[L] = ref_waypoints.x/.y/.yaw; obs[M][T][3] = obs_preds[j][k]
+    // from the current tick on (T >= N + 1); u_out[N][2], x_out[N+1][4].
+    void solve(const double x0[4], const double* lane_x, const double* lane_y, const double* lane_yaw, int L,
+               double ref_velo, const double* obs, int M, int T, const double road_boaders[2], double* u_out,
+               double* x_out, cilqr_result* res = nullptr) {
+        cilqr_scenario_desc sc{};
+        sc.lane_x = lane_x; sc.lane_y = lane_y; sc.lane_yaw = lane_yaw; sc.L = L;
+        sc.M = M; sc.obs = obs; sc.T = T;
+        sc.road_borders[0] = road_boaders[0]; sc.road_borders[1] = road_boaders[1];
+        sc.ref_velo = ref_velo;
+        check(cilqr_set_scenarios(h_, &sc, 1), "cilqr_set_scenarios");
+        const bool warm = !is_first_solve_ && params_.use_last_solution;
+        check(cilqr_solve_batch(h_, 1, x0, nullptr, nullptr, nullptr, warm ? last_solve_u_.data() : nullptr, u_out,
+                                x_out, res, nullptr, 0), "cilqr_solve_batch");
+        is_first_solve_ = false;
+        last_solve_u_.assign(u_out, u_out + 2 * params_.N);
+    }
+
+#ifdef CILQR_SHIM_HAS_EIGEN
+    // Eigen form with the reference's signature; ReferenceLine / RoutingLine are duck-typed
+    // (members x, y, yaw as std::vector<double>), so the reference's own classes fit.
+    template <class ReferenceLineT, class RoutingLineT>
+    std::tuple<Eigen::MatrixX2d, Eigen::MatrixX4d> solve(const Eigen::Vector4d& x0, const ReferenceLineT& ref_waypoints,
+                                                         double ref_velo, const std::vector<RoutingLineT>& obs_preds,
+                                                         const Eigen::Vector2d& road_boaders) {
+        const int N = params_.N, M = static_cast<int>(obs_preds.size());
+        int T = 0;
+        for (const auto& r : obs_preds) {
+            const int n = static_cast<int>(std::min(r.x.size(), std::min(r.y.size(), r.yaw.size())));
+            T = (T == 0 || n < T) ? n : T;
+        }
+        std::vector<double> obs(static_cast<size_t>(M) * T * 3);
+        for (int j = 0; j < M; ++j)
+            for (int k = 0; k < T; ++k) {
+                obs[(static_cast<size_t>(j) * T + k) * 3 + 0] = obs_preds[j].x[k];
+                obs[(static_cast<size_t>(j) * T + k) * 3 + 1] = obs_preds[j].y[k];
+                obs[(static_cast<size_t>(j) * T + k) * 3 + 2] = obs_preds[j].yaw[k];
+            }
+        std::vector<double> u(2 * N), x(4 * (N + 1));
+        const double xs[4] = {x0[0], x0[1], x0[2], x0[3]};
+        const double rb[2] = {road_boaders[0], road_boaders[1]};
+        solve(xs, ref_waypoints.x.data(), ref_waypoints.y.data(), ref_waypoints.yaw.data(),
+              static_cast<int>(ref_waypoints.x.size()), ref_velo, obs.data(), M, T, rb, u.data(), x.data());
+        Eigen::MatrixX2d U(N, 2);
+        Eigen::MatrixX4d X(N + 1, 4);
+        for (int k = 0; k < N; ++k) { U(k, 0) = u[2 * k]; U(k, 1) = u[2 * k + 1]; }
+        for (int k = 0; k <= N; ++k)
+            for (int c = 0; c < 4; ++c) X(k, c) = x[4 * k + c];
+        return std::make_tuple(U, X);
+    }
+#endif
+
+    const cilqr_params& params() const { return params_; }
+
+  private:
+    static void check(int rc, const char* where) {
+        if (rc != CILQR_OK) throw std::runtime_error(std::string(where) + ": " + cilqr_last_error());
+    }
+    cilqr_params params_;
+    cilqr_handle* h_ = nullptr;
+    bool is_first_solve_ = true;
+    std::vector<double> last_solve_u_;
+};
+
+}  // namespace cilqr_amd

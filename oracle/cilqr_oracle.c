@@ -62,6 +62,9 @@ struct orc_solver {
     double* alm_mu_next; /* [N][alm_cols] */
     int alm_cols;
     int cost_evals;
+    /* work space, allocated once (keeps the batch driver free of malloc traffic) */
+    double *ws_ref, *ws_lub, *ws_luub, *ws_lxb, *ws_lxxb, *ws_dfdx, *ws_dfdu;
+    double *ws_u, *ws_x, *ws_nu, *ws_nx, *ws_d, *ws_K;
 };
 
 static void ensure_alm(struct orc_solver* s, int cols);
@@ -322,7 +325,7 @@ double orc_total_cost(orc_solver* s, const double* u, const double* x, const orc
     const int M = sc->M;
     s->cost_evals++;
     if (p->solve_type == 1) ensure_alm(s, 8 + 2 * M);
-    double* ref = (double*)malloc(sizeof(double) * 3 * (N + 1));
+    double* ref = s->ws_ref;
     orc_ref_exact_points(x, N + 1, sc, ref, NULL);
 
     double W[16] = {0}, R[4] = {0};
@@ -402,7 +405,6 @@ double orc_total_cost(orc_solver* s, const double* u, const double* x, const orc
         }
         J_barrier += J_barrier_k;
     }
-    free(ref);
     return J_prime + J_barrier;
 }
 
@@ -424,17 +426,21 @@ static void cost_derivatives_and_Hessians(orc_solver* s, const double* u, const 
     }
     s->status = ORC_RUNNING;
 
-    double* ref = (double*)malloc(sizeof(double) * 3 * (N + 1));
+    double* ref = s->ws_ref;
     orc_ref_exact_points(x, N + 1, sc, ref, NULL);
 
     double W[16] = {0}, R[4] = {0};
     W[0] = p->w_pos; W[5] = p->w_pos; W[10] = p->w_vel; W[15] = p->w_yaw;
     R[0] = p->w_acc; R[3] = p->w_stl;
 
-    double* l_u_barrier = (double*)calloc((size_t)N * 2, sizeof(double));
-    double* l_uu_barrier = (double*)calloc((size_t)N * 4, sizeof(double));
-    double* l_x_barrier = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
-    double* l_xx_barrier = (double*)calloc((size_t)(N + 1) * 16, sizeof(double));
+    double* l_u_barrier = s->ws_lub;
+    double* l_uu_barrier = s->ws_luub;
+    double* l_x_barrier = s->ws_lxb;
+    double* l_xx_barrier = s->ws_lxxb;
+    memset(l_u_barrier, 0, sizeof(double) * (size_t)N * 2);
+    memset(l_uu_barrier, 0, sizeof(double) * (size_t)N * 4);
+    memset(l_x_barrier, 0, sizeof(double) * (size_t)(N + 1) * 4);
+    memset(l_xx_barrier, 0, sizeof(double) * (size_t)(N + 1) * 16);
 
     for (int k = 1; k < N + 1; ++k) {
         const double* u_k = u + (k - 1) * 2;
@@ -556,11 +562,6 @@ static void cost_derivatives_and_Hessians(orc_solver* s, const double* u, const 
         for (int i = 0; i < 4; ++i) s->l_x[k * 4 + i] = t[i] + l_x_barrier[k * 4 + i];
         for (int i = 0; i < 16; ++i) s->l_xx[k * 16 + i] = 2 * W[i] + l_xx_barrier[k * 16 + i];
     }
-    free(ref);
-    free(l_u_barrier);
-    free(l_uu_barrier);
-    free(l_x_barrier);
-    free(l_xx_barrier);
 }
 
 void orc_cost_derivatives(orc_solver* s, const double* u, const double* x, const orc_scene* sc,
@@ -580,8 +581,8 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
     const orc_params* p = &s->p;
     const int N = p->N;
     cost_derivatives_and_Hessians(s, u, x, sc);
-    double* df_dx = (double*)malloc(sizeof(double) * 16 * N);
-    double* df_du = (double*)malloc(sizeof(double) * 8 * N);
+    double* df_dx = s->ws_dfdx;
+    double* df_du = s->ws_dfdu;
     orc_model_derivatives(x, u, p->dt, p->wheelbase, N, p->reference_point, df_dx, df_du);
 
     delta_V[0] = 0.0;
@@ -633,8 +634,6 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
             }
             if (fail) {
                 s->status = ORC_BACKWARD_PASS_FAIL;
-                free(df_dx);
-                free(df_du);
                 return s->status;
             }
         }
@@ -672,8 +671,6 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
         delta_V[0] += q0;
         delta_V[1] += q1;
     }
-    free(df_dx);
-    free(df_du);
     return s->status;
 }
 
@@ -772,6 +769,19 @@ orc_solver* orc_create(const orc_params* p) {
     s->l_u = (double*)calloc((size_t)N * 2, sizeof(double));
     s->l_xx = (double*)calloc((size_t)(N + 1) * 16, sizeof(double));
     s->l_uu = (double*)calloc((size_t)N * 4, sizeof(double));
+    s->ws_ref = (double*)calloc((size_t)(N + 1) * 3, sizeof(double));
+    s->ws_lub = (double*)calloc((size_t)N * 2, sizeof(double));
+    s->ws_luub = (double*)calloc((size_t)N * 4, sizeof(double));
+    s->ws_lxb = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
+    s->ws_lxxb = (double*)calloc((size_t)(N + 1) * 16, sizeof(double));
+    s->ws_dfdx = (double*)calloc((size_t)N * 16, sizeof(double));
+    s->ws_dfdu = (double*)calloc((size_t)N * 8, sizeof(double));
+    s->ws_u = (double*)calloc((size_t)N * 2, sizeof(double));
+    s->ws_x = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
+    s->ws_nu = (double*)calloc((size_t)N * 2, sizeof(double));
+    s->ws_nx = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
+    s->ws_d = (double*)calloc((size_t)N * 2, sizeof(double));
+    s->ws_K = (double*)calloc((size_t)N * 8, sizeof(double));
     s->alm_mu = NULL;
     s->alm_mu_next = NULL;
     s->alm_cols = 0;
@@ -788,6 +798,9 @@ void orc_destroy(orc_solver* s) {
     free(s->l_uu);
     free(s->alm_mu);
     free(s->alm_mu_next);
+    free(s->ws_ref); free(s->ws_lub); free(s->ws_luub); free(s->ws_lxb); free(s->ws_lxxb);
+    free(s->ws_dfdx); free(s->ws_dfdu);
+    free(s->ws_u); free(s->ws_x); free(s->ws_nu); free(s->ws_nx); free(s->ws_d); free(s->ws_K);
     free(s);
 }
 
@@ -825,12 +838,9 @@ int orc_solve(orc_solver* s, const double x0[4], const orc_scene* sc, double* u_
     s->status = ORC_RUNNING;
     s->cost_evals = 0;
 
-    double* u = (double*)calloc((size_t)N * 2, sizeof(double));
-    double* x = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
-    double* new_u = (double*)calloc((size_t)N * 2, sizeof(double));
-    double* new_x = (double*)calloc((size_t)(N + 1) * 4, sizeof(double));
-    double* d = (double*)calloc((size_t)N * 2, sizeof(double));
-    double* K = (double*)calloc((size_t)N * 8, sizeof(double));
+    double *u = s->ws_u, *x = s->ws_x, *new_u = s->ws_nu, *new_x = s->ws_nx, *d = s->ws_d, *K = s->ws_K;
+    memset(u, 0, sizeof(double) * (size_t)N * 2);
+    memset(x, 0, sizeof(double) * (size_t)(N + 1) * 4);
 
     if (!s->is_first_solve && p->use_last_solution) {
         /* cs:163-180 get_init_traj_increment */
@@ -904,7 +914,6 @@ int orc_solve(orc_solver* s, const double x0[4], const orc_scene* sc, double* u_
         res->trace_len = (tl < trace_cap || !trace) ? tl : trace_cap;
         res->J_final = orc_total_cost(s, u, x, sc);
     }
-    free(u); free(x); free(new_u); free(new_x); free(d); free(K);
     return 0;
 }
 
@@ -914,26 +923,34 @@ int orc_solve_batch(const orc_params* params, int32_t n_params, const orc_scene*
                     double* x_out, orc_result* res) {
     int rc_all = 0;
     if (n_threads < 1) n_threads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
-    for (int b = 0; b < B; ++b) {
-        int pid = param_id ? param_id[b] : 0;
-        int sid = scene_id ? scene_id[b] : 0;
-        if (pid < 0 || pid >= n_params || sid < 0 || sid >= n_scenes) {
+#pragma omp parallel num_threads(n_threads)
+    {
+        /* one solver instance per thread and parameter set, reset before every (cold-start) solve */
+        orc_solver** pool = (orc_solver**)calloc((size_t)n_params, sizeof(orc_solver*));
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < B; ++b) {
+            int pid = param_id ? param_id[b] : 0;
+            int sid = scene_id ? scene_id[b] : 0;
+            if (pid < 0 || pid >= n_params || sid < 0 || sid >= n_scenes) {
 #pragma omp atomic write
-            rc_all = -3;
-            continue;
-        }
-        const orc_params* p = params + pid;
-        orc_scene sc = scenes[sid];
-        if (tick) sc.tick = tick[b];
-        orc_solver* s = orc_create(p);
-        int rc = orc_solve(s, x0 + (size_t)b * 4, &sc, u_out + (size_t)b * p->N * 2,
-                           x_out + (size_t)b * (p->N + 1) * 4, res ? res + b : NULL, NULL, 0);
-        if (rc != 0) {
+                rc_all = -3;
+                continue;
+            }
+            const orc_params* p = params + pid;
+            orc_scene sc = scenes[sid];
+            if (tick) sc.tick = tick[b];
+            if (!pool[pid]) pool[pid] = orc_create(p);
+            orc_solver* s = pool[pid];
+            orc_reset(s);
+            int rc = orc_solve(s, x0 + (size_t)b * 4, &sc, u_out + (size_t)b * p->N * 2,
+                               x_out + (size_t)b * (p->N + 1) * 4, res ? res + b : NULL, NULL, 0);
+            if (rc != 0) {
 #pragma omp atomic write
-            rc_all = rc;
+                rc_all = rc;
+            }
         }
-        orc_destroy(s);
+        for (int i = 0; i < n_params; ++i) orc_destroy(pool[i]);
+        free(pool);
     }
     return rc_all;
 }

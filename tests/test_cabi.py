@@ -89,3 +89,12 @@ def test_config_mirror(pkg):
     assert p.N == 50 and p.use_last_solution == 1 and p.reference_point == 1 and p.solve_type == 0
     p2 = pkg.params_from_config(pkg.GlobalConfig.get_instance("two_straight"))
     assert p2.reference_point == 0 and p2.stl_lim == 0.12 and p2.w_stl == 20.0
+
+
+def test_cpp_host_driver_builds_against_the_cabi(pkg):
+    """examples/headless_planner.cpp (the reference's planning loop without drawing) compiles with plain
+    g++ against include/*.h and links libcilqr_amd.so"""
+    import importlib
+    build = importlib.import_module("toy-example-of-ilqr_amd.build")
+    exe = build.build_examples()
+    assert exe.exists()

@@ -335,3 +335,31 @@ def test_uniform_and_lane_parallel_backward_agree(pkg, orc_det, engines):
             eq_bits(a[1], b[1], "K")
             ok = a[3] == 0
             eq_bits(a[2][ok], b[2][ok], "dV")
+
+
+def test_cpp_headless_planner_closed_loop(pkg, orc_det, scenarios):
+    """host C++ -> C-ABI -> HIP: the closed loop of motion_planning.cpp:180-197 for a few ticks,
+    against the oracle driven the same way (three_straight exercises use_last_solution)."""
+    import importlib
+    import subprocess
+    build = importlib.import_module("toy-example-of-ilqr_amd.build")
+    exe = build.build_examples()
+    for name in ("two_straight", "three_straight"):
+        cfg, sc = scenarios[name]
+        path = pkg.config.SCENARIO_DIR / f"{name}.json"
+        out = subprocess.run([str(exe), str(path), "4"], check=True, capture_output=True, text=True).stdout
+        rows = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()])
+        assert rows.shape == (4, 9)
+        p = pkg.params_from_config(cfg)
+        s = orc_det.solver(p)
+        ego = sc.ego_state.copy()
+        t = 0.0
+        for i in range(4):
+            index = int(t / sc.delta_t)
+            r = s.solve(ego, oracle_scene(sc, index))
+            ego = r["x"][1].copy()
+            assert rows[i, 0] == index and rows[i, 7] == r["res"]["iters"]
+            eq_bits(rows[i, 1:5], ego, f"{name} tick {i} ego")
+            eq_bits(rows[i, 5:7], r["u"][0], f"{name} tick {i} u0")
+            eq_bits(rows[i, 8], r["res"]["J_final"], f"{name} tick {i} J")
+            t += sc.delta_t

@@ -40,5 +40,23 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_examples(force=False, verbose=False):
+    """host C++ driver on top of the C-ABI (plain g++, links libcilqr_amd.so)"""
+    src = ROOT / "examples" / "headless_planner.cpp"
+    exe = ROOT / "examples" / "headless_planner"
+    deps = [src, ROOT / "include" / "cilqr_amd.h", ROOT / "include" / "cilqr_solver_shim.hpp",
+            ROOT / "include" / "cilqr_config.hpp", LIB]
+    if not force and _newer(exe, deps):
+        return exe
+    cmd = ["g++", "-std=c++17", "-O2", "-I", str(ROOT / "include"), str(src), "-L", str(PKG), "-lcilqr_amd",
+           "-Wl,-rpath," + str(PKG), "-Wl,-rpath,$ORIGIN/../toy-example-of-ilqr_amd", "-o", str(exe)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return exe
+
+
 def build_all(force=False, verbose=False):
-    return build_library(force, verbose)
+    lib = build_library(force, verbose)
+    build_examples(force, verbose)
+    return lib
