@@ -158,6 +158,15 @@ def main():
         my_iters = float(res["iters"].sum())
         alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot be nested
+        # inside the benchmark); recorded under profiles/ together with how it was collected
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_config2.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == wl.name and world == 1:
+                traffic = pmc["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/r01_pmc_config2.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         out = {
             "metric": "iLQR iterations/sec (batch x horizon)", "value": value, "unit": "iLQR iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,7 +176,7 @@ def main():
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
                        "parallelism": f"trajectory-sharded x{world}, one wavefront per trajectory"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_solve", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"},

@@ -255,13 +255,13 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
     rollout_trials(c, l, scr, lane, n_alpha);
     for (int t = 0; t < n_alpha; ++t) {
-        const double* tr = scr + (size_t)t * CILQR_TRIAL_ROWS * R;
+        const double* tr = scr + t;
         for (int k = lane; k <= N; k += CILQR_WAVE) {
             double* xo = new_x + (((size_t)b * n_alpha + t) * R + k) * 4;
-            xo[0] = tr[k]; xo[1] = tr[R + k]; xo[2] = tr[2 * R + k]; xo[3] = tr[3 * R + k];
+            xo[0] = TR(tr, 0, k); xo[1] = TR(tr, 1, k); xo[2] = TR(tr, 2, k); xo[3] = TR(tr, 3, k);
             if (k < N) {
                 double* uo = new_u + (((size_t)b * n_alpha + t) * N + k) * 2;
-                uo[0] = tr[4 * R + k]; uo[1] = tr[5 * R + k];
+                uo[0] = TR(tr, 4, k); uo[1] = TR(tr, 5, k);
             }
         }
         int nfb = 0;

@@ -164,9 +164,11 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
     __syncthreads();
 }
 
-// scratch slab of the trial trajectories: [alpha][6][(N+1)] doubles
-// rows 0-3 = x' components, 4-5 = u' components
+// scratch slab of the trial trajectories: [6][(N+1)][20 alphas] doubles, alpha fastest, so that the
+// 20 rollout lanes of one store instruction write 160 contiguous bytes.
+// rows 0-3 = x' components, 4-5 = u' components.  TR(t, c, k) with t = slab + alpha.
 #define CILQR_TRIAL_ROWS 6
+#define TR(t, c, k) (t)[((size_t)(c) * R + (size_t)(k)) * CILQR_MAX_ALPHA_TRIALS]
 __host__ __device__ inline size_t scratch_doubles(int N) {
     return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
 }
@@ -499,7 +501,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
     const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
+    const double* t = scr + a;
     long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
     // this lane's rows of the trial, fetched once
     double xk[NCH][4], uk[NCH][2], um[NCH][2];
@@ -511,9 +513,9 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         uk[ch][0] = uk[ch][1] = um[ch][0] = um[ch][1] = 0.0;
         guess[ch] = idx0;
         if (k <= N) {
-            xk[ch][0] = t[k]; xk[ch][1] = t[R + k]; xk[ch][2] = t[2 * R + k]; xk[ch][3] = t[3 * R + k];
-            if (k < N) { uk[ch][0] = t[4 * R + k]; uk[ch][1] = t[5 * R + k]; }
-            if (k >= 1) { um[ch][0] = t[4 * R + k - 1]; um[ch][1] = t[5 * R + k - 1]; }
+            xk[ch][0] = TR(t, 0, k); xk[ch][1] = TR(t, 1, k); xk[ch][2] = TR(t, 2, k); xk[ch][3] = TR(t, 3, k);
+            if (k < N) { uk[ch][0] = TR(t, 4, k); uk[ch][1] = TR(t, 5, k); }
+            if (k >= 1) { um[ch][0] = TR(t, 4, k - 1); um[ch][1] = TR(t, 5, k - 1); }
             guess[ch] = l.ridx[k];
         }
     }
@@ -574,7 +576,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         int s = idx0;
         if (lane == 0) l.tidx[0] = s;
         for (int i = 1; i <= N; ++i) {
-            s = ref_scan_from(c, l, t[i], t[R + i], s);
+            s = ref_scan_from(c, l, TR(t, 0, i), TR(t, 1, i), s);
             if (lane == 0) l.tidx[i] = s;
         }
         __syncthreads();
@@ -664,15 +666,16 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
     const int R = N + 1;
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
-        double* t = scr + (size_t)lane * CILQR_TRIAL_ROWS * R;
+        double* t = scr + lane;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
-        t[0] = xc[0]; t[R] = xc[1]; t[2 * R] = xc[2]; t[3 * R] = xc[3];
+        TR(t, 0, 0) = xc[0]; TR(t, 1, 0) = xc[1]; TR(t, 2, 0) = xc[2]; TR(t, 3, 0) = xc[3];
         const double* Ki = l.K;
         const double* xi = l.x;
         const double* ui = l.u;
         const double* di = l.d;
-        double* tx = t + 1;          // x' rows 0..3 at strides R
-        double* tu = t + 4 * R;      // u' rows 0..1
+        const size_t CS = (size_t)R * CILQR_MAX_ALPHA_TRIALS; // component stride
+        double* tx = &TR(t, 0, 1);   // x' components at strides CS
+        double* tu = &TR(t, 4, 0);   // u' components
         for (int i = 0; i < N; ++i) {
             double dx0 = xc[0] - xi[0], dx1 = xc[1] - xi[1], dx2 = xc[2] - xi[2], dx3 = xc[3] - xi[3];
             double k0 = ((Ki[0] * dx0 + Ki[1] * dx1) + Ki[2] * dx2) + Ki[3] * dx3;
@@ -683,13 +686,13 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             double xn[4];
             propagate<RP>(c, xc, un, xn);
             tu[0] = un[0];
-            tu[R] = un[1];
+            tu[CS] = un[1];
             tx[0] = xn[0];
-            tx[R] = xn[1];
-            tx[2 * R] = xn[2];
-            tx[3 * R] = xn[3];
+            tx[CS] = xn[1];
+            tx[2 * CS] = xn[2];
+            tx[3 * CS] = xn[3];
             xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-            Ki += 8; xi += 4; ui += 2; di += 2; tx += 1; tu += 1;
+            Ki += 8; xi += 4; ui += 2; di += 2; tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
         }
     }
     __syncthreads();
@@ -705,16 +708,16 @@ __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, i
 __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane) {
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + (size_t)a * CILQR_TRIAL_ROWS * R;
+    const double* t = scr + a;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
-        l.x[4 * k] = t[k];
-        l.x[4 * k + 1] = t[R + k];
-        l.x[4 * k + 2] = t[2 * R + k];
-        l.x[4 * k + 3] = t[3 * R + k];
+        l.x[4 * k] = TR(t, 0, k);
+        l.x[4 * k + 1] = TR(t, 1, k);
+        l.x[4 * k + 2] = TR(t, 2, k);
+        l.x[4 * k + 3] = TR(t, 3, k);
         l.ridx[k] = l.tidx[k];
         if (k < N) {
-            l.u[2 * k] = t[4 * R + k];
-            l.u[2 * k + 1] = t[5 * R + k];
+            l.u[2 * k] = TR(t, 4, k);
+            l.u[2 * k + 1] = TR(t, 5, k);
         }
     }
     __syncthreads();
