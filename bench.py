@@ -103,7 +103,7 @@ def main():
         sys.exit("bench.py needs a GPU: the CILQR solve path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CILQR_FORCE_DIST") == "1":  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,

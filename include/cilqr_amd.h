@@ -143,6 +143,13 @@ int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
 /* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */
 int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
 
+/* solve_type "alm" (cs:88-93, 253-277, 377-378, 581-643, 665-680): the multipliers alm_mu / alm_mu_next
+ * ([B][N][cols], cols = 8 + 2 * max M over the scenarios) and alm_rho ([B]) live in the handle, as they
+ * live in the reference instance; a solve with last_u == NULL resets them, a warm-started solve keeps
+ * them.  These two calls expose them (tests; resuming a batch on another handle).  Any pointer may be NULL. */
+int cilqr_set_alm_state(cilqr_handle* h, int32_t B, const double* mu, const double* rho);
+int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next, double* rho, int32_t* cols);
+
 /* Optional in-kernel cycle accounting of the fused solve (development aid): when enabled, the next
  * solve records, per trajectory, shader-clock cycles spent in
  * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,

@@ -954,3 +954,14 @@ int orc_solve_batch(const orc_params* params, int32_t n_params, const orc_scene*
     }
     return rc_all;
 }
+
+/* test hooks: inject / read the augmented-Lagrangian state of an instance */
+void orc_set_alm_state(orc_solver* s, const double* mu, double rho, int32_t cols) {
+    ensure_alm(s, cols);
+    memcpy(s->alm_mu, mu, sizeof(double) * (size_t)s->p.N * cols);
+    s->alm_rho = rho;
+}
+
+void orc_get_alm_next(orc_solver* s, double* mu_next) {
+    memcpy(mu_next, s->alm_mu_next, sizeof(double) * (size_t)s->p.N * s->alm_cols);
+}

@@ -155,6 +155,10 @@ int orc_backward_pass(orc_solver* s, const double* u, const double* x, double la
 void orc_forward_pass(const orc_params* p, const double* u, const double* x, const double* d,
                       const double* K, double alpha, double* new_u, double* new_x);
 
+/* test hooks for the ALM state */
+void orc_set_alm_state(orc_solver* s, const double* mu, double rho, int32_t cols);
+void orc_get_alm_next(orc_solver* s, double* mu_next);
+
 /* detmath / libm elementary functions as used by this build (for tests) */
 double orc_m_exp(double x);
 double orc_m_sin(double x);

@@ -37,7 +37,22 @@ struct BatchArgs {
     int N;
     int W;                      // capacity (samples) of the per-trajectory LDS lane window
     int flags;                  // CILQR_DBG_* (testing aids)
+    // augmented-Lagrangian state kept by the handle (solve_type alm): [B][N][alm_C], [B]
+    double* alm_mu;
+    double* alm_mu_next;
+    double* alm_rho;
+    int alm_C;
+    int alm;                    // 1 when the handle's parameter sets use the ALM solve type
 };
+
+__device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
+    AlmSt al;
+    al.C = a.alm_C;
+    al.mu = a.alm_mu ? a.alm_mu + (size_t)b * N * a.alm_C : nullptr;
+    al.mu_next = a.alm_mu_next ? a.alm_mu_next + (size_t)b * N * a.alm_C : nullptr;
+    al.rho = a.alm_rho ? a.alm_rho[b] : 1.0;
+    return al;
+}
 
 // phase ids of the optional in-kernel cycle accounting
 #define CILQR_PROF_SLOTS 13
@@ -62,7 +77,7 @@ __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
 // CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
 // DBG = true compiles the testing-aid paths in (cilqr_set_debug_flags); the production
 // instantiation carries neither their code nor their registers.
-template <bool DBG, int NCH>
+template <bool DBG, int NCH, bool ALM>
 __global__ void __launch_bounds__(CILQR_WAVE, CILQR_SOLVE_WAVES_PER_SIMD)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -74,8 +89,15 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     load_cst(c, a, b);
     const int N = c.N;
     Lds l;
-    carve(l, g_lds, N, a.W);
+    carve(l, g_lds, N, a.W, ALM ? 1 : 0);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    AlmSt al = load_alm(a, b, N);
+    if (ALM && last_u == nullptr) {
+        // cs:88-93: fresh multipliers unless this call continues a previous solution
+        al.rho = c.alm_rho_init;
+        for (int e = lane; e < N * al.C; e += CILQR_WAVE) { al.mu[e] = 0.0; al.mu_next[e] = 0.0; }
+        __syncthreads();
+    }
 
     long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -83,7 +105,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
     init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
-    double J_cur = total_cost_lds(c, l, lane);
+    double J_cur = total_cost_lds<ALM>(c, l, al, lane);
     const double J_init = J_cur;
     PROF_ADD(PH_INIT);
 
@@ -95,15 +117,16 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     int n_fallback = 0;
     for (int itr = 0; itr < c.max_iter; ++itr) {
         // ---- iter_step ----
-        cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
-        // cs:469-475: after a failed pass the expansion of the unchanged trajectory is kept
-        if (status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
-            cost_and_model_derivatives(c, l, lane);
+        cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
+        if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
+        // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
+        if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
+            cost_and_model_derivatives<ALM>(c, l, al, lane);
         }
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
-        bool ok = backward_sweep<DBG>(c, l, lamb, lane, dV, a.flags);
+        bool ok = backward_sweep<(DBG && !ALM)>(c, l, lamb, lane, dV, a.flags);
         __syncthreads();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
@@ -117,7 +140,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             bool done = false;
             for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
                 const double alpha = dm_pow2i(-t);
-                new_J = total_cost_trial<DBG, NCH>(c, l, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                new_J = total_cost_trial<DBG, NCH, ALM>(c, l, al, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
                 PROF_ADD(PH_TRIAL_COST);
                 trials++;
                 const double decay = J_cur - new_J;
@@ -139,7 +162,15 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     }
                 }
             }
-            if (!done) status = CILQR_FORWARD_PASS_FAIL;
+            if (!done) {
+                status = CILQR_FORWARD_PASS_FAIL;
+                if (ALM) { // cs:377-378
+                    for (int e = lane; e < N * al.C; e += CILQR_WAVE) al.mu[e] = al.mu_next[e];
+                    double r = (1 + c.alm_gamma) * al.rho;
+                    al.rho = (c.max_rho < r) ? c.max_rho : r;
+                    __syncthreads();
+                }
+            }
         }
         // ---- back in solve (cs:113-141) ----
         iters++;
@@ -160,6 +191,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         tl++;
         if (lamb > c.max_lamb) { end_reason = CILQR_END_MAX_LAMB; break; }
         if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; break; }
+    }
+    if (ALM) {
+        J_cur = total_cost_lds<ALM>(c, l, al, lane); // J_final := get_total_cost(u_ret, x_ret) with the final multipliers
+        if (lane == 0) a.alm_rho[b] = al.rho;
     }
     // results: u, x of the last accepted trajectory
     for (int k = lane; k <= N; k += CILQR_WAVE) {
@@ -198,7 +233,7 @@ k_init_traj(BatchArgs a, const double* __restrict__ x0, double* __restrict__ x_o
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
     init_trajectory(c, l, xs, nullptr, lane, idx0, a.W);
@@ -211,7 +246,7 @@ k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), nullptr, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
@@ -223,20 +258,23 @@ k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref
     }
 }
 
+template <bool ALM>
 __global__ void __launch_bounds__(CILQR_WAVE)
 k_total_cost(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
              double* __restrict__ J_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     Cst c; load_cst(c, a, b);
     const int N = c.N;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), u + (size_t)b * 2 * N, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
-    double J = total_cost_lds(c, l, lane);
+    AlmSt al = load_alm(a, b, N);
+    double J = total_cost_lds<ALM>(c, l, al, lane);
     if (lane == 0) J_out[b] = J;
 }
 
+template <bool ALM>
 __global__ void __launch_bounds__(CILQR_WAVE)
 k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
                const double* __restrict__ d, const double* __restrict__ K, int n_alpha,
@@ -245,7 +283,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = K[(size_t)b * 8 * N + e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = d[(size_t)b * 2 * N + e];
@@ -253,6 +291,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W); // indices of the current trajectory: the guesses for its trials
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    AlmSt al = load_alm(a, b, N);
     rollout_trials(c, l, scr, lane, n_alpha);
     for (int t = 0; t < n_alpha; ++t) {
         const double* tr = scr + t;
@@ -265,11 +304,12 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
             }
         }
         int nfb = 0;
-        double J = total_cost_trial<true, 2>(c, l, scr, t, lane, idx0, a.flags, &nfb);
+        double J = total_cost_trial<true, 2, ALM>(c, l, al, scr, t, lane, idx0, a.flags, &nfb);
         if (lane == 0 && J_out) J_out[(size_t)b * n_alpha + t] = J;
     }
 }
 
+template <bool ALM>
 __global__ void __launch_bounds__(CILQR_WAVE)
 k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
                    double* __restrict__ o_lx, double* __restrict__ o_lu, double* __restrict__ o_lxx,
@@ -278,18 +318,23 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
-    cost_and_model_derivatives(c, l, lane);
+    AlmSt al = load_alm(a, b, N);
+    cost_and_model_derivatives<ALM>(c, l, al, lane);
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         if (o_lx) for (int e = 0; e < 4; ++e) o_lx[((size_t)b * R + k) * 4 + e] = l.lx[4 * k + e];
         if (o_lxx) {
-            const double* hx = l.lxx + 7 * k;
-            const double dn[16] = {hx[0], hx[1], 0.0, hx[2], hx[1], hx[3], 0.0, hx[4],
-                                   0.0, 0.0, hx[6], 0.0, hx[2], hx[4], 0.0, hx[5]};
-            for (int e = 0; e < 16; ++e) o_lxx[((size_t)b * R + k) * 16 + e] = dn[e];
+            if (ALM) {
+                for (int e = 0; e < 16; ++e) o_lxx[((size_t)b * R + k) * 16 + e] = l.lxx[16 * k + e];
+            } else {
+                const double* hx = l.lxx + 7 * k;
+                const double dn[16] = {hx[0], hx[1], 0.0, hx[2], hx[1], hx[3], 0.0, hx[4],
+                                       0.0, 0.0, hx[6], 0.0, hx[2], hx[4], 0.0, hx[5]};
+                for (int e = 0; e < 16; ++e) o_lxx[((size_t)b * R + k) * 16 + e] = dn[e];
+            }
         }
         if (k < N) {
             if (o_lu) for (int e = 0; e < 2; ++e) o_lu[((size_t)b * N + k) * 2 + e] = l.lu[2 * k + e];
@@ -311,6 +356,7 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
     }
 }
 
+template <bool ALM>
 __global__ void __launch_bounds__(CILQR_WAVE)
 k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
                 const double* __restrict__ lamb, double* __restrict__ o_d, double* __restrict__ o_K,
@@ -319,15 +365,16 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
     Cst c; load_cst(c, a, b);
     const int N = c.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W);
+    Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = 0.0;
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = 0.0;
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
-    cost_and_model_derivatives(c, l, lane);
+    AlmSt al = load_alm(a, b, N);
+    cost_and_model_derivatives<ALM>(c, l, al, lane);
     double dV[2];
-    bool ok = backward_sweep<true>(c, l, lamb[b], lane, dV, a.flags);
+    bool ok = backward_sweep<!ALM>(c, l, lamb[b], lane, dV, a.flags);
     __syncthreads();
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) o_K[(size_t)b * 8 * N + e] = l.K[e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) o_d[(size_t)b * 2 * N + e] = l.d[e];
@@ -432,6 +479,8 @@ struct cilqr_handle {
     // scratch + staging
     int win = 0;      // LDS lane-window capacity in samples (derived from the tables)
     DevBuf scratch;
+    DevBuf alm_mu, alm_mu_next, alm_rho; // ALM solve type: per-trajectory multipliers carried across calls
+    int alm_B = 0, alm_C = 0;
     DevBuf prof;      // [B][8] int64, filled when profiling is on
     bool profiling = false;
     int debug_flags = 0;
@@ -498,6 +547,9 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     h->d_params.release();
     h->d_scenes.release();
     h->scratch.release();
+    h->alm_mu.release();
+    h->alm_mu_next.release();
+    h->alm_rho.release();
     h->prof.release();
     for (auto& s : h->st) s.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -516,6 +568,36 @@ extern "C" int cilqr_set_timing(cilqr_handle* h, int32_t enabled) {
 extern "C" int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     h->profiling = enabled != 0;
+    return CILQR_OK;
+}
+
+static int ensure_alm(cilqr_handle* h, int B);
+
+extern "C" int cilqr_set_alm_state(cilqr_handle* h, int32_t B, const double* mu, const double* rho) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->params[0].solve_type != 1 || B < 1) return fail(CILQR_ERR_BAD_ARG, "handle is not in alm mode");
+    HIP_TRY(hipSetDevice(h->device));
+    rc = ensure_alm(h, B);
+    if (rc) return rc;
+    const size_t nb = sizeof(double) * (size_t)B * h->params[0].N * h->alm_C;
+    if (mu) HIP_TRY(hipMemcpy(h->alm_mu.p, mu, nb, hipMemcpyHostToDevice));
+    if (rho) HIP_TRY(hipMemcpy(h->alm_rho.p, rho, sizeof(double) * B, hipMemcpyHostToDevice));
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next, double* rho,
+                                   int32_t* cols) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->params[0].solve_type != 1 || B < 1 || B > h->alm_B) return fail(CILQR_ERR_BAD_ARG, "no alm state for that batch");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t nb = sizeof(double) * (size_t)B * h->params[0].N * h->alm_C;
+    if (mu) HIP_TRY(hipMemcpy(mu, h->alm_mu.p, nb, hipMemcpyDeviceToHost));
+    if (mu_next) HIP_TRY(hipMemcpy(mu_next, h->alm_mu_next.p, nb, hipMemcpyDeviceToHost));
+    if (rho) HIP_TRY(hipMemcpy(rho, h->alm_rho.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+    if (cols) *cols = h->alm_C;
     return CILQR_OK;
 }
 
@@ -551,7 +633,8 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
         const cilqr_params& p = params[i];
         if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 127]");
         if (p.N != params[0].N) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share N");
-        if (p.solve_type != 0) return fail(CILQR_ERR_UNSUPPORTED, "solve_type alm is not implemented on the device yet");
+        if (p.solve_type != 0 && p.solve_type != 1) return fail(CILQR_ERR_BAD_ARG, "solve_type must be 0 (barrier) or 1 (alm)");
+        if (p.solve_type != params[0].solve_type) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share solve_type");
         if (p.reference_point != 0 && p.reference_point != 1) return fail(CILQR_ERR_BAD_ARG, "reference_point must be 0 or 1");
         if (p.max_iter < 0) return fail(CILQR_ERR_BAD_ARG, "max_iter < 0");
     }
@@ -696,11 +779,40 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.N = h->params[0].N;
     a.W = h->win;
     a.flags = h->debug_flags;
+    a.alm = h->params[0].solve_type == 1 ? 1 : 0;
+    a.alm_mu = static_cast<double*>(h->alm_mu.p);
+    a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
+    a.alm_rho = static_cast<double*>(h->alm_rho.p);
+    a.alm_C = h->alm_C;
     return a;
+}
+
+// ALM multipliers: (re)allocated zeroed when the batch grows or the scenario set changes the column count
+static int ensure_alm(cilqr_handle* h, int B) {
+    if (h->params[0].solve_type != 1) return CILQR_OK;
+    const int N = h->params[0].N;
+    int maxM = 0;
+    for (int m : h->scene_M) maxM = m > maxM ? m : maxM;
+    const int C = 8 + 2 * maxM;
+    if (B <= h->alm_B && C == h->alm_C && h->alm_mu.p) return CILQR_OK;
+    const size_t nb = sizeof(double) * (size_t)B * N * C;
+    if (h->alm_mu.ensure(nb) || h->alm_mu_next.ensure(nb) || h->alm_rho.ensure(sizeof(double) * B))
+        return fail(CILQR_ERR_DEVICE, "hipMalloc alm state");
+    HIP_TRY(hipMemset(h->alm_mu.p, 0, nb));
+    HIP_TRY(hipMemset(h->alm_mu_next.p, 0, nb));
+    std::vector<double> rho((size_t)B, h->params[0].alm_rho_init);
+    HIP_TRY(hipMemcpy(h->alm_rho.p, rho.data(), sizeof(double) * B, hipMemcpyHostToDevice));
+    h->alm_B = B;
+    h->alm_C = C;
+    return CILQR_OK;
 }
 
 static int ensure_scratch(cilqr_handle* h, int B) {
     const int N = h->params[0].N;
+    {
+        int rc_alm = ensure_alm(h, B);
+        if (rc_alm) return rc_alm;
+    }
     if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
     return CILQR_OK;
@@ -724,7 +836,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
     BatchArgs a = make_args(h, B, ids);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t shm = lds_bytes(a.N, a.W);
+    const size_t shm = lds_bytes(a.N, a.W, a.alm);
     if (h->profiling) {
         if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
         a.prof = static_cast<long long*>(h->prof.p);
@@ -732,10 +844,11 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     {
-        auto kern = k_solve<false, 1>;
         const bool two = (a.N + 1 > CILQR_WAVE);
-        if (a.flags != 0) kern = two ? k_solve<true, 2> : k_solve<true, 1>;
-        else kern = two ? k_solve<false, 2> : k_solve<false, 1>;
+        auto kern = k_solve<false, 1, false>;
+        if (a.alm) kern = two ? k_solve<true, 2, true> : k_solve<true, 1, true>;
+        else if (a.flags != 0) kern = two ? k_solve<true, 2, false> : k_solve<true, 1, false>;
+        else kern = two ? k_solve<false, 2, false> : k_solve<false, 1, false>;
         hipLaunchKernelGGL(kern, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
                            d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }
@@ -814,7 +927,7 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     if (rc) return rc;
     pc.a = make_args(h, B, pc.ids);
     pc.N = pc.a.N;
-    pc.shm = lds_bytes(pc.N, pc.a.W);
+    pc.shm = lds_bytes(pc.N, pc.a.W, pc.a.alm);
     return CILQR_OK;
 }
 
@@ -871,7 +984,7 @@ extern "C" int cilqr_total_cost_batch(cilqr_handle* h, int32_t B, const double* 
     rc = up(h, 4, x, sizeof(double) * 4 * R * (size_t)B, &d_x); if (rc) return rc;
     void* d_J;
     rc = alloc_out(h, 5, sizeof(double) * B, &d_J); if (rc) return rc;
-    hipLaunchKernelGGL(k_total_cost, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, static_cast<double*>(d_J));
+    hipLaunchKernelGGL((pc.a.alm ? k_total_cost<true> : k_total_cost<false>), dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, static_cast<double*>(d_J));
     HIP_TRY(hipGetLastError());
     DL(5, J_out, sizeof(double) * B);
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -898,7 +1011,7 @@ extern "C" int cilqr_forward_pass_batch(cilqr_handle* h, int32_t B, const double
     rc = alloc_out(h, 7, nb_u, &d_nu); if (rc) return rc;
     rc = alloc_out(h, 8, nb_x, &d_nx); if (rc) return rc;
     rc = alloc_out(h, 9, sizeof(double) * (size_t)B * n_alpha, &d_J); if (rc) return rc;
-    hipLaunchKernelGGL(k_forward_pass, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_d, d_K,
+    hipLaunchKernelGGL((pc.a.alm ? k_forward_pass<true> : k_forward_pass<false>), dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_d, d_K,
                        n_alpha, static_cast<double*>(d_nu), static_cast<double*>(d_nx), static_cast<double*>(d_J));
     HIP_TRY(hipGetLastError());
     DL(7, new_u, nb_u);
@@ -931,7 +1044,7 @@ extern "C" int cilqr_cost_derivatives_batch(cilqr_handle* h, int32_t B, const do
         rc = alloc_out(h, 5 + i, nb[i], &dev[i]);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_cost_derivatives, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x,
+    hipLaunchKernelGGL((pc.a.alm ? k_cost_derivatives<true> : k_cost_derivatives<false>), dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x,
                        static_cast<double*>(dev[0]), static_cast<double*>(dev[1]), static_cast<double*>(dev[2]),
                        static_cast<double*>(dev[3]), static_cast<double*>(dev[4]), static_cast<double*>(dev[5]));
     HIP_TRY(hipGetLastError());
@@ -959,7 +1072,7 @@ extern "C" int cilqr_backward_pass_batch(cilqr_handle* h, int32_t B, const doubl
     rc = alloc_out(h, 7, sizeof(double) * 8 * N * (size_t)B, &o_K); if (rc) return rc;
     rc = alloc_out(h, 8, sizeof(double) * 2 * B, &o_dV); if (rc) return rc;
     rc = alloc_out(h, 9, sizeof(int32_t) * B, &o_st); if (rc) return rc;
-    hipLaunchKernelGGL(k_backward_pass, dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_l,
+    hipLaunchKernelGGL((pc.a.alm ? k_backward_pass<true> : k_backward_pass<false>), dim3(B), dim3(CILQR_WAVE), pc.shm, h->stream, pc.a, d_u, d_x, d_l,
                        static_cast<double*>(o_d), static_cast<double*>(o_K), static_cast<double*>(o_dV),
                        static_cast<int32_t*>(o_st));
     HIP_TRY(hipGetLastError());

@@ -57,6 +57,7 @@ struct Cst {
     double ell_a2, ell_b2;
     double ref_velo;
     double init_lamb, lamb_decay, lamb_amplify, max_lamb, conv_thr, accept_thr;
+    double alm_rho_init, alm_gamma, max_rho, max_mu;
     gdouble* lane_xy;
     gdouble* lane_aux;
     gdouble* obs;
@@ -80,6 +81,7 @@ __device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s
     c.ref_velo = s.ref_velo;
     c.init_lamb = p.init_lamb; c.lamb_decay = p.lamb_decay; c.lamb_amplify = p.lamb_amplify;
     c.max_lamb = p.max_lamb; c.conv_thr = p.convergence_threshold; c.accept_thr = p.accept_step_threshold;
+    c.alm_rho_init = p.alm_rho_init; c.alm_gamma = p.alm_gamma; c.max_rho = p.max_rho; c.max_mu = p.max_mu;
     c.lane_xy = (gdouble*)s.lane_xy; c.lane_aux = (gdouble*)s.lane_aux; c.obs = (gdouble*)s.obs;
 }
 
@@ -92,7 +94,8 @@ struct Lds {
     double* d;   // [N][2]
     double* lx;  // [(N+1)][4]
     double* lu;  // [N][2]
-    double* lxx; // [(N+1)][7]
+    double* lxx; // [(N+1)][lxs]: 7 packed entries (barrier mode: symmetric) or 16 dense (ALM mode)
+    int lxs;
     double* luu; // [N][2]
     double* A5;  // [N][5]  a02 a03 a12 a13 a32
     double* B3;  // [N][3]  b01 b11 b31
@@ -113,15 +116,15 @@ struct Lds {
 #define CILQR_XCH_CONST 100
 #define CILQR_XCH 104
 
-__host__ __device__ inline int lds_doubles(int N) {
-    return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + 7 * (N + 1) + 2 * N + 5 * N +
+__host__ __device__ inline int lds_doubles(int N, int alm) {
+    return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + 5 * N +
            3 * N + CILQR_XCH + 3 * (N + 1);
 }
-__host__ __device__ inline size_t lds_bytes(int N, int W) {
-    return sizeof(double) * ((size_t)lds_doubles(N) + 2 * (size_t)W) + sizeof(int) * (size_t)(2 * N + 4);
+__host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
+    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)(2 * N + 4);
 }
 
-__device__ inline void carve(Lds& l, double* base, int N, int W) {
+__device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
@@ -129,7 +132,8 @@ __device__ inline void carve(Lds& l, double* base, int N, int W) {
     l.d = p; p += 2 * N;
     l.lx = p; p += 4 * (N + 1);
     l.lu = p; p += 2 * N;
-    l.lxx = p; p += 7 * (N + 1);
+    l.lxs = alm ? 16 : 7;
+    l.lxx = p; p += l.lxs * (N + 1);
     l.luu = p; p += 2 * N;
     l.A5 = p; p += 5 * N;
     l.B3 = p; p += 3 * N;
@@ -398,11 +402,28 @@ __device__ inline gdouble* obs_at(const Cst& c, int j, int k) {
     return c.obs + ((size_t)j * c.T + (size_t)(c.tick + k)) * CILQR_OBS_STRIDE;
 }
 
+// Augmented-Lagrangian state of one trajectory (hpp:106-112): multipliers in HBM, [N][C], C = 8 + 2 M
+struct AlmSt {
+    double* mu;
+    double* mu_next;
+    double rho;
+    int C;
+};
+
+// hpp:81-83 augmented_lagrangian_item
+__device__ inline double alm_item(double cv, double rho, double mu) {
+    double t = cv + mu / rho;
+    double m = (t > 0.0) ? t : 0.0;
+    return rho * (m * m) / 2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage cost of row k (cs:199-287).  xk = x[k], uk = u[k] (k < N), ukm1 = u[k-1] (k >= 1).
 // sd = k-th diagonal entry of (x-ref) W (x-ref)^T, ce = k-th of u R u^T, jb = J_barrier_k.
-__device__ inline void stage_cost(const Cst& c, const Lds& l, int k, const double xk[4], const double uk[2],
-                                  const double ukm1[2], int ridx, double& sd, double& ce, double& jb) {
+template <bool ALM>
+__device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, int k, const double xk[4],
+                                  const double uk[2], const double ukm1[2], int ridx, double& sd, double& ce,
+                                  double& jb) {
     double rx, ry;
     lane_point(c, l, ridx, rx, ry);
     gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
@@ -420,20 +441,37 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, int k, const doubl
         double hyp = dm_hypot(e0, e1);
         double cur_d = (d_sign < 0) ? -hyp : hyp;
         double pos_up = cur_d - c.pos_up_b, pos_lo = c.pos_lo_b - cur_d;
-        double j = c.sq1 * dm_exp(c.sq2 * acc_up) + c.sq1 * dm_exp(c.sq2 * acc_lo);
-        j = j + c.sq1 * dm_exp(c.sq2 * stl_up);
-        j = j + c.sq1 * dm_exp(c.sq2 * stl_lo);
-        j = j + c.sq1 * dm_exp(c.sq2 * vel_up);
-        j = j + c.sq1 * dm_exp(c.sq2 * vel_lo);
-        j = j + c.sq1 * dm_exp(c.sq2 * pos_up);
-        j = j + c.sq1 * dm_exp(c.sq2 * pos_lo);
+        const double* mu = ALM ? (al.mu + (size_t)(k - 1) * al.C) : nullptr;
+        double j;
+        if (ALM) {
+            j = alm_item(acc_up, al.rho, mu[0]) + alm_item(acc_lo, al.rho, mu[1]);
+            j = j + alm_item(stl_up, al.rho, mu[2]);
+            j = j + alm_item(stl_lo, al.rho, mu[3]);
+            j = j + alm_item(vel_up, al.rho, mu[4]);
+            j = j + alm_item(vel_lo, al.rho, mu[5]);
+            j = j + alm_item(pos_up, al.rho, mu[6]);
+            j = j + alm_item(pos_lo, al.rho, mu[7]);
+        } else {
+            j = c.sq1 * dm_exp(c.sq2 * acc_up) + c.sq1 * dm_exp(c.sq2 * acc_lo);
+            j = j + c.sq1 * dm_exp(c.sq2 * stl_up);
+            j = j + c.sq1 * dm_exp(c.sq2 * stl_lo);
+            j = j + c.sq1 * dm_exp(c.sq2 * vel_up);
+            j = j + c.sq1 * dm_exp(c.sq2 * vel_lo);
+            j = j + c.sq1 * dm_exp(c.sq2 * pos_up);
+            j = j + c.sq1 * dm_exp(c.sq2 * pos_lo);
+        }
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
         for (int o = 0; o < c.M; ++o) {
             ObsOut t;
             obstacle_terms<false>(c, xk, sy, cy, obs_at(c, o, k), t);
-            j = j + c.oq1 * dm_exp(c.oq2 * t.mf);
-            j = j + c.oq1 * dm_exp(c.oq2 * t.mr);
+            if (ALM) {
+                j = j + alm_item(t.mf, al.rho, mu[8 + 2 * o]);
+                j = j + alm_item(t.mr, al.rho, mu[9 + 2 * o]);
+            } else {
+                j = j + c.oq1 * dm_exp(c.oq2 * t.mf);
+                j = j + c.oq1 * dm_exp(c.oq2 * t.mr);
+            }
         }
         jb = j;
     }
@@ -466,7 +504,8 @@ __device__ inline double sum_stage_costs(const Lds& l, int N, int lane) {
 }
 
 // get_total_cost of the trajectory held in LDS (x, u, ridx)
-__device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
+template <bool ALM>
+__device__ inline double total_cost_lds(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
     const int N = c.N;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
@@ -474,7 +513,7 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
         if (k < N) { uk[0] = l.u[2 * k]; uk[1] = l.u[2 * k + 1]; }
         if (k >= 1) { um[0] = l.u[2 * k - 2]; um[1] = l.u[2 * k - 1]; }
         double sd, ce, jb;
-        stage_cost(c, l, k, xk, uk, um, l.ridx[k], sd, ce, jb);
+        stage_cost<ALM>(c, l, al, k, xk, uk, um, l.ridx[k], sd, ce, jb);
         l.cs[k] = sd;
         l.cs[(N + 1) + k] = ce;
         l.cs[2 * (N + 1) + k] = jb;
@@ -495,9 +534,10 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, int lane) {
 // decreasing at m[k].  If that holds for every row, idx == m by induction from idx[0] = idx0;
 // otherwise (non-monotone candidates, an earlier minimum missed, ...) the serial chain runs.
 // NCH = rows per lane: 1 when N + 1 <= 64, else 2 (N + 1 <= 128; cilqr_set_params caps N at 127)
-template <bool DBG, int NCH>
-__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane, int idx0,
-                                          int flags_in, int* n_fallback, long long* sub = nullptr) {
+template <bool DBG, int NCH, bool ALM>
+__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a,
+                                          int lane, int idx0, int flags_in, int* n_fallback,
+                                          long long* sub = nullptr) {
     const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
@@ -587,7 +627,7 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const doub
         const int k = lane + CILQR_WAVE * ch;
         if (k <= N) {
             double sd, ce, jb;
-            stage_cost(c, l, k, xk[ch], uk[ch], um[ch], l.tidx[k], sd, ce, jb);
+            stage_cost<ALM>(c, l, al, k, xk[ch], uk[ch], um[ch], l.tidx[k], sd, ce, jb);
             l.cs[k] = sd;
             l.cs[R + k] = ce;
             l.cs[2 * R + k] = jb;
@@ -724,11 +764,28 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
 }
 
 // ---------------------------------------------------------------------------------------------
-// get_total_cost_derivatives_and_Hessians (cs:463-690, barrier mode) and
-// get_kinematic_model_derivatives (ut:285-342), lane = k.  Row k holds l_x[k], l_xx[k] (from x[k],
-// u[k-1]-independent), lane k also produces l_u[k-1], l_uu[k-1] (they depend on u[k-1]) and, for
-// k < N, the model Jacobian entries of step k.
-__device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, int lane) {
+// hpp/cs:701-713 lagrangian_derivative_and_Hessian: the scalar s with b_dot = s * c_dot,
+// b_ddot = b_dot * c_dot^T (s = 0 when the constraint is inactive)
+__device__ inline double alm_slope(double cv, double rho, double mu) {
+    double t = cv + mu / rho;
+    return (t > 0) ? rho * t : 0.0;
+}
+// cs:622-637 / 673-676 multiplier update
+__device__ inline double alm_next_mu(const Cst& c, double mu, double rho, double cv) {
+    double v = mu + rho * cv;
+    v = (v > 0.0) ? v : 0.0;
+    v = (c.max_mu < v) ? c.max_mu : v;
+    return v;
+}
+
+// get_total_cost_derivatives_and_Hessians (cs:463-690) and get_kinematic_model_derivatives
+// (ut:285-342), lane = k.  Row k holds l_x[k], l_xx[k]; lane k also produces l_u[k-1], l_uu[k-1]
+// (they depend on u[k-1]) and, for k < N, the model Jacobian entries of step k.
+// ALM = false: exponential barriers, l_xx packed (symmetric).  ALM = true: augmented Lagrangian
+// terms (cs:581-643, 665-680), l_xx dense (b_dot c_dot^T is not bitwise symmetric), and the
+// multiplier proposal alm_mu_next is written.
+template <bool ALM>
+__device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
     const int N = c.N;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
@@ -744,7 +801,64 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, in
         double b0 = 0, b1 = 0, b2 = 0, b3 = 0;                                 // barrier gradient
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
-        if (k >= 1) {
+        double g10 = 0, g30 = 0, g31 = 0; // ALM only: the other halves of the non-symmetric Hessian
+        if (ALM && k >= 1) {
+            const double um0 = l.u[2 * k - 2], um1 = l.u[2 * k - 1];
+            const double* mu = al.mu + (size_t)(k - 1) * al.C;
+            double* mun = al.mu_next + (size_t)(k - 1) * al.C;
+            const double rho = al.rho;
+            const double d_sign = e1 * cr - e0 * sr;
+            const double hyp = dm_hypot(e0, e1);
+            const double cur_d = (d_sign < 0) ? -hyp : hyp;
+            const double cv[8] = {um0 - c.acc_max, c.acc_min - um0, um1 - c.stl_lim, -c.stl_lim - um1,
+                                  xk[2] - c.velo_max, c.velo_min - xk[2], cur_d - c.pos_up_b, c.pos_lo_b - cur_d};
+            double sl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sl[j] = alm_slope(cv[j], rho, mu[j]);
+                mun[j] = alm_next_mu(c, mu[j], rho, cv[j]);
+            }
+            l.lu[2 * (k - 1)] = 2 * (um0 * c.w_acc) + (sl[0] - sl[1]);
+            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.w_stl) + (sl[2] - sl[3]);
+            l.luu[2 * (k - 1)] = 2 * c.w_acc + (sl[0] + sl[1]);
+            l.luu[2 * (k - 1) + 1] = 2 * c.w_stl + (sl[2] + sl[3]);
+            double px = e0 / hyp, py = e1 / hyp;
+            if (d_sign < 0) { px = -px; py = -py; }
+            const double nx = -px, ny = -py;
+            const double ux = sl[6] * px, uy = sl[6] * py, vx = sl[7] * nx, vy = sl[7] * ny; // b_dot of pos_up / pos_lo
+            b0 = ux + vx;
+            b1 = uy + vy;
+            b2 = sl[4] - sl[5];
+            b3 = 0.0;
+            h00 = ux * px + vx * nx;
+            h01 = ux * py + vx * ny;
+            g10 = uy * px + vy * nx;
+            h11 = uy * py + vy * ny;
+            h22 = sl[4] + sl[5];
+            for (int o = 0; o < c.M; ++o) {
+                ObsOut t;
+                obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
+                const double sf = alm_slope(t.mf, rho, mu[8 + 2 * o]);
+                const double sr2 = alm_slope(t.mr, rho, mu[9 + 2 * o]);
+                mun[8 + 2 * o] = alm_next_mu(c, mu[8 + 2 * o], rho, t.mf);
+                mun[9 + 2 * o] = alm_next_mu(c, mu[9 + 2 * o], rho, t.mr);
+                const double f0 = sf * t.gf[0], f1 = sf * t.gf[1], f3 = sf * t.gf[2];
+                const double r0 = sr2 * t.gr[0], r1 = sr2 * t.gr[1], r3 = sr2 * t.gr[2];
+                b0 = b0 + (f0 + r0);
+                b1 = b1 + (f1 + r1);
+                b3 = b3 + (f3 + r3);
+                h00 = h00 + (f0 * t.gf[0] + r0 * t.gr[0]);
+                h01 = h01 + (f0 * t.gf[1] + r0 * t.gr[1]);
+                h03 = h03 + (f0 * t.gf[2] + r0 * t.gr[2]);
+                g10 = g10 + (f1 * t.gf[0] + r1 * t.gr[0]);
+                h11 = h11 + (f1 * t.gf[1] + r1 * t.gr[1]);
+                h13 = h13 + (f1 * t.gf[2] + r1 * t.gr[2]);
+                g30 = g30 + (f3 * t.gf[0] + r3 * t.gr[0]);
+                g31 = g31 + (f3 * t.gf[1] + r3 * t.gr[1]);
+                h33 = h33 + (f3 * t.gf[2] + r3 * t.gr[2]);
+            }
+        }
+        if (!ALM && k >= 1) {
             double um0 = l.u[2 * k - 2], um1 = l.u[2 * k - 1];
             // control bounds (cs:510-513, 537-558)
             double b_au = c.sq1 * dm_exp(c.sq2 * (um0 - c.acc_max));
@@ -806,14 +920,22 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, in
         l.lx[4 * k + 1] = lx1 + b1;
         l.lx[4 * k + 2] = lx2 + b2;
         l.lx[4 * k + 3] = lx3 + b3;
-        double* hx = l.lxx + 7 * k;
-        hx[0] = 2 * c.w_pos + h00;
-        hx[1] = 0.0 + h01;
-        hx[2] = 0.0 + h03;
-        hx[3] = 2 * c.w_pos + h11;
-        hx[4] = 0.0 + h13;
-        hx[5] = 2 * c.w_yaw + h33;
-        hx[6] = 2 * c.w_vel + h22;
+        if (ALM) {
+            double* hx = l.lxx + 16 * k;
+            hx[0] = 2 * c.w_pos + h00; hx[1] = 0.0 + h01; hx[2] = 0.0; hx[3] = 0.0 + h03;
+            hx[4] = 0.0 + g10; hx[5] = 2 * c.w_pos + h11; hx[6] = 0.0; hx[7] = 0.0 + h13;
+            hx[8] = 0.0; hx[9] = 0.0; hx[10] = 2 * c.w_vel + h22; hx[11] = 0.0;
+            hx[12] = 0.0 + g30; hx[13] = 0.0 + g31; hx[14] = 0.0; hx[15] = 2 * c.w_yaw + h33;
+        } else {
+            double* hx = l.lxx + 7 * k;
+            hx[0] = 2 * c.w_pos + h00;
+            hx[1] = 0.0 + h01;
+            hx[2] = 0.0 + h03;
+            hx[3] = 2 * c.w_pos + h11;
+            hx[4] = 0.0 + h13;
+            hx[5] = 2 * c.w_yaw + h33;
+            hx[6] = 2 * c.w_vel + h22;
+        }
         if (k < N) {
             // model Jacobians of step k (ut:285-342)
             double v = xk[2];
@@ -1032,6 +1154,7 @@ __device__ inline void lane_map_M(const Lds& l, int k, int j, int& off, int& str
 }
 
 __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
+    const bool dense_lxx = (l.lxs == 16);
     const int rp = (lane >> 3) % 6, cc = lane & 7;      // lanes >= 48 alias rows 0/1 (results unused)
     const int ccm = (cc < 6) ? cc : 5;
     const int CC = (int)(l.xch - l.x) + CILQR_XCH_CONST;
@@ -1052,6 +1175,7 @@ __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
         if (a == 3 && b == 3) e = 5;
         if (a == 2 && b == 2) e = 6;
         if (e >= 0) { m.lq = LXX + e; m.slq = 7; }
+        if (dense_lxx) { m.lq = LXX + 4 * rp + cc; m.slq = 16; }
     } else if (rp >= 4 && cc == rp) {
         m.lq = LUU + (rp - 4); m.slq = 2;
     }

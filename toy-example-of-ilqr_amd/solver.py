@@ -140,6 +140,22 @@ class BatchedCILQR:
     def set_debug_flags(self, flags):
         check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
+    def set_alm_state(self, mu=None, rho=None):
+        B = (mu.shape[0] if mu is not None else np.asarray(rho).shape[0])
+        mu = None if mu is None else _f64(mu)
+        rho = None if rho is None else _f64(rho)
+        check(self._lib.cilqr_set_alm_state(self._h, int(B), _p(mu), _p(rho)), "cilqr_set_alm_state")
+
+    def get_alm_state(self, B):
+        cols = C.c_int32(0)
+        check(self._lib.cilqr_get_alm_state(self._h, int(B), None, None, None, C.byref(cols)), "cilqr_get_alm_state")
+        mu = np.empty((B, self.N, cols.value))
+        mun = np.empty((B, self.N, cols.value))
+        rho = np.empty(B)
+        check(self._lib.cilqr_get_alm_state(self._h, int(B), _p(mu), _p(mun), _p(rho), C.byref(cols)),
+              "cilqr_get_alm_state")
+        return mu, mun, rho
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         check(self._lib.cilqr_last_kernel_ms(self._h, C.byref(ms)), "cilqr_last_kernel_ms")
