@@ -138,29 +138,47 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
             PROF_ADD(PH_ROLLOUT);
             bool done = false;
-            for (int t = 0; t < CILQR_MAX_ALPHA_TRIALS && !done; ++t) {
-                const double alpha = dm_pow2i(-t);
-                new_J = total_cost_trial<DBG, NCH, ALM>(c, l, al, scr, t, lane, idx0, a.flags, &n_fallback, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
-                PROF_ADD(PH_TRIAL_COST);
-                trials++;
-                const double decay = J_cur - new_J;
-                const double adecay = (decay < 0) ? -decay : decay;
-                if (t == 0 && adecay < c.conv_thr) {
-                    status = CILQR_CONVERGED;
-                    alpha_idx = t;
-                    done = true;
+            // the line search of cs:354-372; the costs are produced pass by pass — alpha = 1 alone
+            // (usually accepted), then CILQR_NT trials per pass — and consumed strictly in order
+            for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
+                double Jp[CILQR_NT];
+                int nt = (t0 == 0) ? 1 : CILQR_NT;
+                if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
+                if (nt == 1) {
+                    double J1[1];
+                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
+                                                        a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                    Jp[0] = J1[0];
                 } else {
-                    const double approx = -(alpha * alpha * dV[0] + alpha * dV[1]);
-                    if (decay > 0.0 && (approx < 0.0 || decay / approx > c.accept_thr)) {
-                        if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
-                        flag = 1;
+                    total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, scr, t0, nt, lane, idx0, a.flags, &n_fallback,
+                                                               Jp, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                }
+                PROF_ADD(PH_TRIAL_COST);
+                for (int tt = 0; tt < nt && !done; ++tt) {
+                    const int t = t0 + tt;
+                    const double alpha = dm_pow2i(-t);
+                    new_J = Jp[tt];
+                    trials++;
+                    const double decay = J_cur - new_J;
+                    const double adecay = (decay < 0) ? -decay : decay;
+                    if (t == 0 && adecay < c.conv_thr) {
+                        status = CILQR_CONVERGED;
                         alpha_idx = t;
-                        accept_trial(c, l, scr, t, lane);
-                        PROF_ADD(PH_ACCEPT);
-                        J_cur = new_J;
                         done = true;
+                    } else {
+                        const double approx = -(alpha * alpha * dV[0] + alpha * dV[1]);
+                        if (decay > 0.0 && (approx < 0.0 || decay / approx > c.accept_thr)) {
+                            if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
+                            flag = 1;
+                            alpha_idx = t;
+                            accept_trial(c, l, scr, t, tt, lane);
+                            PROF_ADD(PH_ACCEPT);
+                            J_cur = new_J;
+                            done = true;
+                        }
                     }
                 }
+                t0 += nt;
             }
             if (!done) {
                 status = CILQR_FORWARD_PASS_FAIL;

@@ -100,10 +100,10 @@ struct Lds {
     double* A5;  // [N][5]  a02 a03 a12 a13 a32
     double* B3;  // [N][3]  b01 b11 b31
     double* xch; // [CILQR_XCH] exchange buffers of the lane-parallel backward sweep (see backward_sweep_lanes)
-    double* cs;  // [3][(N+1)] stage-cost scratch: state, ctrl, barrier
+    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
-    int* tidx;   // [(N+1)] the same for the trial trajectory being costed
+    int* tidx;   // [CILQR_NT][(N+2)] the same for the trial trajectories being costed
     int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
     int W;
 };
@@ -115,13 +115,14 @@ struct Lds {
 #define CILQR_XCH_QV 92
 #define CILQR_XCH_CONST 100
 #define CILQR_XCH 104
+#define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
     return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + 5 * N +
-           3 * N + CILQR_XCH + 3 * (N + 1);
+           3 * N + CILQR_XCH + CILQR_NT * 3 * (N + 1);
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
-    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)(2 * N + 4);
+    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2));
 }
 
 __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
@@ -138,7 +139,7 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.A5 = p; p += 5 * N;
     l.B3 = p; p += 3 * N;
     l.xch = p; p += CILQR_XCH;
-    l.cs = p; p += 3 * (N + 1);
+    l.cs = p; p += CILQR_NT * 3 * (N + 1);
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
     l.tidx = l.ridx + (N + 2);
@@ -479,6 +480,33 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
 
 // J = (sum_k sd + sum_k ce) + sum_k jb, each sum sequential in k as Eigen's trace()/the loop at
 // cs:217 accumulate.  All lanes compute the same value from LDS broadcasts.
+// NTR trials at once: lanes 3*tt + {0,1,2} take trial slot tt; J[tt] for every slot on every lane.
+template <int NTR>
+__device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, double J[NTR]) {
+    const int R = N + 1;
+    const int slot = (lane < 3 * NTR) ? lane / 3 : 0;
+    const int row = (lane < 3 * NTR) ? lane % 3 : 0;
+    const double* v = l.cs + (size_t)slot * 3 * R + row * R;
+    const int last = (row == 1) ? N - 1 : N;
+    double acc = (row == 2) ? 0.0 : v[0];
+    int k = 1;
+    for (; k + 7 <= last; k += 8) {
+        double a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = v[k + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = acc + a[t];
+    }
+    for (; k <= last; ++k) acc = acc + v[k];
+#pragma unroll
+    for (int tt = 0; tt < NTR; ++tt) {
+        double sd = __shfl(acc, 3 * tt, CILQR_WAVE);
+        double ce = __shfl(acc, 3 * tt + 1, CILQR_WAVE);
+        double jb = __shfl(acc, 3 * tt + 2, CILQR_WAVE);
+        J[tt] = (sd + ce) + jb;
+    }
+}
+
 __device__ inline double sum_stage_costs(const Lds& l, int N, int lane) {
     // lanes 0, 1, 2 each run one of the three sequential sums (state, control, barrier) over its own
     // row of l.cs; one instruction stream, three chains.  Then J = (sd + ce) + jb on every lane.
@@ -534,111 +562,160 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, const AlmSt&
 // decreasing at m[k].  If that holds for every row, idx == m by induction from idx[0] = idx0;
 // otherwise (non-monotone candidates, an earlier minimum missed, ...) the serial chain runs.
 // NCH = rows per lane: 1 when N + 1 <= 64, else 2 (N + 1 <= 128; cilqr_set_params caps N at 127)
-template <bool DBG, int NCH, bool ALM>
-__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a,
-                                          int lane, int idx0, int flags_in, int* n_fallback,
-                                          long long* sub = nullptr) {
+// NTR = trials costed in this pass (a0, a0+1, ...; slots beyond `nt` are skipped): their loads and
+// LDS round trips overlap, so a pass of two costs much less than two passes of one.
+template <bool DBG, int NCH, bool ALM, int NTR>
+__device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a0,
+                                         int nt, int lane, int idx0, int flags_in, int* n_fallback, double J[NTR],
+                                         long long* sub = nullptr) {
     const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + a;
     long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
-    // this lane's rows of the trial, fetched once
-    double xk[NCH][4], uk[NCH][2], um[NCH][2];
+    // this lane's rows of the trials, fetched once
+    double xk[NTR][NCH][4], uk[NTR][NCH][2], um[NTR][NCH][2];
     int guess[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int k = lane + CILQR_WAVE * ch;
-        xk[ch][0] = xk[ch][1] = xk[ch][2] = xk[ch][3] = 0.0;
-        uk[ch][0] = uk[ch][1] = um[ch][0] = um[ch][1] = 0.0;
-        guess[ch] = idx0;
-        if (k <= N) {
-            xk[ch][0] = TR(t, 0, k); xk[ch][1] = TR(t, 1, k); xk[ch][2] = TR(t, 2, k); xk[ch][3] = TR(t, 3, k);
-            if (k < N) { uk[ch][0] = TR(t, 4, k); uk[ch][1] = TR(t, 5, k); }
-            if (k >= 1) { um[ch][0] = TR(t, 4, k - 1); um[ch][1] = TR(t, 5, k - 1); }
-            guess[ch] = l.ridx[k];
-        }
+        guess[ch] = (k <= N) ? l.ridx[k] : idx0;
     }
-    bool proven = false;
-    if (!(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
-        // level 0: the trial keeps the current trajectory's indices (small steps: the usual case of a
-        // failing line search) — one cheap check per row, no search, no exchange
-        bool ok0 = true;
+#pragma unroll
+    for (int tt = 0; tt < NTR; ++tt) {
+        const double* t = scr + a0 + tt;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
-            if (k >= 1 && k <= N) ok0 = ok0 && verify_window_fast(l, xk[ch][0], xk[ch][1], l.ridx[k - 1], guess[ch]);
+            xk[tt][ch][0] = xk[tt][ch][1] = xk[tt][ch][2] = xk[tt][ch][3] = 0.0;
+            uk[tt][ch][0] = uk[tt][ch][1] = um[tt][ch][0] = um[tt][ch][1] = 0.0;
+            if (tt < nt && k <= N) {
+                xk[tt][ch][0] = TR(t, 0, k); xk[tt][ch][1] = TR(t, 1, k);
+                xk[tt][ch][2] = TR(t, 2, k); xk[tt][ch][3] = TR(t, 3, k);
+                if (k < N) { uk[tt][ch][0] = TR(t, 4, k); uk[tt][ch][1] = TR(t, 5, k); }
+                if (k >= 1) { um[tt][ch][0] = TR(t, 4, k - 1); um[tt][ch][1] = TR(t, 5, k - 1); }
+            }
         }
-        if (__ballot(!ok0) == 0ULL) {
+    }
+    bool proven[NTR];
+#pragma unroll
+    for (int tt = 0; tt < NTR; ++tt) proven[tt] = (tt >= nt);
+    if (!(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
+        // level 0: the trial keeps the current trajectory's indices (small steps: the usual case of a
+        // failing line search) — one cheap check per row, no search, no exchange
+#pragma unroll
+        for (int tt = 0; tt < NTR; ++tt) {
+            if (tt >= nt) continue;
+            bool ok0 = true;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int k = lane + CILQR_WAVE * ch;
-                if (k <= N) l.tidx[k] = guess[ch];
+                if (k >= 1 && k <= N)
+                    ok0 = ok0 && verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], l.ridx[k - 1], guess[ch]);
             }
-            proven = true;
+            if (__ballot(!ok0) == 0ULL) {
+                int* tix = l.tidx + tt * (N + 2);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = lane + CILQR_WAVE * ch;
+                    if (k <= N) tix[k] = guess[ch];
+                }
+                proven[tt] = true;
+            }
+        }
+        // level 1: independent search for a candidate per row, then the proof
+        bool any_l1 = false;
+#pragma unroll
+        for (int tt = 0; tt < NTR; ++tt) any_l1 = any_l1 || !proven[tt];
+        if (any_l1) {
+#pragma unroll
+            for (int tt = 0; tt < NTR; ++tt) {
+                if (proven[tt]) continue;
+                int* tix = l.tidx + tt * (N + 2);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = lane + CILQR_WAVE * ch;
+                    if (k <= N) {
+                        int m = idx0;
+                        if (k > 0) {
+                            int g = guess[ch];
+                            g = (g < idx0) ? idx0 : g;
+                            g = (g > c.L - 1) ? c.L - 1 : g;
+                            m = local_min_near(c, l, xk[tt][ch][0], xk[tt][ch][1], g, idx0);
+                        }
+                        tix[k] = m;
+                    }
+                }
+            }
             __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < NTR; ++tt) {
+                if (proven[tt]) continue;
+                const int* tix = l.tidx + tt * (N + 2);
+                bool ok = true;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = lane + CILQR_WAVE * ch;
+                    if (k >= 1 && k <= N) {
+                        const int lo = tix[k - 1], hi = tix[k];
+                        bool good = (lo <= hi);
+                        if (good && !verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], lo, hi))
+                            good = verify_interval(c, l, xk[tt][ch][0], xk[tt][ch][1], lo, hi);
+                        ok = ok && good;
+                    }
+                }
+                proven[tt] = (__ballot(!ok) == 0ULL);
+            }
         }
     }
-    if (!proven && !(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
-        // level 1: independent search for a candidate per row, then the proof
+    // level 2: the serial chain of cs:289-314
+#pragma unroll
+    for (int tt = 0; tt < NTR; ++tt) {
+        if (proven[tt]) continue;
+        __syncthreads();
+        *n_fallback += 1;
+        const double* t = scr + a0 + tt;
+        int* tix = l.tidx + tt * (N + 2);
+        int s = idx0;
+        if (lane == 0) tix[0] = s;
+        for (int i = 1; i <= N; ++i) {
+            s = ref_scan_from(c, l, TR(t, 0, i), TR(t, 1, i), s);
+            if (lane == 0) tix[i] = s;
+        }
+    }
+    __syncthreads();
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
+#pragma unroll
+    for (int tt = 0; tt < NTR; ++tt) {
+        if (tt >= nt) continue;
+        const int* tix = l.tidx + tt * (N + 2);
+        double* cs = l.cs + (size_t)tt * 3 * R;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
             if (k <= N) {
-                int m = idx0;
-                if (k > 0) {
-                    int g = guess[ch];
-                    g = (g < idx0) ? idx0 : g;
-                    g = (g > c.L - 1) ? c.L - 1 : g;
-                    m = local_min_near(c, l, xk[ch][0], xk[ch][1], g, idx0);
-                }
-                l.tidx[k] = m;
+                double sd, ce, jb;
+                stage_cost<ALM>(c, l, al, k, xk[tt][ch], uk[tt][ch], um[tt][ch], tix[k], sd, ce, jb);
+                cs[k] = sd;
+                cs[R + k] = ce;
+                cs[2 * R + k] = jb;
             }
-        }
-        __syncthreads();
-        bool ok = true;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int k = lane + CILQR_WAVE * ch;
-            if (k >= 1 && k <= N) {
-                const int lo = l.tidx[k - 1], hi = l.tidx[k];
-                bool good = (lo <= hi);
-                if (good && !verify_window_fast(l, xk[ch][0], xk[ch][1], lo, hi))
-                    good = verify_interval(c, l, xk[ch][0], xk[ch][1], lo, hi);
-                ok = ok && good;
-            }
-        }
-        proven = (__ballot(!ok) == 0ULL);
-        __syncthreads();
-    }
-    if (!proven) {
-        *n_fallback += 1;
-        int s = idx0;
-        if (lane == 0) l.tidx[0] = s;
-        for (int i = 1; i <= N; ++i) {
-            s = ref_scan_from(c, l, TR(t, 0, i), TR(t, 1, i), s);
-            if (lane == 0) l.tidx[i] = s;
-        }
-        __syncthreads();
-    }
-    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int k = lane + CILQR_WAVE * ch;
-        if (k <= N) {
-            double sd, ce, jb;
-            stage_cost<ALM>(c, l, al, k, xk[ch], uk[ch], um[ch], l.tidx[k], sd, ce, jb);
-            l.cs[k] = sd;
-            l.cs[R + k] = ce;
-            l.cs[2 * R + k] = jb;
         }
     }
     __syncthreads();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[1] += t1 - t0; t0 = t1; }
-    double J = sum_stage_costs(l, N, lane);
+    sum_stage_costs_multi<NTR>(l, N, lane, J);
     __syncthreads();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[2] += t1 - t0; }
-    return J;
+}
+
+// single-trial form (piecewise kernel)
+template <bool DBG, int NCH, bool ALM>
+__device__ inline double total_cost_trial(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a,
+                                          int lane, int idx0, int flags_in, int* n_fallback,
+                                          long long* sub = nullptr) {
+    double J[1];
+    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, a, 1, lane, idx0, flags_in, n_fallback, J, sub);
+    return J[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,8 +821,8 @@ __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, i
     else rollout_trials_rp<1>(c, l, scr, lane, n_alpha);
 }
 
-// copy trial `a` (whose cost was evaluated last, so l.tidx is its index row) into the current trajectory
-__device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int lane) {
+// copy trial `a` (costed in slot `slot` of the last pass, whose index row is still in l.tidx) into the current trajectory
+__device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int slot, int lane) {
     const int N = c.N;
     const int R = N + 1;
     const double* t = scr + a;
@@ -754,7 +831,7 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
         l.x[4 * k + 1] = TR(t, 1, k);
         l.x[4 * k + 2] = TR(t, 2, k);
         l.x[4 * k + 3] = TR(t, 3, k);
-        l.ridx[k] = l.tidx[k];
+        l.ridx[k] = l.tidx[slot * (N + 2) + k];
         if (k < N) {
             l.u[2 * k] = TR(t, 4, k);
             l.u[2 * k + 1] = TR(t, 5, k);
