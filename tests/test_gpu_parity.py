@@ -432,3 +432,56 @@ def test_alm_closed_loop_keeps_multipliers(pkg, orc_det, engines):
         compare_solves(out, [s.solve(x0, oracle_scene(sc, tick))], f"alm tick {tick}")
         last_u = out["u"][0]
         x0 = out["x"][0, 1].copy()
+
+
+# ---- BASELINE.json configurations at (or near) full size ------------------------------------------
+def test_config2_full_batch_bitexact(pkg, orc_det):
+    """configs[1], the benchmark workload: all 1024 trajectories, every output field, against the oracle."""
+    wl = pkg.workloads.config2()
+    assert wl.B == 1024 and wl.N == 50
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+    from oracle import Scene
+    s0 = wl.scenes[0]
+    scene = Scene(s0.lane_x, s0.lane_y, s0.lane_yaw, s0.obs, s0.road_borders, s0.ref_velo)
+    ref = orc_det.solve_batch(wl.params, scene, wl.x0, n_threads=16)
+    eq_bits(out["u"], ref["u"], "config2 u")
+    eq_bits(out["x"], ref["x"], "config2 x")
+    for f in ("J_init", "J_final", "iters", "end_reason", "final_status", "ls_trials", "cost_evals"):
+        assert np.array_equal(out["res"][f], ref["res"][f]), f
+    # the statistics bench.py prints
+    assert int(out["res"]["iters"].sum()) == 21955 and int(out["res"]["ls_trials"].sum()) == 57348
+    eng.close()
+
+
+def test_config3_and_config5_properties_at_scale(pkg, orc_det):
+    """configs[2] (8192 x three_bend) and configs[4] (barrier sweep): size-independent properties on the
+    full batch + oracle parity on a strided sample."""
+    from oracle import Scene
+    for wl in (pkg.workloads.config3(), pkg.workloads.config5(B_base=512)):
+        eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+        out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+        res = out["res"]
+        assert np.isfinite(out["x"]).all() and np.isfinite(out["u"]).all()
+        assert (res["J_final"] <= res["J_init"]).all()                       # accepted steps only ever lower the cost
+        assert ((res["iters"] >= 1) & (res["iters"] <= wl.params[0].max_iter)).all()
+        assert (res["cost_evals"] == 1 + res["iters"] + res["ls_trials"]).all()
+        assert np.array_equal(out["x"][:, 0], wl.x0)                          # x[0] is the given state
+        # recomputing the cost of the returned trajectory reproduces J_final (idempotence)
+        sel = np.arange(0, wl.B, max(1, wl.B // 256))
+        J2 = np.empty(sel.size)
+        for pid in np.unique(wl.param_id[sel]):
+            m = wl.param_id[sel] == pid
+            J2[m] = eng.total_cost(out["u"][sel][m], out["x"][sel][m], wl.scenario_id[sel][m], wl.param_id[sel][m], wl.tick[sel][m])
+        eq_bits(J2, res["J_final"][sel], "J_final recomputed")
+        # shard invariance: solving a slice alone gives the same rows
+        lo, hi = wl.B // 3, wl.B // 3 + 64
+        part = eng.solve_batch(wl.x0[lo:hi], wl.scenario_id[lo:hi], wl.param_id[lo:hi], wl.tick[lo:hi])
+        eq_bits(part["x"], out["x"][lo:hi], "slice x")
+        # oracle parity on the sample
+        s0 = wl.scenes[0]
+        scene = Scene(s0.lane_x, s0.lane_y, s0.lane_yaw, s0.obs, s0.road_borders, s0.ref_velo)
+        ref = orc_det.solve_batch(wl.params, scene, wl.x0[sel], None, wl.param_id[sel], None, n_threads=16)
+        eq_bits(out["x"][sel], ref["x"], "sample x")
+        eq_bits(out["res"]["J_final"][sel], ref["res"]["J_final"], "sample J")
+        eng.close()
