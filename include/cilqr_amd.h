@@ -150,6 +150,11 @@ int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
 int cilqr_set_alm_state(cilqr_handle* h, int32_t B, const double* mu, const double* rho);
 int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next, double* rho, int32_t* cols);
 
+/* Helper wavefronts: -1 (default) = automatic — a second wavefront per trajectory costs every other
+ * line-search trial when the batch is too small (<= 1024) to fill the chip with one wavefront per
+ * trajectory; 0 = never; 1 = always.  Results are identical in every mode. */
+int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
+
 /* Optional in-kernel cycle accounting of the fused solve (development aid): when enabled, the next
  * solve records, per trajectory, shader-clock cycles spent in
  * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,

@@ -485,3 +485,23 @@ def test_config3_and_config5_properties_at_scale(pkg, orc_det):
         eq_bits(out["x"][sel], ref["x"], "sample x")
         eq_bits(out["res"]["J_final"][sel], ref["res"]["J_final"], "sample J")
         eng.close()
+
+
+def test_helper_wavefront_mode_is_transparent(pkg, orc_det, engines):
+    """one wavefront per trajectory vs main + helper wavefront: identical results and traces
+    (barrier and ALM, one and two rows per lane)."""
+    for name, N, over in (("three_bend", 50, dict(use_last_solution=0)), ("two_straight", 100, dict(use_last_solution=0)),
+                          ("three_bend", 30, dict(use_last_solution=0, solve_type=1))):
+        eng, p, sc = engines(name, N, **over)
+        x0 = pkg.workloads.perturbed_starts(sc.ego_state, 48, 1234 + N)
+        eng.set_helper_mode(0)
+        a = eng.solve_batch(x0, trace_cap=128)
+        eng.set_helper_mode(1)
+        b = eng.solve_batch(x0, trace_cap=128)
+        eng.set_helper_mode(-1)
+        eq_bits(a["u"], b["u"], "helper u")
+        eq_bits(a["x"], b["x"], "helper x")
+        assert (a["res"] == b["res"]).all()
+        for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+            eq_bits(a["trace"][f], b["trace"][f], "helper trace." + f)
+        assert (a["res"]["ls_trials"] > a["res"]["iters"]).any()  # some multi-trial line searches were exercised

@@ -77,13 +77,23 @@ __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
 // CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
 // DBG = true compiles the testing-aid paths in (cilqr_set_debug_flags); the production
 // instantiation carries neither their code nor their registers.
-template <bool DBG, int NCH, bool ALM>
-__global__ void __launch_bounds__(CILQR_WAVE, CILQR_SOLVE_WAVES_PER_SIMD)
+// HELP = true: the block has a second wavefront that does nothing but cost every other trial of the
+// line search (slot 1) while the main wavefront costs the ones in between (slot 0); used when the
+// batch is too small to fill the chip with one wavefront per trajectory.  Control words in LDS:
+enum { CTL_MODE = 0, CTL_DONE = 1, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W = 5 };
+#define BLOCK_BAR()            \
+    do {                       \
+        if (HELP) __syncthreads(); \
+    } while (0)
+
+template <bool DBG, int NCH, bool ALM, bool HELP>
+__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : CILQR_SOLVE_WAVES_PER_SIMD)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
         cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (CILQR_WAVE - 1);
+    const int wave = HELP ? (threadIdx.x >> 6) : 0;
     if (b >= a.B) return;
     Cst c;
     load_cst(c, a, b);
@@ -92,11 +102,36 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     carve(l, g_lds, N, a.W, ALM ? 1 : 0);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
     AlmSt al = load_alm(a, b, N);
+    if (HELP && wave == 1) {
+        // ---- helper wavefront: costs trial 2p + 1 of every pass p, mirrors the main wave's control flow ----
+        __syncthreads(); // B0: window, ridx, x, u staged by the main wave
+        const int idx0h = l.ctli[CTL_IDX0];
+        l.w0 = l.ctli[CTL_W0];
+        l.W = l.ctli[CTL_W];
+        int nfb = 0;
+        for (int itr = 0; itr < c.max_iter; ++itr) {
+            __syncthreads(); // B1: K, d, trial slab of this iteration are ready (or the backward pass failed)
+            if (l.ctli[CTL_MODE]) {
+                if (ALM) al.rho = l.ctld[1];
+                for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2) {
+                    double J1[1];
+                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0 + 1, 1, lane, idx0h, a.flags, &nfb, J1, nullptr, 1);
+                    if (lane == 0) l.ctld[0] = J1[0];
+                    __syncthreads(); // B2
+                    __syncthreads(); // B3: the main wave has decided
+                    if (l.ctli[CTL_DONE]) break;
+                }
+            }
+            __syncthreads(); // B4
+            if (l.ctli[CTL_EXIT]) break;
+        }
+        return;
+    }
     if (ALM && last_u == nullptr) {
         // cs:88-93: fresh multipliers unless this call continues a previous solution
         al.rho = c.alm_rho_init;
         for (int e = lane; e < N * al.C; e += CILQR_WAVE) { al.mu[e] = 0.0; al.mu_next[e] = 0.0; }
-        __syncthreads();
+        wave_sync();
     }
 
     long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -108,6 +143,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     double J_cur = total_cost_lds<ALM>(c, l, al, lane);
     const double J_init = J_cur;
     PROF_ADD(PH_INIT);
+    if (HELP) {
+        if (lane == 0) { l.ctli[CTL_IDX0] = idx0; l.ctli[CTL_W0] = l.w0; l.ctli[CTL_W] = l.W; }
+        __syncthreads(); // B0
+    }
 
     double lamb = c.init_lamb;
     int status = CILQR_RUNNING;
@@ -127,24 +166,40 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         status = CILQR_RUNNING;
         double dV[2];
         bool ok = backward_sweep<(DBG && !ALM)>(c, l, lamb, lane, dV, a.flags);
-        __syncthreads();
+        wave_sync();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
         int trials = 0, alpha_idx = -1;
         if (!ok) {
             status = CILQR_BACKWARD_PASS_FAIL;
+            if (HELP) {
+                if (lane == 0) l.ctli[CTL_MODE] = 0;
+                __syncthreads(); // B1
+            }
         } else {
             flag = 0;
             rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
             PROF_ADD(PH_ROLLOUT);
+            if (HELP) {
+                if (lane == 0) { l.ctli[CTL_MODE] = 1; l.ctld[1] = al.rho; }
+                __syncthreads(); // B1
+            }
             bool done = false;
             // the line search of cs:354-372; the costs are produced pass by pass — alpha = 1 alone
             // (usually accepted), then CILQR_NT trials per pass — and consumed strictly in order
             for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
                 double Jp[CILQR_NT];
                 int nt = (t0 == 0) ? 1 : CILQR_NT;
+                if (HELP) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
                 if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
-                if (nt == 1) {
+                if (HELP) {
+                    double J1[1];
+                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
+                                                        a.prof ? &ph_acc[PH_TC_REF] : nullptr, 0);
+                    Jp[0] = J1[0];
+                    __syncthreads(); // B2
+                    Jp[1] = l.ctld[0];
+                } else if (nt == 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
                                                         a.prof ? &ph_acc[PH_TC_REF] : nullptr);
@@ -179,6 +234,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     }
                 }
                 t0 += nt;
+                if (HELP) {
+                    if (lane == 0) l.ctli[CTL_DONE] = (done || t0 >= CILQR_MAX_ALPHA_TRIALS) ? 1 : 0;
+                    __syncthreads(); // B3
+                }
             }
             if (!done) {
                 status = CILQR_FORWARD_PASS_FAIL;
@@ -186,7 +245,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     for (int e = lane; e < N * al.C; e += CILQR_WAVE) al.mu[e] = al.mu_next[e];
                     double r = (1 + c.alm_gamma) * al.rho;
                     al.rho = (c.max_rho < r) ? c.max_rho : r;
-                    __syncthreads();
+                    wave_sync();
                 }
             }
         }
@@ -207,8 +266,14 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             trace_out[(size_t)b * trace_cap + tl] = r;
         }
         tl++;
-        if (lamb > c.max_lamb) { end_reason = CILQR_END_MAX_LAMB; break; }
-        if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; break; }
+        bool leave = false;
+        if (lamb > c.max_lamb) { end_reason = CILQR_END_MAX_LAMB; leave = true; }
+        else if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; leave = true; }
+        if (HELP) {
+            if (lane == 0) l.ctli[CTL_EXIT] = (leave || itr + 1 >= c.max_iter) ? 1 : 0;
+            __syncthreads(); // B4
+        }
+        if (leave) break;
     }
     if (ALM) {
         J_cur = total_cost_lds<ALM>(c, l, al, lane); // J_final := get_total_cost(u_ret, x_ret) with the final multipliers
@@ -243,7 +308,7 @@ __device__ inline void stage_xu(const Lds& l, int N, const double* x, const doub
     for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) l.x[e] = x[e];
     if (u)
         for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.u[e] = u[e];
-    __syncthreads();
+    wave_sync();
 }
 
 __global__ void __launch_bounds__(CILQR_WAVE)
@@ -502,6 +567,8 @@ struct cilqr_handle {
     DevBuf prof;      // [B][8] int64, filled when profiling is on
     bool profiling = false;
     int debug_flags = 0;
+    int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
+    int helper_max_batch = 1024;
     int prof_B = 0;
     DevBuf st[16];
 };
@@ -622,6 +689,12 @@ extern "C" int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, doubl
 extern "C" int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     h->debug_flags = flags;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0 or 1");
+    h->helper_mode = mode;
     return CILQR_OK;
 }
 
@@ -863,12 +936,17 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     {
         const bool two = (a.N + 1 > CILQR_WAVE);
-        auto kern = k_solve<false, 1, false>;
-        if (a.alm) kern = two ? k_solve<true, 2, true> : k_solve<true, 1, true>;
-        else if (a.flags != 0) kern = two ? k_solve<true, 2, false> : k_solve<true, 1, false>;
-        else kern = two ? k_solve<false, 2, false> : k_solve<false, 1, false>;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out,
-                           d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+        // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
+        const bool help = (h->helper_mode == 1) || (h->helper_mode < 0 && B <= h->helper_max_batch);
+        auto kern = k_solve<false, 1, false, false>;
+        if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true> : k_solve<true, 1, true, true>)
+                                : (two ? k_solve<true, 2, true, false> : k_solve<true, 1, true, false>);
+        else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false> : k_solve<true, 1, false, false>;
+        else kern = help ? (two ? k_solve<false, 2, false, true> : k_solve<false, 1, false, true>)
+                         : (two ? k_solve<false, 2, false, false> : k_solve<false, 1, false, false>);
+        const bool helped = help && (a.alm || a.flags == 0);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
+                           d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) {

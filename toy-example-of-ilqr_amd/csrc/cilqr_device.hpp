@@ -32,6 +32,16 @@
 
 namespace cilqr {
 
+// Ordering point between the lanes of ONE wavefront that exchange data through LDS / the scratch
+// slab: the wave's outstanding memory operations complete and the compiler may not move accesses
+// across it.  No s_barrier: kernels may run more than one wavefront per block (helper waves), and a
+// block-wide barrier inside single-wave phases would deadlock.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // pointers into HBM are typed as address space 1 so that every access is a global_load (a generic
 // pointer would compile to flat_load, which also ties up the LDS counter)
 typedef const double __attribute__((address_space(1))) gdouble;
@@ -104,6 +114,8 @@ struct Lds {
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
     int* tidx;   // [CILQR_NT][(N+2)] the same for the trial trajectories being costed
+    int* ctli;   // [8]  control words shared by the main and the helper wavefront of a block
+    double* ctld; // [4]
     int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
     int W;
 };
@@ -119,10 +131,10 @@ struct Lds {
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
     return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + 5 * N +
-           3 * N + CILQR_XCH + CILQR_NT * 3 * (N + 1);
+           3 * N + CILQR_XCH + CILQR_NT * 3 * (N + 1) + 4;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
-    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2));
+    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
 }
 
 __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
@@ -140,9 +152,11 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.B3 = p; p += 3 * N;
     l.xch = p; p += CILQR_XCH;
     l.cs = p; p += CILQR_NT * 3 * (N + 1);
+    l.ctld = p; p += 4;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
     l.tidx = l.ridx + (N + 2);
+    l.ctli = l.tidx + CILQR_NT * (N + 2);
     l.w0 = 0;
     l.W = 0; // nothing staged yet: every lookup goes to global memory
 }
@@ -166,7 +180,7 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
     for (int e = lane; e < 2 * W; e += CILQR_WAVE) l.win[e] = c.lane_xy[2 * (size_t)w0 + e];
     l.w0 = w0;
     l.W = W;
-    __syncthreads();
+    wave_sync();
 }
 
 // scratch slab of the trial trajectories: [6][(N+1)][20 alphas] doubles, alpha fastest, so that the
@@ -482,11 +496,11 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
 // cs:217 accumulate.  All lanes compute the same value from LDS broadcasts.
 // NTR trials at once: lanes 3*tt + {0,1,2} take trial slot tt; J[tt] for every slot on every lane.
 template <int NTR>
-__device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, double J[NTR]) {
+__device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, double J[NTR], int slot0 = 0) {
     const int R = N + 1;
     const int slot = (lane < 3 * NTR) ? lane / 3 : 0;
     const int row = (lane < 3 * NTR) ? lane % 3 : 0;
-    const double* v = l.cs + (size_t)slot * 3 * R + row * R;
+    const double* v = l.cs + (size_t)(slot0 + slot) * 3 * R + row * R;
     const int last = (row == 1) ? N - 1 : N;
     double acc = (row == 2) ? 0.0 : v[0];
     int k = 1;
@@ -546,9 +560,9 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, const AlmSt&
         l.cs[(N + 1) + k] = ce;
         l.cs[2 * (N + 1) + k] = jb;
     }
-    __syncthreads();
+    wave_sync();
     double J = sum_stage_costs(l, N, lane);
-    __syncthreads();
+    wave_sync();
     return J;
 }
 
@@ -567,7 +581,7 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, const AlmSt&
 template <bool DBG, int NCH, bool ALM, int NTR>
 __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a0,
                                          int nt, int lane, int idx0, int flags_in, int* n_fallback, double J[NTR],
-                                         long long* sub = nullptr) {
+                                         long long* sub = nullptr, int slot0 = 0) {
     const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
@@ -613,7 +627,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
                     ok0 = ok0 && verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], l.ridx[k - 1], guess[ch]);
             }
             if (__ballot(!ok0) == 0ULL) {
-                int* tix = l.tidx + tt * (N + 2);
+                int* tix = l.tidx + (slot0 + tt) * (N + 2);
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
                     const int k = lane + CILQR_WAVE * ch;
@@ -630,7 +644,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
 #pragma unroll
             for (int tt = 0; tt < NTR; ++tt) {
                 if (proven[tt]) continue;
-                int* tix = l.tidx + tt * (N + 2);
+                int* tix = l.tidx + (slot0 + tt) * (N + 2);
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
                     const int k = lane + CILQR_WAVE * ch;
@@ -646,11 +660,11 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int tt = 0; tt < NTR; ++tt) {
                 if (proven[tt]) continue;
-                const int* tix = l.tidx + tt * (N + 2);
+                const int* tix = l.tidx + (slot0 + tt) * (N + 2);
                 bool ok = true;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
@@ -671,10 +685,10 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) {
         if (proven[tt]) continue;
-        __syncthreads();
+        wave_sync();
         *n_fallback += 1;
         const double* t = scr + a0 + tt;
-        int* tix = l.tidx + tt * (N + 2);
+        int* tix = l.tidx + (slot0 + tt) * (N + 2);
         int s = idx0;
         if (lane == 0) tix[0] = s;
         for (int i = 1; i <= N; ++i) {
@@ -682,13 +696,13 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
             if (lane == 0) tix[i] = s;
         }
     }
-    __syncthreads();
+    wave_sync();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) {
         if (tt >= nt) continue;
-        const int* tix = l.tidx + tt * (N + 2);
-        double* cs = l.cs + (size_t)tt * 3 * R;
+        const int* tix = l.tidx + (slot0 + tt) * (N + 2);
+        double* cs = l.cs + (size_t)(slot0 + tt) * 3 * R;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
@@ -701,10 +715,10 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[1] += t1 - t0; t0 = t1; }
-    sum_stage_costs_multi<NTR>(l, N, lane, J);
-    __syncthreads();
+    sum_stage_costs_multi<NTR>(l, N, lane, J, slot0);
+    wave_sync();
     if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[2] += t1 - t0; }
 }
 
@@ -734,7 +748,7 @@ __device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4],
         l.u[2 * k] = a;
         l.u[2 * k + 1] = b;
     }
-    __syncthreads();
+    wave_sync();
     idx0 = ref_scan_row0(c, x0[0], x0[1], lane);
     stage_window(c, l, idx0, Wcap, lane);
     double xc[4] = {x0[0], x0[1], x0[2], x0[3]};
@@ -756,7 +770,7 @@ __device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4],
         }
         xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ridx for a trajectory already staged in LDS x (used by the piecewise kernels)
@@ -770,7 +784,7 @@ __device__ inline void ref_indices_lds(const Cst& c, Lds& l, int lane, int& idx0
         s = ref_scan_from(c, l, l.x[4 * i], l.x[4 * i + 1], s);
         if (lane == 0) l.ridx[i] = s;
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -812,7 +826,7 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             Ki += 8; xi += 4; ui += 2; di += 2; tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
@@ -837,7 +851,7 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
             l.u[2 * k + 1] = TR(t, 5, k);
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1049,7 +1063,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1277,13 +1291,13 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         l.xch[CILQR_XCH_CONST + 2] = c.dt;
         l.xch[CILQR_XCH_CONST + 3] = 0.0;
     }
-    __syncthreads();
+    wave_sync();
     // W = [l_xx[N] | l_x[N]]
     if (is_w) {
         double v = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
         Wt[4 * cc + rp] = v;
     }
-    __syncthreads();
+    wave_sync();
     dV[0] = 0.0;
     dV[1] = 0.0;
     const int wc = (cc <= 4) ? cc : 4;
@@ -1310,14 +1324,14 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             if (cc < 4) Xs[4 * rp + cc] = X;
             if (cc == 4) qv[rp] = Zv;
         }
-        __syncthreads();
+        wave_sync();
         // pass 2
         const double x0 = Xs[4 * rp], x1 = Xs[4 * rp + 1], x2 = Xs[4 * rp + 2], x3 = Xs[4 * rp + 3];
         const double Y = ((x0 * m2[0] + x1 * m2[1]) + x2 * m2[2]) + x3 * m2[3];
         double Q = Lq + Y;
         if (diag) Q = Q + lamb;
         if (lane < 48 && cc < 6) Qs[8 * rp + cc] = Q;
-        __syncthreads();
+        wave_sync();
         // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
         const double Quu0 = Qs[8 * 4 + 4], Quu1 = Qs[8 * 4 + 5], Quu2 = Qs[8 * 5 + 4], Quu3 = Qs[8 * 5 + 5];
         const double Qu0 = qv[4], Qu1 = qv[5];
@@ -1363,7 +1377,7 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double g1 = hd0 * Quu1 + hd1 * Quu3;
         dV[0] += g0 * d0 + g1 * d1;
         dV[1] += d0 * Qu0 + d1 * Qu1;
-        __syncthreads();
+        wave_sync();
     }
     return true;
 }

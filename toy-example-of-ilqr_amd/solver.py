@@ -137,6 +137,10 @@ class BatchedCILQR:
         check(self._lib.cilqr_get_phase_cycles(self._h, _p(out), int(B)), "cilqr_get_phase_cycles")
         return out
 
+    def set_helper_mode(self, mode):
+        """-1 automatic, 0 one wavefront per trajectory, 1 main + helper wavefront"""
+        check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
+
     def set_debug_flags(self, flags):
         check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
