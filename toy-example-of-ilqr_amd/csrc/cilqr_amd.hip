@@ -57,10 +57,10 @@ __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
 // phase ids of the optional in-kernel cycle accounting
 #define CILQR_PROF_SLOTS 13
 enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12 };
-#define PROF_T0() long long t_ph_ = a.prof ? (long long)__builtin_readcyclecounter() : 0
+#define PROF_T0() long long t_ph_ = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0
 #define PROF_ADD(ph)                                                  \
     do {                                                              \
-        if (a.prof) {                                                 \
+        if (PROF && a.prof) {                                         \
             long long t_now_ = (long long)__builtin_readcyclecounter(); \
             ph_acc[ph] += t_now_ - t_ph_;                             \
             t_ph_ = t_now_;                                           \
@@ -86,7 +86,7 @@ enum { CTL_MODE = 0, CTL_DONE = 1, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W
         if (HELP) __syncthreads(); \
     } while (0)
 
-template <bool DBG, int NCH, bool ALM, bool HELP>
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : CILQR_SOLVE_WAVES_PER_SIMD)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -135,7 +135,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     }
 
     long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const long long t_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
@@ -195,18 +195,18 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 if (HELP) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                        a.prof ? &ph_acc[PH_TC_REF] : nullptr, 0);
+                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0);
                     Jp[0] = J1[0];
                     __syncthreads(); // B2
                     Jp[1] = l.ctld[0];
                 } else if (nt == 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                        a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                     Jp[0] = J1[0];
                 } else {
                     total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, scr, t0, nt, lane, idx0, a.flags, &n_fallback,
-                                                               Jp, a.prof ? &ph_acc[PH_TC_REF] : nullptr);
+                                                               Jp, (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                 }
                 PROF_ADD(PH_TRIAL_COST);
                 for (int tt = 0; tt < nt && !done; ++tt) {
@@ -288,7 +288,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             uo[0] = l.u[2 * k]; uo[1] = l.u[2 * k + 1];
         }
     }
-    if (a.prof && lane == 0) {
+    if (PROF && a.prof && lane == 0) {
         ph_acc[PH_TOTAL] = (long long)__builtin_readcyclecounter() - t_begin;
         ph_acc[PH_ITERS] = iters;
         ph_acc[PH_REF_FALLBACKS] = n_fallback;
@@ -938,12 +938,14 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool two = (a.N + 1 > CILQR_WAVE);
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
         const bool help = (h->helper_mode == 1) || (h->helper_mode < 0 && B <= h->helper_max_batch);
-        auto kern = k_solve<false, 1, false, false>;
-        if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true> : k_solve<true, 1, true, true>)
-                                : (two ? k_solve<true, 2, true, false> : k_solve<true, 1, true, false>);
-        else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false> : k_solve<true, 1, false, false>;
-        else kern = help ? (two ? k_solve<false, 2, false, true> : k_solve<false, 1, false, true>)
-                         : (two ? k_solve<false, 2, false, false> : k_solve<false, 1, false, false>);
+        auto kern = k_solve<false, 1, false, false, false>;
+        if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>)
+                                : (two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>);
+        else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
+        else if (a.prof) kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
+                                     : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
+        else kern = help ? (two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>)
+                         : (two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>);
         const bool helped = help && (a.alm || a.flags == 0);
         hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);

@@ -26,6 +26,7 @@
 #include "detmath.h"
 
 #define CILQR_WAVE 64
+#define CILQR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define CILQR_EPS 1e-5 /* include/utils.hpp:28 */
 #define CILQR_DBG_SERIAL_REF_SCAN 1 /* cilqr_set_debug_flags: always take the serial reference-point chain */
 #define CILQR_DBG_UNIFORM_BACKWARD 2 /* use the wave-uniform backward sweep instead of the lane-parallel one */
@@ -468,12 +469,19 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
             j = j + alm_item(pos_lo, al.rho, mu[7]);
         } else {
             j = c.sq1 * dm_exp(c.sq2 * acc_up) + c.sq1 * dm_exp(c.sq2 * acc_lo);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * stl_up);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * stl_lo);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * vel_up);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * vel_lo);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * pos_up);
+            CILQR_SCHED_FENCE();
             j = j + c.sq1 * dm_exp(c.sq2 * pos_lo);
+            CILQR_SCHED_FENCE();
         }
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
@@ -952,10 +960,16 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
         if (!ALM && k >= 1) {
             double um0 = l.u[2 * k - 2], um1 = l.u[2 * k - 1];
             // control bounds (cs:510-513, 537-558)
+            // (the scheduling fences keep the eight independent exp chains from being interleaved: that
+            //  would only raise the register count — the wave is issue-bound, not latency-bound, here)
             double b_au = c.sq1 * dm_exp(c.sq2 * (um0 - c.acc_max));
+            CILQR_SCHED_FENCE();
             double b_al = c.sq1 * dm_exp(c.sq2 * (c.acc_min - um0));
+            CILQR_SCHED_FENCE();
             double b_su = c.sq1 * dm_exp(c.sq2 * (um1 - c.stl_lim));
+            CILQR_SCHED_FENCE();
             double b_sl = c.sq1 * dm_exp(c.sq2 * (-c.stl_lim - um1));
+            CILQR_SCHED_FENCE();
             double q22 = c.sq2 * c.sq2;
             double lub0 = (c.sq2 * b_au) - (c.sq2 * b_al);
             double lub1 = (c.sq2 * b_su) - (c.sq2 * b_sl);
@@ -968,12 +982,16 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             l.luu[2 * (k - 1) + 1] = 2 * c.w_stl + luub1;
             // velocity bounds and road borders (cs:507-533, 560-580)
             double b_vu = c.sq1 * dm_exp(c.sq2 * (xk[2] - c.velo_max));
+            CILQR_SCHED_FENCE();
             double b_vl = c.sq1 * dm_exp(c.sq2 * (c.velo_min - xk[2]));
+            CILQR_SCHED_FENCE();
             double d_sign = e1 * cr - e0 * sr;
             double hyp = dm_hypot(e0, e1);
             double cur_d = (d_sign < 0) ? -hyp : hyp;
             double b_pu = c.sq1 * dm_exp(c.sq2 * (cur_d - c.pos_up_b));
+            CILQR_SCHED_FENCE();
             double b_pl = c.sq1 * dm_exp(c.sq2 * (c.pos_lo_b - cur_d));
+            CILQR_SCHED_FENCE();
             double px = e0 / hyp, py = e1 / hyp;
             if (d_sign < 0) { px = -px; py = -py; }
             double nx = -px, ny = -py; // pos_lo_constr_over_x = -1 * pos_up_constr_over_x
@@ -993,7 +1011,9 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
                 ObsOut t;
                 obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
                 double bf = c.oq1 * dm_exp(c.oq2 * t.mf);
+                CILQR_SCHED_FENCE();
                 double br = c.oq1 * dm_exp(c.oq2 * t.mr);
+                CILQR_SCHED_FENCE();
                 double df = c.oq2 * bf, dr = c.oq2 * br;
                 double sf = oq22 * bf, srr = oq22 * br;
                 b0 = b0 + (df * t.gf[0] + dr * t.gr[0]);
@@ -1274,14 +1294,39 @@ __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
     else { m.lv = (int)(l.lu - l.x) + (rp - 4); m.slv = 2; }
 }
 
+// ---- cross-lane moves of a double (two 32-bit halves) -------------------------------------------
+template <int CTRL>
+__device__ inline double dpp_move(double v) {
+    const unsigned long long u = dm_to_bits(v);
+    int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// value of lane `src` (any lane of the wave, per-lane choice): ds_bpermute, no LDS memory involved
+__device__ inline double lane_gather(double v, int src) {
+    const unsigned long long u = dm_to_bits(v);
+    int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+    lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+    return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// value of a lane known at compile time, delivered wave-uniformly (v_readlane -> SGPR)
+template <int SRC>
+__device__ inline double lane_bcast(double v) {
+    const unsigned long long u = dm_to_bits(v);
+    int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+    lo = __builtin_amdgcn_readlane(lo, SRC);
+    hi = __builtin_amdgcn_readlane(hi, SRC);
+    return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+// The operands that pass 2 and the rank-2 update need live in other lanes' registers; they are moved
+// with DPP (inside the 8-lane row of the grid), ds_bpermute (across rows) and v_readlane (the 2x2
+// Q_uu and Q_u, needed by every lane) — no LDS round trips inside a step.
 __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
     const int N = c.N;
     const int rp = (lane >> 3) % 6, cc = lane & 7;
-    const bool is_w = (lane < 32) && (cc <= 4);             // owns W'[r][c], r = rp < 4
-    double* const Wt = l.xch + CILQR_XCH_WT;
-    double* const Xs = l.xch + CILQR_XCH_X;
-    double* const Qs = l.xch + CILQR_XCH_Q;
-    double* const qv = l.xch + CILQR_XCH_QV;
     const double* const base = l.x;
     LaneMap mp;
     make_lane_map(l, lane, mp);
@@ -1292,20 +1337,15 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         l.xch[CILQR_XCH_CONST + 3] = 0.0;
     }
     wave_sync();
-    // W = [l_xx[N] | l_x[N]]
-    if (is_w) {
-        double v = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
-        Wt[4 * cc + rp] = v;
-    }
-    wave_sync();
+    // W = [l_xx[N] | l_x[N]], element (r, c) in the register `wn` of lane 8 r + c (r < 4, c <= 4)
+    double wn = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
     dV[0] = 0.0;
     dV[1] = 0.0;
     const int wc = (cc <= 4) ? cc : 4;
     const bool diag = (rp >= 4) && (cc == rp);
-    // addresses of the c-version / r-version operands of the rank-2 update
-    const int qc0 = (cc < 4) ? (CILQR_XCH_Q + 8 * 4 + cc) : (CILQR_XCH_QV + 4);
-    const int qc1 = (cc < 4) ? (CILQR_XCH_Q + 8 * 5 + cc) : (CILQR_XCH_QV + 5);
     const int r4 = rp & 3;
+    const int src_c0 = 32 + wc, src_c1 = 40 + wc;   // (Q_ux | Q_u)[0][c], [1][c]
+    const int src_r0 = 32 + r4, src_r1 = 40 + r4;   // Q_ux[0][r], [1][r]
     for (int i = N - 1; i >= 0; --i) {
         // per-lane coefficients of this step
         double m1[4], m2[4];
@@ -1316,27 +1356,27 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         }
         const double Lq = base[mp.lq + mp.slq * i];
         const double lv = base[mp.lv + mp.slv * i];
-        // pass 1
-        const double w0 = Wt[4 * wc], w1 = Wt[4 * wc + 1], w2 = Wt[4 * wc + 2], w3 = Wt[4 * wc + 3];
+        // pass 1: column wc of W from the lanes 8 k + wc
+        const double w0 = lane_gather(wn, wc), w1 = lane_gather(wn, 8 + wc);
+        const double w2 = lane_gather(wn, 16 + wc), w3 = lane_gather(wn, 24 + wc);
         const double X = ((m1[0] * w0 + m1[1] * w1) + m1[2] * w2) + m1[3] * w3;
         const double Zv = lv + X; // (Q_x, Q_u) on the lanes of column 4
-        if (lane < 48) {
-            if (cc < 4) Xs[4 * rp + cc] = X;
-            if (cc == 4) qv[rp] = Zv;
-        }
-        wave_sync();
-        // pass 2
-        const double x0 = Xs[4 * rp], x1 = Xs[4 * rp + 1], x2 = Xs[4 * rp + 2], x3 = Xs[4 * rp + 3];
+        // pass 2: row r' of X[:, 0:4] sits in lanes 8 r' + 0..3; bring it to both quads of the row, then
+        // broadcast inside each quad
+        const double Xsh = dpp_move<0x114>(X);            // row_shr:4
+        const double Xq = (cc < 4) ? X : Xsh;
+        const double x0 = dpp_move<0x00>(Xq), x1 = dpp_move<0x55>(Xq);
+        const double x2 = dpp_move<0xAA>(Xq), x3 = dpp_move<0xFF>(Xq);
         const double Y = ((x0 * m2[0] + x1 * m2[1]) + x2 * m2[2]) + x3 * m2[3];
         double Q = Lq + Y;
         if (diag) Q = Q + lamb;
-        if (lane < 48 && cc < 6) Qs[8 * rp + cc] = Q;
-        wave_sync();
         // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
-        const double Quu0 = Qs[8 * 4 + 4], Quu1 = Qs[8 * 4 + 5], Quu2 = Qs[8 * 5 + 4], Quu3 = Qs[8 * 5 + 5];
-        const double Qu0 = qv[4], Qu1 = qv[5];
-        const double c0 = l.xch[qc0], c1 = l.xch[qc1];                 // (Q_ux | Q_u)[:, c]
-        const double r0 = Qs[8 * 4 + r4], r1 = Qs[8 * 5 + r4];         // Q_ux[:, r]
+        const double Quu0 = lane_bcast<36>(Q), Quu1 = lane_bcast<37>(Q);
+        const double Quu2 = lane_bcast<44>(Q), Quu3 = lane_bcast<45>(Q);
+        const double Qu0 = lane_bcast<36>(Zv), Qu1 = lane_bcast<44>(Zv);
+        const double S = (cc == 4) ? Zv : Q;               // rows 4-5: (Q_ux | Q_u)
+        const double c0 = lane_gather(S, src_c0), c1 = lane_gather(S, src_c1);
+        const double r0 = lane_gather(S, src_r0), r1 = lane_gather(S, src_r1);
         bool fail = false;
         if (Quu0 <= 0.0) {
             fail = true;
@@ -1360,8 +1400,7 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double tb = kr0 * c0 + kr1 * c1;
         const double tc = r0 * kc0 + r1 * kc1;
         const double own = (cc < 4) ? Q : Zv;
-        const double wn = ((own + ta) + tb) + tc;
-        if (is_w) Wt[4 * cc + rp] = wn;
+        wn = ((own + ta) + tb) + tc;
         if (lane < 5) { // row r' = 0 holds (K | d) column c
             if (lane < 4) {
                 l.K[8 * i + lane] = kc0;
@@ -1377,8 +1416,8 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double g1 = hd0 * Quu1 + hd1 * Quu3;
         dV[0] += g0 * d0 + g1 * d1;
         dV[1] += d0 * Qu0 + d1 * Qu1;
-        wave_sync();
     }
+    wave_sync();
     return true;
 }
 
