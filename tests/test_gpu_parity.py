@@ -155,7 +155,8 @@ def compare_solves(out, ref_list, what):
         eq_bits(out["x"][b], r["x"], f"{what} x[{b}]")
         res, rr = out["res"][b], r["res"]
         for f in ("J_init", "J_final", "iters", "end_reason", "final_status", "ls_trials", "cost_evals"):
-            assert res[f] == rr[f], (what, b, f, res[f], rr[f])
+            same = (res[f] == rr[f]) or (np.isnan(res[f]) and np.isnan(rr[f]))
+            assert same, (what, b, f, res[f], rr[f])
         tr, rt = out["trace"][b][:res["trace_len"]], r["trace"]
         assert len(tr) == len(rt)
         for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
@@ -505,3 +506,58 @@ def test_helper_wavefront_mode_is_transparent(pkg, orc_det, engines):
         for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
             eq_bits(a["trace"][f], b["trace"][f], "helper trace." + f)
         assert (a["res"]["ls_trials"] > a["res"]["iters"]).any()  # some multi-trial line searches were exercised
+
+
+# ---- edge cases ----------------------------------------------------------------------------------
+def solve_both(pkg, orc_det, p, scene_tab, x0, **kw):
+    from oracle import Scene
+    eng = pkg.BatchedCILQR(p, scene_tab)
+    out = eng.solve_batch(x0, trace_cap=128, **kw)
+    scene = Scene(scene_tab.lane_x, scene_tab.lane_y, scene_tab.lane_yaw, scene_tab.obs if scene_tab.obs.shape[0] else None,
+                  scene_tab.road_borders, scene_tab.ref_velo)
+    refs = [orc_det.solver(p).solve(x, scene) for x in x0]
+    eng.close()
+    return out, refs
+
+
+def test_edge_no_obstacles_short_horizon_tiny_lane(pkg, orc_det, scenarios):
+    cfg, sc = scenarios["two_straight"]
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 8, 31)
+    # no obstacles at all (M = 0), barrier and alm
+    for st in (0, 1):
+        p = pkg.params_from_config(cfg, N=30, solve_type=st)
+        tab = pkg.SceneTable(sc.lane.x, sc.lane.y, sc.lane.yaw, None, sc.road_borders, sc.target_velocity)
+        out, refs = solve_both(pkg, orc_det, p, tab, x0)
+        compare_solves(out, refs, f"M=0 st={st}")
+    # minimal horizon
+    p = pkg.params_from_config(cfg, N=2)
+    out, refs = solve_both(pkg, orc_det, p, pkg.SceneTable.from_scenario(sc), x0)
+    compare_solves(out, refs, "N=2")
+    # a lane table with 1 and with 3 samples, and one that ends inside the horizon
+    for L in (1, 3, 150):
+        tab = pkg.SceneTable(sc.lane.x[:L], sc.lane.y[:L], sc.lane.yaw[:L], sc.obstacles, sc.road_borders, sc.target_velocity)
+        p = pkg.params_from_config(cfg, N=30)
+        out, refs = solve_both(pkg, orc_det, p, tab, x0[:4])
+        compare_solves(out, refs, f"L={L}")
+    # max_iter = 0: the initial trajectory comes back
+    p = pkg.params_from_config(cfg, N=30, max_iter=0)
+    out, refs = solve_both(pkg, orc_det, p, pkg.SceneTable.from_scenario(sc), x0[:4])
+    compare_solves(out, refs, "max_iter=0")
+    assert (out["res"]["iters"] == 0).all() and np.array_equal(out["res"]["J_init"], out["res"]["J_final"])
+    np.testing.assert_array_equal(out["u"], 0.0)
+
+
+def test_edge_start_on_the_reference_line_and_wild_states(pkg, orc_det, scenarios):
+    """hypot == 0 on the lane gives a NaN road-border gradient upstream (cs:527-529, SURVEY quirk 9);
+    huge / non-finite starts must not hang and must match the oracle's non-finite pattern."""
+    cfg, sc = scenarios["two_straight"]
+    p = pkg.params_from_config(cfg, N=30)
+    tab = pkg.SceneTable.from_scenario(sc)
+    j = 117
+    x0 = np.array([[sc.lane.x[j], sc.lane.y[j], 0.0, 0.0],      # exactly on a sample, standing still: every row has hypot == 0
+                   [1e7, 3.0, 5.0, 0.1],                          # far beyond the lane table
+                   [0.0, 0.0, 1e6, 0.0],                          # absurd speed
+                   [0.0, 0.5, 8.0, np.nan]])                      # NaN yaw
+    out, refs = solve_both(pkg, orc_det, p, tab, x0)
+    compare_solves(out, refs, "degenerate starts")
+    assert np.isnan(out["res"]["J_final"][3])
