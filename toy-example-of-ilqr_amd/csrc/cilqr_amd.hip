@@ -6,6 +6,7 @@
 // every stage can be compared with the oracle in isolation.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -86,8 +87,10 @@ enum { CTL_MODE = 0, CTL_DONE = 1, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W
         if (HELP) __syncthreads(); \
     } while (0)
 
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF>
-__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : CILQR_SOLVE_WAVES_PER_SIMD)
+// WPS = waves per SIMD the register allocation must allow (2 for big batches: more resident
+// trajectories at the price of a few spills)
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1>
+__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
         cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
@@ -569,6 +572,7 @@ struct cilqr_handle {
     int debug_flags = 0;
     int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
     int helper_max_batch = 1024;
+    int occ2_min_batch = 4096; // above this the 2-waves-per-SIMD build of the solve kernel is used
     int prof_B = 0;
     DevBuf st[16];
 };
@@ -577,15 +581,29 @@ struct cilqr_handle {
 // still correct — lookups outside the window read global memory), a multiple of 64, <= 1024.
 static void update_window(cilqr_handle* h) {
     if (h->params.empty() || h->scene_spacing.empty()) return;
-    double need = 128;
+    // samples the horizon covers at the target speed
+    double base = 32;
     for (const auto& p : h->params)
         for (size_t i = 0; i < h->scene_spacing.size(); ++i) {
             double ds = h->scene_spacing[i] > 1e-6 ? h->scene_spacing[i] : 0.1;
-            double n = p.N * p.dt * h->scene_velo[i] / ds * 1.5 + 64;
-            if (n > need) need = n;
+            double n = p.N * p.dt * h->scene_velo[i] / ds;
+            if (n > base) base = n;
         }
-    int w = ((int)need + 63) / 64 * 64;
-    h->win = w > 1024 ? 1024 : w;
+    const int want = std::min(1024, ((int)(base * 1.5 + 64) + 63) / 64 * 64); // generous
+    const int floor_ok = std::min(want, ((int)(base * 1.2 + 32) + 63) / 64 * 64); // still comfortable
+    // prefer a window that lets one more block fit into the CU's 160 KiB of LDS, as long as it stays
+    // comfortable (anything outside the window is still read correctly, from global memory)
+    const int N = h->params[0].N;
+    const int alm = h->params[0].solve_type == 1 ? 1 : 0;
+    const size_t fixed = lds_bytes(N, 0, alm);
+    int best = want;
+    for (int k = 8; k >= 1; --k) {
+        const long budget = (long)(163840 / k) - (long)fixed;
+        if (budget <= 0) continue;
+        int wk = (int)(budget / 16) / 64 * 64;
+        if (wk >= floor_ok) { best = std::min(want, wk); break; }
+    }
+    h->win = best;
 }
 
 static int check_ready(cilqr_handle* h) {
@@ -944,8 +962,9 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
         else if (a.prof) kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
                                      : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
-        else kern = help ? (two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>)
-                         : (two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>);
+        else if (help) kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
+        else if (B > h->occ2_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2> : k_solve<false, 1, false, false, false, 2>;
+        else kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         const bool helped = help && (a.alm || a.flags == 0);
         hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);

@@ -110,8 +110,9 @@ struct Lds {
     double* luu; // [N][2]
     double* A5;  // [N][5]  a02 a03 a12 a13 a32
     double* B3;  // [N][3]  b01 b11 b31
-    double* xch; // [CILQR_XCH] exchange buffers of the lane-parallel backward sweep (see backward_sweep_lanes)
-    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier
+    double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
+    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier.  ALIASES K and d: the gains
+                 // are dead once the rollout has produced the trial trajectories, and costs are only summed then
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
     int* tidx;   // [CILQR_NT][(N+2)] the same for the trial trajectories being costed
@@ -121,18 +122,14 @@ struct Lds {
     int W;
 };
 
-// exchange area of the lane-parallel backward sweep: Wt[5][4] X[6][4] Q[6][8] qv[8] const[4]
-#define CILQR_XCH_WT 0
-#define CILQR_XCH_X 20
-#define CILQR_XCH_Q 44
-#define CILQR_XCH_QV 92
-#define CILQR_XCH_CONST 100
-#define CILQR_XCH 104
+// constants the backward sweep's per-lane address maps point at: 0.0, 1.0, dt, 0.0
+#define CILQR_XCH_CONST 0
+#define CILQR_XCH 4
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
     return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + 5 * N +
-           3 * N + CILQR_XCH + CILQR_NT * 3 * (N + 1) + 4;
+           3 * N + CILQR_XCH + 4;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
     return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
@@ -152,7 +149,7 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.A5 = p; p += 5 * N;
     l.B3 = p; p += 3 * N;
     l.xch = p; p += CILQR_XCH;
-    l.cs = p; p += CILQR_NT * 3 * (N + 1);
+    l.cs = l.K; // 10 N doubles (K and d) >= CILQR_NT * 3 * (N + 1) for every N >= 2
     l.ctld = p; p += 4;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
