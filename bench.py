@@ -56,6 +56,27 @@ def make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank, world):
     return wl.config5(B_base=Bb, N=horizon or 50, first=rank * Bb), Bb * 16
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask and cgroup CPU quota both count
+    (the GPU box exposes 256 hardware threads but the container is capped by cpu.max)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    note = None
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                note = f"cgroup cpu.max = {quota} {period} caps the container at {q} of {n} hardware threads"
+                n = q
+    except Exception:
+        pass
+    return n, note
+
+
 def cpu_baseline(pkg, wl, threads):
     """The oracle (CPU restatement of the reference path, glibc libm build, -O3 -ffp-contract=off)
     timed on this box's host cores on a bounded sample of the same workload."""
@@ -188,8 +209,11 @@ def main():
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5])},
         }
         if not args.no_cpu_baseline:
-            threads = args.cpu_threads or (os.cpu_count() or 1)
+            cores, cores_note = usable_cores()
+            threads = args.cpu_threads or cores
             cb, r = cpu_baseline(pkg, wl, threads)
+            if cores_note:
+                cb["cores_note"] = cores_note
             out["cpu_baseline"] = cb
             # parity of the run that was just timed (the oracle is only the checker here)
             nb = r["res"].shape[0]
