@@ -1,24 +1,25 @@
 // cilqr_device.hpp — gfx950 device code of the batched CILQR solve path.
 //
-// Mapping (one wavefront = one trajectory, block = 64 threads, FP64 throughout, no MFMA):
+// Mapping (one wavefront = one trajectory, FP64 throughout, no MFMA):
 //   * phases that are parallel over the horizon (stage cost, cost gradients/Hessians, model
-//     Jacobians) run with lane = time step k;
+//     Jacobians, reference-point search + proof) run with lane = time step k;
 //   * the line search runs with lane = trial step size: lane a rolls the closed-loop dynamics out
 //     with alpha = 2^-a, so all 20 trial trajectories of cs:354 cost one pass of the serial
 //     instruction stream; the trial costs are then evaluated (lane = k again) in the reference's
 //     order until the first trial that the reference would have accepted;
-//   * the backward Riccati-like sweep is serial over the horizon and is computed wave-uniformly
-//     from LDS-resident stage data, exploiting the sparsity of df/dx = I + 5 entries and df/du
-//     (3 entries + dt);
-//   * x, u, K, d, l_*, A, B live in LDS; the 20 trial trajectories live in an L2-resident scratch
-//     slab; lane table / obstacle routes are read through L1/L2 (they are shared by the batch).
+//   * the backward Riccati-like sweep is serial over the horizon; inside a step lane = matrix
+//     element of a 6x8 grid, operands move between lanes with DPP / ds_bpermute / v_readlane
+//     (backward_sweep_lanes); a wave-uniform form (backward_sweep_uniform) is kept as a testing aid;
+//   * x, u, K, d, l_*, A, B and a window of the lane table live in LDS; the 20 trial trajectories
+//     live in an L2-resident scratch slab; obstacle routes are read through L1/L2 (shared by the batch).
 //
 // Arithmetic contract: every value is computed with the same IEEE operations in the same order
-// as oracle/cilqr_oracle.c (which restates the reference's Eigen expressions), with structural
-// zeros dropped (x + 0*y == x) — so results are bit-identical to the oracle's detmath build.
-// Compile with -ffp-contract=off.
+// as oracle/cilqr_oracle.c (which restates the reference's Eigen expressions); where structural
+// zeros are dropped (x + 0*y == x) the value is unchanged for finite data — so results are
+// bit-identical to the oracle's detmath build.  Compile with -ffp-contract=off.
 //
-// Reference citations: "cs:" = /root/reference/src/cilqr_solver.cpp, "ut:" = /root/reference/src/utils.cpp.
+// Reference citations: "cs:" = /root/reference/src/cilqr_solver.cpp, "ut:" = /root/reference/src/utils.cpp,
+// "hpp:" = /root/reference/include/cilqr_solver.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -27,7 +28,6 @@
 
 #define CILQR_WAVE 64
 #define CILQR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define CILQR_EPS 1e-5 /* include/utils.hpp:28 */
 #define CILQR_DBG_SERIAL_REF_SCAN 1 /* cilqr_set_debug_flags: always take the serial reference-point chain */
 #define CILQR_DBG_UNIFORM_BACKWARD 2 /* use the wave-uniform backward sweep instead of the lane-parallel one */
 
@@ -498,8 +498,9 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
 }
 
 // J = (sum_k sd + sum_k ce) + sum_k jb, each sum sequential in k as Eigen's trace()/the loop at
-// cs:217 accumulate.  All lanes compute the same value from LDS broadcasts.
-// NTR trials at once: lanes 3*tt + {0,1,2} take trial slot tt; J[tt] for every slot on every lane.
+// cs:217 accumulate: three lanes per trial slot each run one of the three chains over its own row
+// of l.cs (one instruction stream), then every lane combines them.  NTR trial slots at once: lanes
+// 3*tt + {0,1,2} take slot tt; J[tt] for every slot on every lane.
 template <int NTR>
 __device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, double J[NTR], int slot0 = 0) {
     const int R = N + 1;
@@ -527,27 +528,9 @@ __device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, doub
 }
 
 __device__ inline double sum_stage_costs(const Lds& l, int N, int lane) {
-    // lanes 0, 1, 2 each run one of the three sequential sums (state, control, barrier) over its own
-    // row of l.cs; one instruction stream, three chains.  Then J = (sd + ce) + jb on every lane.
-    const int R = N + 1;
-    const int row = (lane < 3) ? lane : 0;
-    const double* v = l.cs + row * R;
-    const int last = (row == 1) ? N - 1 : N;   // ctrl_energy has N terms
-    // state / control sums start from their k = 0 term, the barrier sum from 0.0 + J_barrier_1
-    double acc = (row == 2) ? 0.0 : v[0];
-    int k = 1;
-    for (; k + 7 <= last; k += 8) {
-        double a[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) a[t] = v[k + t];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc = acc + a[t];
-    }
-    for (; k <= last; ++k) acc = acc + v[k];
-    double sd = __shfl(acc, 0, CILQR_WAVE);
-    double ce = __shfl(acc, 1, CILQR_WAVE);
-    double jb = __shfl(acc, 2, CILQR_WAVE);
-    return (sd + ce) + jb;
+    double J[1];
+    sum_stage_costs_multi<1>(l, N, lane, J);
+    return J[0];
 }
 
 // get_total_cost of the trajectory held in LDS (x, u, ridx)
