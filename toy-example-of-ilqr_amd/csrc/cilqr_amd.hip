@@ -572,7 +572,7 @@ struct cilqr_handle {
     int debug_flags = 0;
     int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
     int helper_max_batch = 1024;
-    int occ2_min_batch = 4096; // above this the 2-waves-per-SIMD build of the solve kernel is used
+    int occ2_min_batch = 1024; // above this the 2-waves-per-SIMD build of the solve kernel is used
     int prof_B = 0;
     DevBuf st[16];
 };
