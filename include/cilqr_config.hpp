@@ -18,13 +18,19 @@ namespace cilqr_amd {
 
 class FlatConfig {
   public:
+    // .json: the flattened files under scenarios/;  .yaml / .yml: the reference's own layout
+    // (/root/reference/config/scenario_*.yaml — nested maps by indentation, scalars, inline lists,
+    // "- [..]" list items, '#' comments), flattened to the same "section/key" names with the
+    // defaults of global_config.cpp applied.
     static FlatConfig load(const std::string& path) {
         std::ifstream f(path);
         if (!f) throw std::runtime_error("cannot open " + path);
         std::stringstream ss;
         ss << f.rdbuf();
         FlatConfig c;
-        c.parse(ss.str());
+        const bool yaml = path.size() > 4 && (path.rfind(".yaml") == path.size() - 5 || path.rfind(".yml") == path.size() - 4);
+        if (yaml) c.parse_yaml(ss.str());
+        else c.parse(ss.str());
         return c;
     }
 
@@ -86,6 +92,71 @@ class FlatConfig {
             skip_ws(s, i);
             if (s[i] == ',') ++i;
         }
+    }
+    static std::string trim(const std::string& t) {
+        size_t a = 0, b = t.size();
+        while (a < b && std::isspace(static_cast<unsigned char>(t[a]))) ++a;
+        while (b > a && std::isspace(static_cast<unsigned char>(t[b - 1]))) --b;
+        return t.substr(a, b - a);
+    }
+    static std::string strip_comment(const std::string& line) {
+        bool in_str = false;
+        for (size_t i = 0; i < line.size(); ++i) {
+            if (line[i] == '"') in_str = !in_str;
+            if (line[i] == '#' && !in_str) return line.substr(0, i);
+        }
+        return line;
+    }
+    void parse_yaml(const std::string& text) {
+        std::vector<std::pair<int, std::string>> stack;  // (indent, key) of the open maps
+        std::string list_key;                             // key whose value is a block list of "- [..]" items
+        std::string list_val;
+        auto flush_list = [&]() {
+            if (!list_key.empty()) raw_[list_key] = "[" + list_val + "]";
+            list_key.clear();
+            list_val.clear();
+        };
+        std::istringstream in(text);
+        std::string line;
+        while (std::getline(in, line)) {
+            line = strip_comment(line);
+            if (trim(line).empty()) continue;
+            int indent = 0;
+            while (indent < static_cast<int>(line.size()) && line[indent] == ' ') ++indent;
+            std::string body = trim(line);
+            if (body[0] == '-') {  // list item of the innermost open key
+                if (!list_key.empty()) list_val += (list_val.empty() ? "" : ", ") + trim(body.substr(1));
+                continue;
+            }
+            flush_list();
+            const size_t colon = body.find(':');
+            if (colon == std::string::npos) continue;
+            const std::string key = trim(body.substr(0, colon));
+            const std::string val = trim(body.substr(colon + 1));
+            while (!stack.empty() && stack.back().first >= indent) stack.pop_back();
+            std::string full;
+            for (const auto& e : stack) full += e.second + "/";
+            full += key;
+            if (val.empty()) {
+                stack.emplace_back(indent, key);
+                list_key = full;  // becomes a list if "- " items follow, a map otherwise
+            } else {
+                raw_[full] = val;
+            }
+        }
+        flush_list();
+        // maps that turned out not to be lists leave an empty "[]" entry behind: drop those
+        for (auto it = raw_.begin(); it != raw_.end();) {
+            if (it->second == "[]") it = raw_.erase(it);
+            else ++it;
+        }
+        // defaults of src/global_config.cpp (.as<T>(default) call sites)
+        const std::pair<const char*, const char*> defaults[] = {
+            {"lqr/alm_rho_init", "1.0"}, {"lqr/alm_gamma", "0.0"}, {"lqr/max_rho", "100.0"}, {"lqr/max_mu", "1000.0"},
+            {"vehicle/reference_point", "\"gravity_center\""}, {"visualization/show_reference_line", "false"},
+            {"visualization/show_obstacle_boundary", "false"}};
+        for (const auto& d : defaults)
+            if (!raw_.count(d.first)) raw_[d.first] = d.second;
     }
     static std::vector<double> numbers(const std::string& v) {
         std::vector<double> out;

@@ -98,3 +98,69 @@ def test_cpp_host_driver_builds_against_the_cabi(pkg):
     build = importlib.import_module("toy-example-of-ilqr_amd.build")
     exe = build.build_examples()
     assert exe.exists()
+
+
+def test_cpp_config_reader_yaml_matches_json(pkg, tmp_path):
+    """include/cilqr_config.hpp reads the reference's YAML layout and the flattened JSON to the same
+    values (checked through a tiny C++ program; the YAML is re-created from our scenario data)."""
+    import json, subprocess, yaml
+    flat = json.loads((pkg.config.SCENARIO_DIR / "three_bend.json").read_text())
+    nested = {"max_simulation_time": flat["max_simulation_time"], "delta_t": flat["delta_t"], "lqr": {}, "iteration": {},
+              "vehicle": {}, "laneline": {"reference": {}}, "visualization": {}}
+    for k, v in flat.items():
+        parts = k.split("/")
+        if len(parts) == 2 and parts[0] in nested:
+            nested[parts[0]][parts[1]] = v
+        elif len(parts) == 3:
+            nested["laneline"]["reference"][parts[2]] = v
+    nested["initial_condition"] = flat["initial_condition"]
+    ypath = tmp_path / "scenario_three_bend.yaml"
+
+    def scalar(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return f'"{v}"'
+        return repr(v)
+
+    def emit(d, ind=0):  # block maps, inline lists, "- [..]" items: the layout of the reference's config files
+        out = []
+        for k, v in d.items():
+            pad = " " * ind
+            if isinstance(v, dict):
+                out.append(f"{pad}{k}:   # section")
+                out += emit(v, ind + 2)
+            elif isinstance(v, list) and v and isinstance(v[0], list):
+                out.append(f"{pad}{k}:")
+                out.append(f"{pad}  # [x, y, v, yaw]")
+                out += [f"{pad}  - [{', '.join(repr(e) for e in row)}]" for row in v]
+            elif isinstance(v, list):
+                out.append(f"{pad}{k}: [{', '.join(repr(e) for e in v)}]")
+            else:
+                out.append(f"{pad}{k}: {scalar(v)}")
+        return out
+
+    text = "\n".join(["# generated for the test"] + emit(nested)) + "\n"
+    assert yaml.safe_load(text)["lqr"]["N"] == 30  # it is valid YAML of the intended shape
+    ypath.write_text(text)
+    src = tmp_path / "cfg.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "cilqr_config.hpp"
+int main(int argc, char** argv) {
+  auto c = cilqr_amd::FlatConfig::load(argv[1]);
+  auto ic = c.get_config<std::vector<std::vector<double>>>("initial_condition");
+  auto rx = c.get_config<std::vector<double>>("laneline/reference/x");
+  auto bd = c.get_config<std::vector<double>>("laneline/border");
+  std::printf("%d %.17g %.17g %s %s %d %zu %zu %.17g %.17g %zu %.17g %d\n", c.get_config<int>("lqr/N"),
+              c.get_config<double>("lqr/w_stl"), c.get_config<double>("vehicle/stl_lim"),
+              c.get_config<std::string>("lqr/slove_type").c_str(), c.get_config<std::string>("vehicle/reference_point").c_str(),
+              (int)c.get_config<bool>("lqr/use_last_solution"), ic.size(), ic[3].size(), ic[3][0], ic[1][3], rx.size(), bd[3],
+              (int)c.has_key("visualization/y_lim"));
+  return 0; }''')
+    exe = tmp_path / "cfg"
+    subprocess.run(["g++", "-std=c++17", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    a = subprocess.run([str(exe), str(ypath)], check=True, capture_output=True, text=True).stdout
+    b = subprocess.run([str(exe), str(pkg.config.SCENARIO_DIR / "three_bend.json")], check=True, capture_output=True, text=True).stdout
+    assert a == b, (a, b)
+    assert a.split()[0] == "30" and a.split()[3] == "barrier" and a.split()[4] == "gravity_center"
