@@ -116,6 +116,12 @@ def cpu_baseline(pkg, wl, threads):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # called directly with --gpus N: re-launch as one process per GPU, the way the driver does
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29541"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvp(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
