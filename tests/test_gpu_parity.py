@@ -561,3 +561,44 @@ def test_edge_start_on_the_reference_line_and_wild_states(pkg, orc_det, scenario
     out, refs = solve_both(pkg, orc_det, p, tab, x0)
     compare_solves(out, refs, "degenerate starts")
     assert np.isnan(out["res"]["J_final"][3])
+
+
+def test_fuzz_random_parameter_sets(pkg, orc_det, scenarios):
+    """randomised parameter sets (weights, barrier shapes, bounds, lambda schedule, horizon, vehicle
+    model, solve type) on all four scenarios: whole solves incl. decision traces stay bit-exact."""
+    from oracle import Scene
+    rng = np.random.default_rng(20250829)
+    names = list(scenarios)
+    total_iters = 0
+    for trial in range(28):
+        name = names[trial % 4]
+        cfg, sc = scenarios[name]
+        N = int(rng.choice([3, 7, 20, 30, 45, 63, 64, 80, 110]))
+        T = sc.routes.shape[1]
+        over = dict(
+            N=N, use_last_solution=0, solve_type=int(rng.random() < 0.3), reference_point=int(rng.random() < 0.5),
+            w_pos=float(rng.uniform(0.2, 3)), w_vel=float(rng.uniform(0.2, 3)), w_yaw=float(rng.uniform(1, 40)),
+            w_acc=float(rng.uniform(0.1, 2)), w_stl=float(rng.uniform(5, 60)),
+            obstacle_exp_q1=float(rng.uniform(1, 12)), obstacle_exp_q2=float(rng.uniform(2, 9)),
+            state_exp_q1=float(rng.uniform(1, 6)), state_exp_q2=float(rng.uniform(2, 6)),
+            init_lamb=float(rng.choice([0.0, 0.0, 1.0, 20.0])), lamb_decay=float(rng.uniform(0.3, 0.9)),
+            lamb_amplify=float(rng.uniform(1.5, 4)), max_lamb=float(rng.choice([100.0, 1000.0, 1e4])),
+            convergence_threshold=float(rng.choice([1e-3, 1e-2, 0.1])), accept_step_threshold=float(rng.uniform(0.1, 0.8)),
+            max_iter=int(rng.choice([3, 25, 100])), velo_max=float(rng.uniform(8, 16)), acc_max=float(rng.uniform(1.5, 4)),
+            acc_min=-float(rng.uniform(1.5, 4)), stl_lim=float(rng.uniform(0.08, 0.4)), d_safe=float(rng.uniform(0.5, 1.2)),
+            alm_rho_init=float(rng.uniform(1, 30)), alm_gamma=float(rng.choice([0.0, 0.5])), max_rho=float(rng.uniform(20, 80)),
+            max_mu=float(rng.uniform(50, 200)))
+        p = pkg.params_from_config(cfg, **over)
+        tick = int(rng.integers(0, max(1, T - N - 1)))
+        B = 10
+        x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 7000 + trial)
+        tab = pkg.SceneTable.from_scenario(sc)
+        eng = pkg.BatchedCILQR(p, tab)
+        eng.set_helper_mode(int(trial % 3) - 1)  # -1 auto, 0 off, 1 on
+        out = eng.solve_batch(x0, tick=np.full(B, tick, np.int32), trace_cap=128)
+        scene = Scene(tab.lane_x, tab.lane_y, tab.lane_yaw, tab.obs, tab.road_borders, tab.ref_velo, tick)
+        refs = [orc_det.solver(p).solve(x, scene) for x in x0]
+        compare_solves(out, refs, f"fuzz {trial} {name} N={N} st={over['solve_type']} rp={over['reference_point']}")
+        total_iters += int(out["res"]["iters"].sum())
+        eng.close()
+    assert total_iters > 1000
