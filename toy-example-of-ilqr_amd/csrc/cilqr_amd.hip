@@ -164,6 +164,8 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
         if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
             cost_and_model_derivatives<ALM>(c, l, al, lane);
+        } else {
+            model_jacobians(c, l, lane); // the gains of the failed pass sit where A, B were
         }
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
@@ -371,8 +373,8 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     const int R = N + 1;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
-    for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = K[(size_t)b * 8 * N + e];
-    for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = d[(size_t)b * 2 * N + e];
+    for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.kd[CILQR_KD * (e >> 3) + CILQR_KD_K(e & 7)] = K[(size_t)b * 8 * N + e];
+    for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.kd[CILQR_KD * (e >> 1) + CILQR_KD_D(e & 1)] = d[(size_t)b * 2 * N + e];
     __syncthreads();
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W); // indices of the current trajectory: the guesses for its trials
@@ -429,12 +431,12 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
                 q[0] = l.luu[2 * k]; q[1] = 0.0; q[2] = 0.0; q[3] = l.luu[2 * k + 1];
             }
             if (o_A) {
-                const double* A = l.A5 + 5 * k;
+                const double* A = l.kd + CILQR_KD * k;
                 const double dn[16] = {1, 0, A[0], A[1], 0, 1, A[2], A[3], 0, 0, 1, 0, 0, 0, A[4], 1};
                 for (int e = 0; e < 16; ++e) o_A[((size_t)b * N + k) * 16 + e] = dn[e];
             }
             if (o_B) {
-                const double* Bq = l.B3 + 3 * k;
+                const double* Bq = l.kd + CILQR_KD * k + CILQR_KD_B;
                 const double dn[8] = {0, Bq[0], 0, Bq[1], c.dt, 0, 0, Bq[2]};
                 for (int e = 0; e < 8; ++e) o_B[((size_t)b * N + k) * 8 + e] = dn[e];
             }
@@ -453,17 +455,18 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
     const int R = N + 1;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
-    for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.K[e] = 0.0;
-    for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.d[e] = 0.0;
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
     AlmSt al = load_alm(a, b, N);
     cost_and_model_derivatives<ALM>(c, l, al, lane);
     double dV[2];
-    bool ok = backward_sweep<!ALM>(c, l, lamb[b], lane, dV, a.flags);
+    int fail_step = -1; // gains exist for the steps after it; d, K start as zeros upstream (cs:392-393)
+    bool ok = backward_sweep<!ALM>(c, l, lamb[b], lane, dV, a.flags, &fail_step);
     __syncthreads();
-    for (int e = lane; e < 8 * N; e += CILQR_WAVE) o_K[(size_t)b * 8 * N + e] = l.K[e];
-    for (int e = lane; e < 2 * N; e += CILQR_WAVE) o_d[(size_t)b * 2 * N + e] = l.d[e];
+    for (int e = lane; e < 8 * N; e += CILQR_WAVE)
+        o_K[(size_t)b * 8 * N + e] = ((e >> 3) > fail_step) ? l.kd[CILQR_KD * (e >> 3) + CILQR_KD_K(e & 7)] : 0.0;
+    for (int e = lane; e < 2 * N; e += CILQR_WAVE)
+        o_d[(size_t)b * 2 * N + e] = ((e >> 1) > fail_step) ? l.kd[CILQR_KD * (e >> 1) + CILQR_KD_D(e & 1)] : 0.0;
     if (lane == 0) {
         o_dV[2 * b] = dV[0];
         o_dV[2 * b + 1] = dV[1];
@@ -564,6 +567,7 @@ struct cilqr_handle {
     DevBuf d_scenes;
     // scratch + staging
     int win = 0;      // LDS lane-window capacity in samples (derived from the tables)
+    int win_occ = 0;  // the same when two wavefronts per SIMD are wanted (large batches)
     DevBuf scratch;
     DevBuf alm_mu, alm_mu_next, alm_rho; // ALM solve type: per-trajectory multipliers carried across calls
     int alm_B = 0, alm_C = 0;
@@ -596,14 +600,20 @@ static void update_window(cilqr_handle* h) {
     const int N = h->params[0].N;
     const int alm = h->params[0].solve_type == 1 ? 1 : 0;
     const size_t fixed = lds_bytes(N, 0, alm);
-    int best = want;
-    for (int k = 8; k >= 1; --k) {
-        const long budget = (long)(163840 / k) - (long)fixed;
-        if (budget <= 0) continue;
-        int wk = (int)(budget / 16) / 64 * 64;
-        if (wk >= floor_ok) { best = std::min(want, wk); break; }
-    }
-    h->win = best;
+    auto pick = [&](int floor_w) {
+        for (int k = 8; k >= 1; --k) {
+            const long budget = (long)(163840 / k) - (long)fixed;
+            if (budget <= 0) continue;
+            const int wk = (int)(budget / 16) / 8 * 8;
+            if (wk >= floor_w) return std::min(want, wk);
+        }
+        return want;
+    };
+    h->win = pick(floor_ok);
+    // batches that fill the chip several times over: occupancy (two wavefronts per SIMD hide each other's
+    // latencies) is worth more than the far end of the window, which only the last rows at full speed reach
+    h->win_occ = pick(std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8));
+    if (const char* e = getenv("CILQR_EXP_WINDOW")) h->win = h->win_occ = atoi(e);
 }
 
 static int check_ready(cilqr_handle* h) {
@@ -886,9 +896,11 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.prof = nullptr;
     a.B = B;
     a.N = h->params[0].N;
-    a.W = h->win;
     a.flags = h->debug_flags;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
+    // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
+    const bool occ2 = B > h->occ2_min_batch && !a.alm && a.flags == 0 && !h->profiling && h->helper_mode != 1;
+    a.W = occ2 ? h->win_occ : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
     a.alm_rho = static_cast<double*>(h->alm_rho.p);

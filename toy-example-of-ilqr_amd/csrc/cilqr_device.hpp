@@ -101,17 +101,15 @@ __device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s
 struct Lds {
     double* x;   // [(N+1)][4]
     double* u;   // [N][2]
-    double* K;   // [N][8]
-    double* d;   // [N][2]
+    double* kd;  // [N][10] per step: the model Jacobians (a02 a03 a12 a13 a32 | b01 b11 b31 | - -) until the
+                 // backward sweep has consumed them, then the gains (K[0][:] d[0] | K[1][:] d[1]) of that step
     double* lx;  // [(N+1)][4]
     double* lu;  // [N][2]
     double* lxx; // [(N+1)][lxs]: 7 packed entries (barrier mode: symmetric) or 16 dense (ALM mode)
     int lxs;
     double* luu; // [N][2]
-    double* A5;  // [N][5]  a02 a03 a12 a13 a32
-    double* B3;  // [N][3]  b01 b11 b31
     double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
-    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier.  ALIASES K and d: the gains
+    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier.  ALIASES kd: the gains
                  // are dead once the rollout has produced the trial trajectories, and costs are only summed then
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
@@ -125,11 +123,17 @@ struct Lds {
 // constants the backward sweep's per-lane address maps point at: 0.0, 1.0, dt, 0.0
 #define CILQR_XCH_CONST 0
 #define CILQR_XCH 4
+#define CILQR_KD 10 /* doubles per step of Lds::kd */
+#define CILQR_KD_B 5 /* offset of b01 b11 b31 */
+/* gains of a step: (K[0][0..3] d[0] | K[1][0..3] d[1]) — column c of (K | d) is written by lane c with one
+ * two-address store */
+#define CILQR_KD_ROW 5
+#define CILQR_KD_K(e) ((e) < 4 ? (e) : (e) + 1) /* K[e / 4][e % 4], e = 0..7 */
+#define CILQR_KD_D(j) (4 + CILQR_KD_ROW * (j))  /* d[j] */
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
-    return 4 * (N + 1) + 2 * N + 8 * N + 2 * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + 5 * N +
-           3 * N + CILQR_XCH + 4;
+    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + 4;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
     return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
@@ -139,17 +143,14 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
-    l.K = p; p += 8 * N;
-    l.d = p; p += 2 * N;
+    l.kd = p; p += CILQR_KD * N;
     l.lx = p; p += 4 * (N + 1);
     l.lu = p; p += 2 * N;
     l.lxs = alm ? 16 : 7;
     l.lxx = p; p += l.lxs * (N + 1);
     l.luu = p; p += 2 * N;
-    l.A5 = p; p += 5 * N;
-    l.B3 = p; p += 3 * N;
     l.xch = p; p += CILQR_XCH;
-    l.cs = l.K; // 10 N doubles (K and d) >= CILQR_NT * 3 * (N + 1) for every N >= 2
+    l.cs = l.kd; // 10 N doubles >= CILQR_NT * 3 * (N + 1) for every N >= 2
     l.ctld = p; p += 4;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
@@ -196,17 +197,17 @@ template <int RP>
 __device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4]) {
     if (RP == 0) {
         double sn, cs;
-        dm_sincos(x[3], &sn, &cs);
-        double tn = dm_tan(u[1]);
+        dm_sincos<1>(x[3], &sn, &cs);
+        double tn = dm_tan<1>(u[1]);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
         xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
     } else {
-        double beta = dm_atan(dm_tan(u[1]) / 2);
+        double beta = dm_atan(dm_tan<1>(u[1]) / 2);
         double sn, cs;
-        dm_sincos(beta + x[3], &sn, &cs);
-        double sb = dm_sin(beta);
+        dm_sincos<1>(beta + x[3], &sn, &cs);
+        double sb = dm_sin<1>(beta);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
@@ -788,20 +789,38 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
         double* t = scr + lane;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         TR(t, 0, 0) = xc[0]; TR(t, 1, 0) = xc[1]; TR(t, 2, 0) = xc[2]; TR(t, 3, 0) = xc[3];
-        const double* Ki = l.K;
+        const double* Ki = l.kd;
         const double* xi = l.x;
         const double* ui = l.u;
-        const double* di = l.d;
         const size_t CS = (size_t)R * CILQR_MAX_ALPHA_TRIALS; // component stride
         double* tx = &TR(t, 0, 1);   // x' components at strides CS
         double* tu = &TR(t, 4, 0);   // u' components
+        // the gains and the nominal point of step i + 1 are fetched from LDS while step i computes
+        double kq[CILQR_KD], xq[4], uq[2];
+#pragma unroll
+        for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[e] = xi[e];
+        uq[0] = ui[0]; uq[1] = ui[1];
         for (int i = 0; i < N; ++i) {
-            double dx0 = xc[0] - xi[0], dx1 = xc[1] - xi[1], dx2 = xc[2] - xi[2], dx3 = xc[3] - xi[3];
-            double k0 = ((Ki[0] * dx0 + Ki[1] * dx1) + Ki[2] * dx2) + Ki[3] * dx3;
-            double k1 = ((Ki[4] * dx0 + Ki[5] * dx1) + Ki[6] * dx2) + Ki[7] * dx3;
+            double kk[CILQR_KD], xr[4], ur[2];
+#pragma unroll
+            for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[e] = xq[e];
+            ur[0] = uq[0]; ur[1] = uq[1];
+            if (i + 1 < N) { Ki += CILQR_KD; xi += 4; ui += 2; }
+#pragma unroll
+            for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = xi[e];
+            uq[0] = ui[0]; uq[1] = ui[1];
+            double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
+            double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
+            double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
             double un[2];
-            un[0] = (ui[0] + k0) + alpha * di[0];
-            un[1] = (ui[1] + k1) + alpha * di[1];
+            un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
+            un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
             double xn[4];
             propagate<RP>(c, xc, un, xn);
             tu[0] = un[0];
@@ -811,7 +830,7 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             tx[2 * CS] = xn[2];
             tx[3 * CS] = xn[3];
             xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-            Ki += 8; xi += 4; ui += 2; di += 2; tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+            tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
         }
     }
     wave_sync();
@@ -855,6 +874,54 @@ __device__ inline double alm_next_mu(const Cst& c, double mu, double rho, double
     v = (v > 0.0) ? v : 0.0;
     v = (c.max_mu < v) ? c.max_mu : v;
     return v;
+}
+
+// model Jacobians of step k (ut:285-342) into l.kd: a02 a03 a12 a13 a32 | b01 b11 b31.
+// sy, cy = dm_sincos(yaw) of row k (the caller has them already).
+__device__ inline void model_jacobians_row(const Cst& c, const Lds& l, int k, double v, double yaw, double sy, double cy) {
+    const double delta = l.u[2 * k + 1];
+    double* A = l.kd + CILQR_KD * k;
+    double* B = A + CILQR_KD_B;
+    if (c.rp == 0) {
+        double td = dm_tan(delta);
+        double cd = dm_cos(delta);
+        A[0] = cy * c.dt;
+        A[1] = v * (-sy) * c.dt;
+        A[2] = sy * c.dt;
+        A[3] = v * cy * c.dt;
+        A[4] = td * c.dt / c.wb;
+        B[0] = 0.0;
+        B[1] = 0.0;
+        B[2] = (v * c.dt / c.wb) / (cd * cd);
+    } else {
+        double beta = dm_atan(dm_tan(delta / 2)); // ut:291 (not the beta of ut:265)
+        double td = dm_tan(delta);
+        double g = 0.5 * (1 + td * td) / (1 + 0.25 * (td * td));
+        double sby, cby;
+        dm_sincos(beta + yaw, &sby, &cby);
+        double sb, cb;
+        dm_sincos(beta, &sb, &cb);
+        A[0] = cby * c.dt;
+        A[1] = v * (-sby) * c.dt;
+        A[2] = sby * c.dt;
+        A[3] = v * cby * c.dt;
+        A[4] = 2 * sb * c.dt / c.wb;
+        B[0] = v * (-sby) * c.dt * g;
+        B[1] = v * cby * c.dt * g;
+        B[2] = (2 * v * c.dt / c.wb) * cb * g;
+    }
+}
+
+// The Jacobians alone: the backward sweep overwrites them with the gains, so an iteration that keeps
+// the cost expansion of an unchanged trajectory (cs:469-475) recomputes them — same inputs, same bits.
+__device__ inline void model_jacobians(const Cst& c, const Lds& l, int lane) {
+    for (int k = lane; k < c.N; k += CILQR_WAVE) {
+        const double* xk = l.x + 4 * k;
+        double sy, cy;
+        dm_sincos(xk[3], &sy, &cy);
+        model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
+    }
+    wave_sync();
 }
 
 // get_total_cost_derivatives_and_Hessians (cs:463-690) and get_kinematic_model_derivatives
@@ -1027,49 +1094,16 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             hx[5] = 2 * c.w_yaw + h33;
             hx[6] = 2 * c.w_vel + h22;
         }
-        if (k < N) {
-            // model Jacobians of step k (ut:285-342)
-            double v = xk[2];
-            double delta = l.u[2 * k + 1];
-            double* A = l.A5 + 5 * k;
-            double* B = l.B3 + 3 * k;
-            if (c.rp == 0) {
-                double td = dm_tan(delta);
-                double cd = dm_cos(delta);
-                A[0] = cy * c.dt;
-                A[1] = v * (-sy) * c.dt;
-                A[2] = sy * c.dt;
-                A[3] = v * cy * c.dt;
-                A[4] = td * c.dt / c.wb;
-                B[0] = 0.0;
-                B[1] = 0.0;
-                B[2] = (v * c.dt / c.wb) / (cd * cd);
-            } else {
-                double beta = dm_atan(dm_tan(delta / 2)); // ut:291 (not the beta of ut:265)
-                double td = dm_tan(delta);
-                double g = 0.5 * (1 + td * td) / (1 + 0.25 * (td * td));
-                double sby, cby;
-                dm_sincos(beta + xk[3], &sby, &cby);
-                double sb, cb;
-                dm_sincos(beta, &sb, &cb);
-                A[0] = cby * c.dt;
-                A[1] = v * (-sby) * c.dt;
-                A[2] = sby * c.dt;
-                A[3] = v * cby * c.dt;
-                A[4] = 2 * sb * c.dt / c.wb;
-                B[0] = v * (-sby) * c.dt * g;
-                B[1] = v * cby * c.dt * g;
-                B[2] = (2 * v * c.dt / c.wb) * cb * g;
-            }
-        }
+        if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
     }
     wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward_pass (cs:383-440) after the expansion above.  Wave-uniform; V_x, V_xx in registers.
-// Returns true on success, false for a non-PD Q_uu (BACKWARD_PASS_FAIL); fills l.K, l.d, dV.
-__device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
+// Returns true on success, false for a non-PD Q_uu (BACKWARD_PASS_FAIL); fills the gains in l.kd, dV.
+__device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
+                                              int* fail_step = nullptr) {
     const int N = c.N;
     double Vx[4], V[16];
     {
@@ -1084,8 +1118,8 @@ __device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double
     dV[1] = 0.0;
     const double dt = c.dt;
     for (int i = N - 1; i >= 0; --i) {
-        const double* Ap = l.A5 + 5 * i;
-        const double* Bp = l.B3 + 3 * i;
+        const double* Ap = l.kd + CILQR_KD * i;
+        const double* Bp = Ap + CILQR_KD_B;
         const double a02 = Ap[0], a03 = Ap[1], a12 = Ap[2], a13 = Ap[3], a32 = Ap[4];
         const double b01 = Bp[0], b11 = Bp[1], b31 = Bp[2];
         const double* hx = l.lxx + 7 * i;
@@ -1153,7 +1187,10 @@ __device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double
             double piv1 = Quu[3] - l10 * l10;
             if (piv1 <= 0.0) fail = true;
         }
-        if (fail) return false;
+        if (fail) {
+            if (fail_step) *fail_step = i; // steps i .. 0 of l.kd still hold Jacobians, not gains
+            return false;
+        }
         double det = Quu[0] * Quu[3] - Quu[2] * Quu[1];
         double invdet = 1.0 / det;
         double n00 = -(Quu[3] * invdet), n01 = -(-Quu[1] * invdet), n10 = -(-Quu[2] * invdet), n11 = -(Quu[0] * invdet);
@@ -1167,10 +1204,12 @@ __device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double
             Kk[4 + cidx] = n10 * Qux[cidx] + n11 * Qux[4 + cidx];
         }
         if (lane == 0) {
-            l.d[2 * i] = dd[0];
-            l.d[2 * i + 1] = dd[1];
+            // over the Jacobians of this step, which are in registers by now
+            double* kd = l.kd + CILQR_KD * i;
+            kd[CILQR_KD_D(0)] = dd[0];
+            kd[CILQR_KD_D(1)] = dd[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) l.K[8 * i + e] = Kk[e];
+            for (int e = 0; e < 8; ++e) kd[CILQR_KD_K(e)] = Kk[e];
         }
         // value function update (cs:427-432)
         double P[8]; // K^T Q_uu (4x2)
@@ -1229,19 +1268,19 @@ struct LaneMap {
 
 __device__ inline void lane_map_M(const Lds& l, int k, int j, int& off, int& stride) {
     // M = [A | B], A = I + {a02 a03 a12 a13 a32}, B = {b01 b11 dt b31}
-    const int A5 = (int)(l.A5 - l.x), B3 = (int)(l.B3 - l.x), CC = (int)(l.xch - l.x) + CILQR_XCH_CONST;
+    const int A5 = (int)(l.kd - l.x), B3 = A5 + CILQR_KD_B, CC = (int)(l.xch - l.x) + CILQR_XCH_CONST;
     const int ZERO = CC, ONE = CC + 1, DT = CC + 2;
     off = ZERO; stride = 0;
     if (j < 4 && k == j) off = ONE;
-    if (j == 2 && k == 0) { off = A5 + 0; stride = 5; }
-    if (j == 2 && k == 1) { off = A5 + 2; stride = 5; }
-    if (j == 2 && k == 3) { off = A5 + 4; stride = 5; }
-    if (j == 3 && k == 0) { off = A5 + 1; stride = 5; }
-    if (j == 3 && k == 1) { off = A5 + 3; stride = 5; }
+    if (j == 2 && k == 0) { off = A5 + 0; stride = CILQR_KD; }
+    if (j == 2 && k == 1) { off = A5 + 2; stride = CILQR_KD; }
+    if (j == 2 && k == 3) { off = A5 + 4; stride = CILQR_KD; }
+    if (j == 3 && k == 0) { off = A5 + 1; stride = CILQR_KD; }
+    if (j == 3 && k == 1) { off = A5 + 3; stride = CILQR_KD; }
     if (j == 4 && k == 2) off = DT;
-    if (j == 5 && k == 0) { off = B3 + 0; stride = 3; }
-    if (j == 5 && k == 1) { off = B3 + 1; stride = 3; }
-    if (j == 5 && k == 3) { off = B3 + 2; stride = 3; }
+    if (j == 5 && k == 0) { off = B3 + 0; stride = CILQR_KD; }
+    if (j == 5 && k == 1) { off = B3 + 1; stride = CILQR_KD; }
+    if (j == 5 && k == 3) { off = B3 + 2; stride = CILQR_KD; }
 }
 
 __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
@@ -1304,7 +1343,8 @@ __device__ inline double lane_bcast(double v) {
 // The operands that pass 2 and the rank-2 update need live in other lanes' registers; they are moved
 // with DPP (inside the 8-lane row of the grid), ds_bpermute (across rows) and v_readlane (the 2x2
 // Q_uu and Q_u, needed by every lane) — no LDS round trips inside a step.
-__device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2]) {
+__device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
+                                            int* fail_step = nullptr) {
     const int N = c.N;
     const int rp = (lane >> 3) % 6, cc = lane & 7;
     const double* const base = l.x;
@@ -1326,16 +1366,31 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     const int r4 = rp & 3;
     const int src_c0 = 32 + wc, src_c1 = 40 + wc;   // (Q_ux | Q_u)[0][c], [1][c]
     const int src_r0 = 32 + r4, src_r1 = 40 + r4;   // Q_ux[0][r], [1][r]
+    // this lane's ten coefficient addresses walk backwards with the step
+    const double* pm1[4];
+    const double* pm2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pm1[k] = base + mp.m1[k] + mp.s1[k] * (N - 1);
+        pm2[k] = base + mp.m2[k] + mp.s2[k] * (N - 1);
+    }
+    const double* plq = base + mp.lq + mp.slq * (N - 1);
+    const double* plv = base + mp.lv + mp.slv * (N - 1);
     for (int i = N - 1; i >= 0; --i) {
-        // per-lane coefficients of this step
+        // per-lane coefficients of this step (issued together with the cross-lane moves of pass 1, whose
+        // latency they share; fetching them a step ahead was measured and is slower)
         double m1[4], m2[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m1[k] = base[mp.m1[k] + mp.s1[k] * i];
-            m2[k] = base[mp.m2[k] + mp.s2[k] * i];
+            m1[k] = *pm1[k];
+            m2[k] = *pm2[k];
+            pm1[k] -= mp.s1[k];
+            pm2[k] -= mp.s2[k];
         }
-        const double Lq = base[mp.lq + mp.slq * i];
-        const double lv = base[mp.lv + mp.slv * i];
+        const double Lq = *plq;
+        const double lv = *plv;
+        plq -= mp.slq;
+        plv -= mp.slv;
         // pass 1: column wc of W from the lanes 8 k + wc
         const double w0 = lane_gather(wn, wc), w1 = lane_gather(wn, 8 + wc);
         const double w2 = lane_gather(wn, 16 + wc), w3 = lane_gather(wn, 24 + wc);
@@ -1357,16 +1412,32 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double S = (cc == 4) ? Zv : Q;               // rows 4-5: (Q_ux | Q_u)
         const double c0 = lane_gather(S, src_c0), c1 = lane_gather(S, src_c1);
         const double r0 = lane_gather(S, src_r0), r1 = lane_gather(S, src_r1);
+        // Eigen::LLT's verdict: Quu0 > 0 and the second pivot Quu3 - (Quu2 / sqrt(Quu0))^2 > 0.  The pivot as
+        // computed is Quu3 - (Quu2^2 / Quu0)(1 + e), |e| < 2^-50 (one sqrt, one quotient, one square, and the
+        // final subtraction keeps the sign).  So when Quu0 and Quu3 are positive and of ordinary size
+        // (2^-332 .. 2^332: no product below leaves the normal numbers) and Quu0 Quu3 exceeds Quu2^2 by a factor
+        // 1 + 2^-40, the pivot is positive and need not be evaluated.  Anything else — including NaN, for
+        // which every comparison is false — takes the exact path.
         bool fail = false;
-        if (Quu0 <= 0.0) {
-            fail = true;
-        } else {
-            double l00 = dm_sqrt(Quu0);
-            double l10 = Quu2 / l00;
-            double piv1 = Quu3 - l10 * l10;
-            if (piv1 <= 0.0) fail = true;
+        {
+            const unsigned h0 = (unsigned)(dm_to_bits(Quu0) >> 32), h3 = (unsigned)(dm_to_bits(Quu3) >> 32);
+            const bool ordinary = ((h0 - 0x2B300000u) < 0x29800000u) && ((h3 - 0x2B300000u) < 0x29800000u);
+            const bool surely_pd = ordinary && (Quu0 * Quu3 > (Quu2 * Quu2) * 1.0000000000009095);
+            if (!surely_pd) {
+                if (Quu0 <= 0.0) {
+                    fail = true;
+                } else {
+                    double l00 = dm_sqrt(Quu0);
+                    double l10 = Quu2 / l00;
+                    double piv1 = Quu3 - l10 * l10;
+                    if (piv1 <= 0.0) fail = true;
+                }
+            }
         }
-        if (fail) return false;
+        if (fail) {
+            if (fail_step) *fail_step = i; // steps i .. 0 of l.kd still hold Jacobians, not gains
+            return false;
+        }
         const double det = Quu0 * Quu3 - Quu2 * Quu1;
         const double invdet = 1.0 / det;
         const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
@@ -1382,13 +1453,10 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double own = (cc < 4) ? Q : Zv;
         wn = ((own + ta) + tb) + tc;
         if (lane < 5) { // row r' = 0 holds (K | d) column c
-            if (lane < 4) {
-                l.K[8 * i + lane] = kc0;
-                l.K[8 * i + 4 + lane] = kc1;
-            } else {
-                l.d[2 * i] = kc0;
-                l.d[2 * i + 1] = kc1;
-            }
+            // over the Jacobians of this step: every lane loaded its coefficients at the top of the step
+            double* kd = l.kd + CILQR_KD * i + lane;
+            kd[0] = kc0;
+            kd[CILQR_KD_ROW] = kc1;
         }
         // expected cost reduction (cs:435-436)
         const double hd0 = 0.5 * d0, hd1 = 0.5 * d1;
@@ -1402,9 +1470,10 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
 }
 
 template <bool DBG>
-__device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags) {
-    if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV);
-    return backward_sweep_lanes(c, l, lamb, lane, dV);
+__device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags,
+                                      int* fail_step = nullptr) {
+    if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV, fail_step);
+    return backward_sweep_lanes(c, l, lamb, lane, dV, fail_step);
 }
 
 } // namespace cilqr

@@ -30,6 +30,31 @@
 
 #define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
+/* DM_K(constant): the trigonometric functions exist in two device flavours, selected by a template
+ * argument that only the HIP compilation sees — dm_sincos(x, ..) keeps its coefficients as literals
+ * (scalar registers), dm_sincos<1>(x, ..) pins them to vector registers.  Inside the rollout loop the
+ * literals (two SGPRs each, ~40 in dm_sincos + dm_tan) overflow the scalar file and are re-materialised
+ * and spilled every step; pinned, they are loaded once before the loop.  Same operations, same bits.
+ * For the C oracle build all of this expands to the plain function. */
+#if defined(__HIPCC__)
+#define DM_TFN template <int VK = 0> DM_FN
+#define DM_T(fn) fn<VK>
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int VK>
+static __device__ inline double dm_const(double k) {
+    if (VK) __asm__("" : "+v"(k));
+    return k;
+}
+#define DM_K(x) dm_const<VK>(x)
+#else
+#define DM_K(x) (x)
+#endif
+#else
+#define DM_TFN DM_FN
+#define DM_T(fn) fn
+#define DM_K(x) (x)
+#endif
+
 DM_FN double dm_from_bits(unsigned long long u) {
     double d;
     __builtin_memcpy(&d, &u, sizeof(d));
@@ -111,13 +136,13 @@ DM_FN double dm_exp(double x) {
 }
 
 /* ---- trigonometric range reduction: x = n*(pi/2) + r, |r| <= pi/4 (+eps) ---- */
-DM_FN double dm_trig_reduce(double x, int* quadrant) {
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double P1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
-    const double P2 = 6.07710050630396597660e-11;  /* next 33 bits */
-    const double P3 = 2.02226624871116645580e-21;  /* next 33 bits */
-    const double P4 = 8.47842766036889956997e-32;  /* remainder */
-    const double MAGIC = 6755399441055744.0;
+DM_TFN double dm_trig_reduce(double x, int* quadrant) {
+    const double INV_PIO2 = DM_K(6.36619772367581382433e-01);
+    const double P1 = DM_K(1.57079632673412561417e+00);  /* first 33 bits of pi/2 */
+    const double P2 = DM_K(6.07710050630396597660e-11);  /* next 33 bits */
+    const double P3 = DM_K(2.02226624871116645580e-21);  /* next 33 bits */
+    const double P4 = DM_K(8.47842766036889956997e-32);  /* remainder */
+    const double MAGIC = DM_K(6755399441055744.0);
     /* accurate for |x| <~ 2^30; beyond that the result is meaningless but still the same on host
      * and device (saturating quadrant conversion), and +-inf / NaN give NaN through r */
     double nd = (x * INV_PIO2 + MAGIC) - MAGIC;
@@ -130,19 +155,19 @@ DM_FN double dm_trig_reduce(double x, int* quadrant) {
 }
 
 /* sin and cos kernels on |r| <= pi/4 share z = r*r */
-DM_FN void dm_ksincos(double r, double* s_out, double* c_out) {
-    const double S1 = -1.66666666666666324348e-01;
-    const double S2 = 8.33333333332248946124e-03;
-    const double S3 = -1.98412698298579493134e-04;
-    const double S4 = 2.75573137070700676789e-06;
-    const double S5 = -2.50507602534068634195e-08;
-    const double S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02;
-    const double C2 = -1.38888888888741095749e-03;
-    const double C3 = 2.48015872894767294178e-05;
-    const double C4 = -2.75573143513906633035e-07;
-    const double C5 = 2.08757232129817482790e-09;
-    const double C6 = -1.13596475577881948265e-11;
+DM_TFN void dm_ksincos(double r, double* s_out, double* c_out) {
+    const double S1 = DM_K(-1.66666666666666324348e-01);
+    const double S2 = DM_K(8.33333333332248946124e-03);
+    const double S3 = DM_K(-1.98412698298579493134e-04);
+    const double S4 = DM_K(2.75573137070700676789e-06);
+    const double S5 = DM_K(-2.50507602534068634195e-08);
+    const double S6 = DM_K(1.58969099521155010221e-10);
+    const double C1 = DM_K(4.16666666666666019037e-02);
+    const double C2 = DM_K(-1.38888888888741095749e-03);
+    const double C3 = DM_K(2.48015872894767294178e-05);
+    const double C4 = DM_K(-2.75573143513906633035e-07);
+    const double C5 = DM_K(2.08757232129817482790e-09);
+    const double C6 = DM_K(-1.13596475577881948265e-11);
     double z = r * r;
     double p = DM_FMA(z, S6, S5);
     p = DM_FMA(z, p, S4);
@@ -167,34 +192,34 @@ DM_FN double dm_negate_if(double d, int cond) {
     return dm_from_bits(dm_to_bits(d) ^ ((unsigned long long)(cond != 0) << 63));
 }
 
-DM_FN void dm_sincos(double x, double* s_out, double* c_out) {
+DM_TFN void dm_sincos(double x, double* s_out, double* c_out) {
     int q;
-    double r = dm_trig_reduce(x, &q);
+    double r = DM_T(dm_trig_reduce)(x, &q);
     double s, c;
-    dm_ksincos(r, &s, &c);
+    DM_T(dm_ksincos)(r, &s, &c);
     double ss = (q & 1) ? c : s;
     double cc = (q & 1) ? s : c;
     *s_out = dm_negate_if(ss, q & 2);
     *c_out = dm_negate_if(cc, (q + 1) & 2);
 }
 
-DM_FN double dm_sin(double x) {
+DM_TFN double dm_sin(double x) {
     double s, c;
-    dm_sincos(x, &s, &c);
+    DM_T(dm_sincos)(x, &s, &c);
     return s;
 }
 
-DM_FN double dm_cos(double x) {
+DM_TFN double dm_cos(double x) {
     double s, c;
-    dm_sincos(x, &s, &c);
+    DM_T(dm_sincos)(x, &s, &c);
     return c;
 }
 
-DM_FN double dm_tan(double x) {
+DM_TFN double dm_tan(double x) {
     int q;
-    double r = dm_trig_reduce(x, &q);
+    double r = DM_T(dm_trig_reduce)(x, &q);
     double s, c;
-    dm_ksincos(r, &s, &c);
+    DM_T(dm_ksincos)(r, &s, &c);
     double num = (q & 1) ? c : s;
     double den = (q & 1) ? s : c;
     return dm_negate_if(num, q & 1) / den;
