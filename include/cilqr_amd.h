@@ -160,8 +160,10 @@ int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
  * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,
  * [4] trial cost evaluations, [5] accepting a trial, [6] whole solve, [7] iterations,
  * [8] trial cost evaluations that fell back to the serial reference-point chain, [9] trials,
- * [10..12] split of [4]: reference points, stage costs, ordered sum.  out[B][13]. */
-#define CILQR_PROF_SLOTS 13
+ * [10..12] split of [4]: reference points, stage costs, ordered sum, [13] trial cost evaluations in which
+ * some row's reference-point proof had to sample the lane interval (convexity certificate not
+ * applicable).  out[B][14]. */
+#define CILQR_PROF_SLOTS 14
 int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
 /* Testing aid.  bit 0: always use the serial reference-point chain (cs:289-314 as written) instead
  * of the lane-parallel search + proof; bit 1: wave-uniform backward sweep instead of the

@@ -19,7 +19,7 @@ ERR_NO_DEVICE = -5
 
 MAX_HORIZON = 127
 MAX_ALPHA_TRIALS = 20
-PROF_SLOTS = 13
+PROF_SLOTS = 14
 DBG_SERIAL_REF_SCAN = 1
 DBG_UNIFORM_BACKWARD = 2
 

@@ -56,8 +56,7 @@ __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
 }
 
 // phase ids of the optional in-kernel cycle accounting
-#define CILQR_PROF_SLOTS 13
-enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12 };
+enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12, PH_TC_SAMPLED = 13 };
 #define PROF_T0() long long t_ph_ = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0
 #define PROF_ADD(ph)                                                  \
     do {                                                              \
@@ -137,7 +136,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         wave_sync();
     }
 
-    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
@@ -765,6 +764,36 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
     return CILQR_OK;
 }
 
+// Constants of convex_interior() (cilqr_device.hpp) for one lane table, every rounding taken against the
+// certificate: g = min_j (L_{j+2} - L_{j+1}).(M_{j+1} - M_j), h = max_j |(L_{j+2} - L_{j+1}) - (L_{j+1} - L_j)|,
+// s_max = longest segment; rcap = min(1e3, (g - 1e-6) / h) (0 when the table cannot be certified).
+static void lane_convexity_bounds(const double* x, const double* y, int L, double* rcap, double* smax) {
+    *rcap = 0.0;
+    *smax = 0.0;
+    if (L < 3) return;
+    double g = HUGE_VAL, hm = 0.0, sm = 0.0, cmax = 0.0;
+    for (int j = 0; j < L; ++j) cmax = std::max(cmax, std::max(std::fabs(x[j]), std::fabs(y[j])));
+    for (int j = 0; j + 1 < L; ++j) sm = std::max(sm, std::hypot(x[j + 1] - x[j], y[j + 1] - y[j]));
+    for (int j = 0; j + 2 < L; ++j) {
+        const double d0x = x[j + 1] - x[j], d0y = y[j + 1] - y[j];
+        const double d1x = x[j + 2] - x[j + 1], d1y = y[j + 2] - y[j + 1];
+        const double mx = 0.5 * (x[j + 2] - x[j]), my = 0.5 * (y[j + 2] - y[j]); // M_{j+1} - M_j
+        g = std::min(g, d1x * mx + d1y * my);
+        hm = std::max(hm, std::hypot(d1x - d0x, d1y - d0y));
+    }
+    if (!(cmax < 1e6) || !(sm < 1e3) || !(g == g) || !(hm == hm)) return; // non-finite or absurd table
+    // coordinate differences carry an absolute error of a few ulp(cmax); products with segments <= sm
+    const double slack = 64.0 * 2.220446049250313e-16 * (cmax + 1.0);
+    g = g * (1.0 - 1e-9) - slack * (sm + 1.0);
+    hm = hm * (1.0 + 1e-9) + slack;
+    sm = sm * (1.0 + 1e-9) + slack;
+    if (!(g > 1e-6)) return;
+    double r = (g - 1e-6) / hm;
+    r = std::min(r, 1e3) * (1.0 - 1e-8);
+    *rcap = r;
+    *smax = sm;
+}
+
 extern "C" int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* scen, int32_t n_scen) {
     if (!h || !scen || n_scen < 1) return fail(CILQR_ERR_BAD_ARG, "bad scenario table");
     for (int i = 0; i < n_scen; ++i) {
@@ -820,6 +849,7 @@ extern "C" int cilqr_set_scenarios(cilqr_handle* h, const cilqr_scenario_desc* s
         d.border_hi = s.road_borders[0];
         d.border_lo = s.road_borders[1];
         d.ref_velo = s.ref_velo;
+        lane_convexity_bounds(s.lane_x, s.lane_y, s.L, &d.cert_rcap, &d.cert_smax);
         h->scenes.push_back(d);
         h->scene_T.push_back(s.T);
         h->scene_M.push_back(s.M);

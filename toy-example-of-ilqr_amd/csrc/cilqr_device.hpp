@@ -55,6 +55,7 @@ struct DevScene {
     const double* obs;      // [M][T][5] x, y, yaw, sin, cos
     int L, M, T, pad;
     double border_hi, border_lo, ref_velo;
+    double cert_rcap, cert_smax; // convexity certificate of the lane table (see convex_interior), filled by the host
 };
 
 // wave-uniform constants of one trajectory
@@ -67,6 +68,7 @@ struct Cst {
     double pos_up_b, pos_lo_b;
     double ell_a2, ell_b2;
     double ref_velo;
+    double cert_rcap, cert_smax;
     double init_lamb, lamb_decay, lamb_amplify, max_lamb, conv_thr, accept_thr;
     double alm_rho_init, alm_gamma, max_rho, max_mu;
     gdouble* lane_xy;
@@ -90,6 +92,7 @@ __device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s
     c.ell_a2 = a * a;
     c.ell_b2 = b * b;
     c.ref_velo = s.ref_velo;
+    c.cert_rcap = s.cert_rcap; c.cert_smax = s.cert_smax;
     c.init_lamb = p.init_lamb; c.lamb_decay = p.lamb_decay; c.lamb_amplify = p.lamb_amplify;
     c.max_lamb = p.max_lamb; c.conv_thr = p.convergence_threshold; c.accept_thr = p.accept_step_threshold;
     c.alm_rho_init = p.alm_rho_init; c.alm_gamma = p.alm_gamma; c.max_rho = p.max_rho; c.max_mu = p.max_mu;
@@ -287,8 +290,12 @@ __device__ inline double lane_d2(const Cst& c, const Lds& l, double px, double p
 
 // A local minimum of the distance profile of one row near `guess` (>= lo): walk forward while the
 // distance strictly decreases, otherwise walk backward to where the strict decrease starts.  Only
-// a CANDIDATE for cs:295-311 — verify_interval() proves or rejects it.
-__device__ inline int local_min_near(const Cst& c, const Lds& l, double px, double py, int guess, int lo) {
+// a CANDIDATE for cs:295-311 — but one that comes with two facts, established with the reference's own
+// comparisons on the way: the returned m satisfies  not d(m+1) < d(m)  (the scan would stop at m; the
+// table end counts as +inf), and, if m > lo,  d(m) < d(m-1)  (the scan would not have stopped at m-1).
+// *q_m = squared distance at m.
+__device__ inline int local_min_near(const Cst& c, const Lds& l, double px, double py, int guess, int lo,
+                                     double* q_m) {
     int j = guess;
     // the three neighbours are fetched together: when the guess is already right this is all it takes
     double cur = lane_d2(c, l, px, py, j);
@@ -305,17 +312,18 @@ __device__ inline int local_min_near(const Cst& c, const Lds& l, double px, doub
             bool f1 = dist_less(n1, cur), f2 = dist_less(n2, n1), f3 = dist_less(n3, n2), f4 = dist_less(n4, n3);
             int adv = f1 ? (f2 ? (f3 ? (f4 ? 4 : 3) : 2) : 1) : 0;
             j += adv;
+            cur = (adv == 0) ? cur : ((adv == 1) ? n1 : ((adv == 2) ? n2 : ((adv == 3) ? n3 : n4)));
             if (adv < 4) break;
-            cur = n4;
         }
     } else {
         while (j > lo) {
             if (dist_less(cur, prv)) break; // strictly decreasing into j: the reference would not stop at j-1
             j -= 1;
-            cur = prv;
+            cur = prv; // and d(j+1) < d(j) was just found false for the new j
             prv = lane_d2(c, l, px, py, (j > lo) ? j - 1 : j);
         }
     }
+    *q_m = cur;
     return j;
 }
 
@@ -342,6 +350,27 @@ __device__ inline bool verify_window_fast(const Lds& l, double px, double py, in
     ey = py - w[2 * (len + 1) + 1];
     const double nxt = ex * ex + ey * ey;
     return good && (nxt >= prev);
+}
+
+// The interior of the same proof without looking at the interior, when the lane is locally convex for
+// this point.  Given (from local_min_near) that d(b) < d(b-1) and not d(b+1) < d(b), is d strictly
+// decreasing on all of [a, b], b - a >= 2?
+//
+// Write q(j) = |p - L_j|^2, D(j) = q(j+1) - q(j) = -2 (L_{j+1} - L_j).(p - M_j) with M_j the midpoint of
+// segment j.  Then D(j+1) - D(j) = 2 [ (L_{j+2} - L_{j+1}).(M_{j+1} - M_j) - ((L_{j+2} - L_{j+1}) - (L_{j+1} - L_j)).(p - M_j) ]
+//                                >= 2 [ g - h |p - M_j| ],
+// g = min over the table of the first product, h = max over the table of the second-difference norm
+// (both computed once per scenario on the host, rounded against us).  For j in [a, b] the point is within
+// r = d(b) + (b - a + 1) s_max of M_j (s_max = longest segment).  The host hands over
+// cert_rcap = min(1e3, (g - 1e-6) / h) shrunk by 1e-8: r <= cert_rcap gives D(j+1) - D(j) >= 2e-6 on the
+// interval.  d(b) < d(b-1) as the reference computes it means D(b-1) <= 2^-49 q.  For j <= b - 2 this
+// leaves D(j) <= 2^-49 q - 2e-6 with q <= r^2 <= 1e6, i.e. q(j+1) is below q(j) by more than 1e-6 absolute
+// = 1e-12 relative — four orders of magnitude more than the rounding of the two squared distances and of
+// their square roots (2^-50), so the reference's comparison hypot(j+1) < hypot(j) holds at every j in
+// [a, b-2] without being evaluated.  A `false` only means "not proven this way" (kinked lane, far point, NaN).
+__device__ inline bool convex_interior(const Cst& c, double q_b, int a, int b) {
+    const double lim = c.cert_rcap - (double)(b - a + 1) * c.cert_smax;
+    return (lim > 0.0) && (q_b <= lim * lim);
 }
 
 // With the comparisons the reference makes: does d strictly decrease on [a, b] (a <= b) and stop
@@ -603,71 +632,54 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) proven[tt] = (tt >= nt);
     if (!(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
-        // level 0: the trial keeps the current trajectory's indices (small steps: the usual case of a
-        // failing line search) — one cheap check per row, no search, no exchange
+        // level 1: every row looks for its candidate near the index the current trajectory has on that row
+        // (unchanged for the small steps of a failing line search: three samples and done) ...
+        double qm[NTR][NCH];
 #pragma unroll
         for (int tt = 0; tt < NTR; ++tt) {
             if (tt >= nt) continue;
-            bool ok0 = true;
+            int* tix = l.tidx + (slot0 + tt) * (N + 2);
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int k = lane + CILQR_WAVE * ch;
-                if (k >= 1 && k <= N)
-                    ok0 = ok0 && verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], l.ridx[k - 1], guess[ch]);
-            }
-            if (__ballot(!ok0) == 0ULL) {
-                int* tix = l.tidx + (slot0 + tt) * (N + 2);
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int k = lane + CILQR_WAVE * ch;
-                    if (k <= N) tix[k] = guess[ch];
+                qm[tt][ch] = 0.0;
+                if (k <= N) {
+                    int m = idx0;
+                    if (k > 0) {
+                        int g = guess[ch];
+                        g = (g < idx0) ? idx0 : g;
+                        g = (g > c.L - 1) ? c.L - 1 : g;
+                        m = local_min_near(c, l, xk[tt][ch][0], xk[tt][ch][1], g, idx0, &qm[tt][ch]);
+                    }
+                    tix[k] = m;
                 }
-                proven[tt] = true;
             }
         }
-        // level 1: independent search for a candidate per row, then the proof
-        bool any_l1 = false;
+        wave_sync();
+        // ... then the proof that the chain of cs:289-314 visits exactly these: row k's scan starts at
+        // m[k-1]; it must decrease strictly up to m[k] and stop there.  The two comparisons at m[k] come
+        // with the candidate; the interior is covered by the convexity certificate, else sample by sample.
 #pragma unroll
-        for (int tt = 0; tt < NTR; ++tt) any_l1 = any_l1 || !proven[tt];
-        if (any_l1) {
+        for (int tt = 0; tt < NTR; ++tt) {
+            if (tt >= nt) continue;
+            const int* tix = l.tidx + (slot0 + tt) * (N + 2);
+            bool ok = true, sampled = false;
 #pragma unroll
-            for (int tt = 0; tt < NTR; ++tt) {
-                if (proven[tt]) continue;
-                int* tix = l.tidx + (slot0 + tt) * (N + 2);
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int k = lane + CILQR_WAVE * ch;
-                    if (k <= N) {
-                        int m = idx0;
-                        if (k > 0) {
-                            int g = guess[ch];
-                            g = (g < idx0) ? idx0 : g;
-                            g = (g > c.L - 1) ? c.L - 1 : g;
-                            m = local_min_near(c, l, xk[tt][ch][0], xk[tt][ch][1], g, idx0);
-                        }
-                        tix[k] = m;
-                    }
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int tt = 0; tt < NTR; ++tt) {
-                if (proven[tt]) continue;
-                const int* tix = l.tidx + (slot0 + tt) * (N + 2);
-                bool ok = true;
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const int k = lane + CILQR_WAVE * ch;
-                    if (k >= 1 && k <= N) {
-                        const int lo = tix[k - 1], hi = tix[k];
-                        bool good = (lo <= hi);
-                        if (good && !verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], lo, hi))
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = lane + CILQR_WAVE * ch;
+                if (k >= 1 && k <= N) {
+                    const int lo = tix[k - 1], hi = tix[k];
+                    bool good = (lo <= hi);
+                    if (good && hi - lo >= 2 && !convex_interior(c, qm[tt][ch], lo, hi)) {
+                        sampled = true;
+                        if (!verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], lo, hi))
                             good = verify_interval(c, l, xk[tt][ch][0], xk[tt][ch][1], lo, hi);
-                        ok = ok && good;
                     }
+                    ok = ok && good;
                 }
-                proven[tt] = (__ballot(!ok) == 0ULL);
             }
+            proven[tt] = (__ballot(!ok) == 0ULL);
+            if (sub && __ballot(sampled) != 0ULL) sub[3] += 1;
         }
     }
     // level 2: the serial chain of cs:289-314
