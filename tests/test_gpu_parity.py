@@ -563,6 +563,55 @@ def test_edge_start_on_the_reference_line_and_wild_states(pkg, orc_det, scenario
     assert np.isnan(out["res"]["J_final"][3])
 
 
+def test_irregular_lane_tables_reference_search(pkg, orc_det, scenarios):
+    """The reference-point proof leans on a per-lane convexity certificate; on lane tables that cannot be
+    certified (a sharp corner, jittered or very uneven sampling, a lane that doubles back, a gap) it must
+    fall back to sampling / the serial chain and still reproduce the oracle bit for bit."""
+    cfg, sc = scenarios["two_straight"]
+    p = pkg.params_from_config(cfg, N=40)
+    rng = np.random.default_rng(77)
+    L = len(sc.lane.x)
+    s = np.arange(L) * 0.1
+    lanes = {}
+    # sharp 60 degree corner 12 m ahead of the ego
+    k = int(np.searchsorted(sc.lane.x, sc.ego_state[0] + 12.0))
+    x, y = sc.lane.x.copy(), sc.lane.y.copy()
+    t = s[k:] - s[k]
+    x[k:] = x[k] + t * np.cos(np.pi / 3); y[k:] = y[k] + t * np.sin(np.pi / 3)
+    yaw = sc.lane.yaw.copy(); yaw[k:] = np.pi / 3
+    lanes["corner"] = (x, y, yaw)
+    # centimetre jitter on every sample: second differences of the table are as large as the segments
+    lanes["jitter"] = (sc.lane.x + rng.normal(0, 0.03, L), sc.lane.y + rng.normal(0, 0.03, L), sc.lane.yaw)
+    # uneven sampling: segment lengths between 1 cm and 60 cm
+    ds = rng.uniform(0.01, 0.6, L)
+    lanes["uneven"] = (sc.lane.x[0] + np.cumsum(ds) - ds[0], sc.lane.y.copy(), sc.lane.yaw)
+    # a hairpin: the lane comes back 3 m to the side of itself
+    xa = sc.lane.x[:k + 200]
+    xb = xa[::-1]
+    lanes["hairpin"] = (np.concatenate([xa, xb]), np.concatenate([sc.lane.y[:k + 200], sc.lane.y[:k + 200] + 3.0]),
+                        np.concatenate([sc.lane.yaw[:k + 200], sc.lane.yaw[:k + 200] + np.pi]))
+    # a 5 m gap in the table
+    keep = np.r_[0:k, k + 50:L]
+    lanes["gap"] = (sc.lane.x[keep], sc.lane.y[keep], sc.lane.yaw[keep])
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 12, 909)
+    sampled = serial = 0
+    for name, (lx, ly, lyaw) in lanes.items():
+        tab = pkg.SceneTable(lx, ly, lyaw, sc.obstacles, sc.road_borders, sc.target_velocity)
+        out, refs = solve_both(pkg, orc_det, p, tab, x0)
+        compare_solves(out, refs, f"lane={name}")
+        # the same through the instrumented kernel: which proof levels did this table need?
+        eng = pkg.BatchedCILQR(p, tab)
+        eng.set_phase_profiling(True)
+        out2 = eng.solve_batch(x0, trace_cap=128)
+        cyc = eng.phase_cycles(len(x0))
+        eng.close()
+        compare_solves(out2, refs, f"lane={name} (instrumented)")
+        sampled += int(cyc[:, 13].sum())
+        serial += int(cyc[:, 8].sum())
+    assert sampled > 0, "no table needed the sample-by-sample proof: the test does not exercise it"
+    assert serial > 0, "no table needed the serial chain: the test does not exercise it"
+
+
 def test_fuzz_random_parameter_sets(pkg, orc_det, scenarios):
     """randomised parameter sets (weights, barrier shapes, bounds, lambda schedule, horizon, vehicle
     model, solve type) on all four scenarios: whole solves incl. decision traces stay bit-exact."""
