@@ -201,7 +201,8 @@ int cilqr_backward_pass_batch(cilqr_handle* h, int32_t B, const double* u, const
                               const int32_t* param_id, const int32_t* tick, double* d, double* K,
                               double* dV, int32_t* status);
 /* elementary functions as evaluated on the device (csrc/detmath.h):
- * func 0 exp, 1 sin, 2 cos, 3 tan, 4 atan, 5 hypot(x,y), 6 x/y, 7 sqrt(|x|) */
+ * func 0 exp, 1 sin, 2 cos, 3 tan, 4 atan, 5 hypot(x,y), 6 x/y, 7 sqrt(|x|),
+ * 8 sin, 9 cos, 10 tan in the register flavour the rollout uses (same values) */
 int cilqr_detmath_eval(cilqr_handle* h, int32_t func, const double* x, const double* y, int32_t n,
                        double* out);
 

@@ -54,6 +54,17 @@ def test_detmath_device_bitexact(pkg, orc_det, engines):
         x = rng.uniform(lo, hi, 20000)
         x[:8] = [0.0, np.nan, np.inf, -np.inf, 1e300, -1e-310, 5e-324, -0.0]
         eq_bits(eng.detmath(f, x), orc_det.math(names[f], x), names[f])
+    # the wave-uniform shortcuts (every lane of a wavefront below pi/4, resp. 7/16): whole arrays of small
+    # arguments take them, arrays that straddle the thresholds take both paths inside one launch
+    edge = np.array([0.785, np.nextafter(0.785, 0), np.nextafter(0.785, 1), np.pi / 4, 0.4375,
+                     np.nextafter(0.4375, 0), np.nextafter(0.4375, 1), 0.0, -0.0, 5e-324, -5e-324, 1e-300])
+    small = np.concatenate([rng.uniform(-0.78, 0.78, 8192), np.tile(np.concatenate([edge, -edge]), 4),
+                            rng.uniform(-0.43, 0.43, 8192), rng.uniform(-0.9, 0.9, 4096)])
+    for f, nm in ((1, "sin"), (2, "cos"), (3, "tan"), (4, "atan"), (8, "sin"), (9, "cos"), (10, "tan")):
+        eq_bits(eng.detmath(f, small), orc_det.math(nm, small), f"{nm} (small arguments, code {f})")
+    big = rng.uniform(-1e4, 1e4, 20000)
+    for f, nm in ((8, "sin"), (9, "cos"), (10, "tan")):
+        eq_bits(eng.detmath(f, big), orc_det.math(nm, big), f"{nm} (pinned coefficients)")
     x, y = rng.uniform(-300, 300, 20000), rng.uniform(-300, 300, 20000)
     eq_bits(eng.detmath(5, x, y), orc_det.math("hypot", x, y), "hypot")
     eq_bits(eng.detmath(6, x, y), x / y, "div")

@@ -67,11 +67,11 @@ enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST
         }                                                             \
     } while (0)
 
-__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b) {
+__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l, int lane) {
     int pid = a.param_id ? a.param_id[b] : 0;
     int sid = a.scenario_id ? a.scenario_id[b] : 0;
     int tk = a.tick ? a.tick[b] : 0;
-    make_cst(c, a.params[pid], a.scenes[sid], tk);
+    make_cst(c, a.params[pid], a.scenes[sid], tk, l.ck, lane);
 }
 
 // CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
@@ -97,11 +97,11 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
     if (b >= a.B) return;
-    Cst c;
-    load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N; // one horizon per handle
     Lds l;
     carve(l, g_lds, N, a.W, ALM ? 1 : 0);
+    Cst c;
+    load_cst(c, a, b, l, lane);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
     AlmSt al = load_alm(a, b, N);
     if (HELP && wave == 1) {
@@ -131,7 +131,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     }
     if (ALM && last_u == nullptr) {
         // cs:88-93: fresh multipliers unless this call continues a previous solution
-        al.rho = c.alm_rho_init;
+        al.rho = c.k->alm_rho_init;
         for (int e = lane; e < N * al.C; e += CILQR_WAVE) { al.mu[e] = 0.0; al.mu_next[e] = 0.0; }
         wave_sync();
     }
@@ -150,7 +150,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         __syncthreads(); // B0
     }
 
-    double lamb = c.init_lamb;
+    double lamb = c.k->init_lamb;
     int status = CILQR_RUNNING;
     int iters = 0, ls_trials = 0, cost_evals = 1, tl = 0;
     int end_reason = CILQR_END_MAX_ITER;
@@ -220,13 +220,13 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     trials++;
                     const double decay = J_cur - new_J;
                     const double adecay = (decay < 0) ? -decay : decay;
-                    if (t == 0 && adecay < c.conv_thr) {
+                    if (t == 0 && adecay < c.k->conv_thr) {
                         status = CILQR_CONVERGED;
                         alpha_idx = t;
                         done = true;
                     } else {
                         const double approx = -(alpha * alpha * dV[0] + alpha * dV[1]);
-                        if (decay > 0.0 && (approx < 0.0 || decay / approx > c.accept_thr)) {
+                        if (decay > 0.0 && (approx < 0.0 || decay / approx > c.k->accept_thr)) {
                             if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
                             flag = 1;
                             alpha_idx = t;
@@ -247,8 +247,8 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 status = CILQR_FORWARD_PASS_FAIL;
                 if (ALM) { // cs:377-378
                     for (int e = lane; e < N * al.C; e += CILQR_WAVE) al.mu[e] = al.mu_next[e];
-                    double r = (1 + c.alm_gamma) * al.rho;
-                    al.rho = (c.max_rho < r) ? c.max_rho : r;
+                    double r = (1 + c.k->alm_gamma) * al.rho;
+                    al.rho = (c.k->max_rho < r) ? c.k->max_rho : r;
                     wave_sync();
                 }
             }
@@ -258,10 +258,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         ls_trials += trials;
         cost_evals += trials;
         if (status == CILQR_BACKWARD_PASS_FAIL || status == CILQR_FORWARD_PASS_FAIL) {
-            double la = lamb * c.lamb_amplify;
-            lamb = (c.lamb_amplify < la) ? la : c.lamb_amplify;
+            double la = lamb * c.k->lamb_amplify;
+            lamb = (c.k->lamb_amplify < la) ? la : c.k->lamb_amplify;
         } else if (status == CILQR_RUNNING) {
-            lamb *= c.lamb_decay;
+            lamb *= c.k->lamb_decay;
         }
         if (trace_out && tl < trace_cap && lane == 0) {
             cilqr_trace_rec r;
@@ -271,7 +271,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         }
         tl++;
         bool leave = false;
-        if (lamb > c.max_lamb) { end_reason = CILQR_END_MAX_LAMB; leave = true; }
+        if (lamb > c.k->max_lamb) { end_reason = CILQR_END_MAX_LAMB; leave = true; }
         else if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; leave = true; }
         if (HELP) {
             if (lane == 0) l.ctli[CTL_EXIT] = (leave || itr + 1 >= c.max_iter) ? 1 : 0;
@@ -318,9 +318,9 @@ __device__ inline void stage_xu(const Lds& l, int N, const double* x, const doub
 __global__ void __launch_bounds__(CILQR_WAVE)
 k_init_traj(BatchArgs a, const double* __restrict__ x0, double* __restrict__ x_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
     init_trajectory(c, l, xs, nullptr, lane, idx0, a.W);
@@ -331,9 +331,9 @@ __global__ void __launch_bounds__(CILQR_WAVE)
 k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref_out,
              int32_t* __restrict__ idx_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), nullptr, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
@@ -350,9 +350,9 @@ __global__ void __launch_bounds__(CILQR_WAVE)
 k_total_cost(BatchArgs a, const double* __restrict__ u, const double* __restrict__ x,
              double* __restrict__ J_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), u + (size_t)b * 2 * N, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
@@ -367,10 +367,10 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
                const double* __restrict__ d, const double* __restrict__ K, int n_alpha,
                double* __restrict__ new_u, double* __restrict__ new_x, double* __restrict__ J_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     const int R = N + 1;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.kd[CILQR_KD * (e >> 3) + CILQR_KD_K(e & 7)] = K[(size_t)b * 8 * N + e];
     for (int e = lane; e < 2 * N; e += CILQR_WAVE) l.kd[CILQR_KD * (e >> 1) + CILQR_KD_D(e & 1)] = d[(size_t)b * 2 * N + e];
@@ -402,10 +402,10 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
                    double* __restrict__ o_lx, double* __restrict__ o_lu, double* __restrict__ o_lxx,
                    double* __restrict__ o_luu, double* __restrict__ o_A, double* __restrict__ o_B) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     const int R = N + 1;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
@@ -449,10 +449,10 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
                 const double* __restrict__ lamb, double* __restrict__ o_d, double* __restrict__ o_K,
                 double* __restrict__ o_dV, int32_t* __restrict__ o_status) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    Cst c; load_cst(c, a, b);
-    const int N = c.N;
+    const int N = a.N;
     const int R = N + 1;
     Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W);
@@ -506,6 +506,9 @@ __global__ void k_detmath(int f, const double* __restrict__ x, const double* __r
         case 5: r = dm_hypot(a, b); break;
         case 6: r = a / b; break;
         case 7: r = dm_sqrt(a < 0 ? -a : a); break;
+        case 8: r = dm_sin<1>(a); break;  // the flavours with coefficients pinned to vector registers
+        case 9: r = dm_cos<1>(a); break;
+        case 10: r = dm_tan<1>(a); break;
         default: break;
     }
     o[i] = r;
@@ -1245,7 +1248,7 @@ extern "C" int cilqr_backward_pass_batch(cilqr_handle* h, int32_t B, const doubl
 
 extern "C" int cilqr_detmath_eval(cilqr_handle* h, int32_t func, const double* x, const double* y,
                                   int32_t n, double* out) {
-    if (!h || !x || !out || n < 1 || func < 0 || func > 7) return fail(CILQR_ERR_BAD_ARG, "bad argument");
+    if (!h || !x || !out || n < 1 || func < 0 || func > 10) return fail(CILQR_ERR_BAD_ARG, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const double *d_x, *d_y = nullptr;
     int rc = up(h, 3, x, sizeof(double) * n, &d_x); if (rc) return rc;

@@ -58,10 +58,11 @@ struct DevScene {
     double cert_rcap, cert_smax; // convexity certificate of the lane table (see convex_interior), filled by the host
 };
 
-// wave-uniform constants of one trajectory
-struct Cst {
-    int N, rp, M, L, T, tick, max_iter, pad;
-    double dt, wb, half_wb;
+// Wave-uniform constants of one trajectory.  The few that the serial sweeps and the control flow use
+// travel by value (scalar registers); the cost model's constants sit in LDS (CstK) and are read where a
+// cost or a derivative is evaluated — as one struct by value they would claim ~100 scalar registers for
+// the whole solve and keep the register allocator spilling around every loop.
+struct CstK {
     double w_pos, w_vel, w_yaw, w_acc, w_stl;
     double sq1, sq2, oq1, oq2;
     double acc_max, acc_min, stl_lim, velo_max, velo_min;
@@ -71,32 +72,51 @@ struct Cst {
     double cert_rcap, cert_smax;
     double init_lamb, lamb_decay, lamb_amplify, max_lamb, conv_thr, accept_thr;
     double alm_rho_init, alm_gamma, max_rho, max_mu;
+    double pad;
+};
+#define CILQR_CSTK_DOUBLES ((int)(sizeof(CstK) / sizeof(double)))
+
+struct Cst {
+    int N, rp, M, L, T, tick, max_iter, pad;
+    double dt, wb, half_wb;
     gdouble* lane_xy;
     gdouble* lane_aux;
     gdouble* obs;
+    const CstK* k;
 };
 
-__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick) {
+// fills the by-value part on every lane and, from lane 0, the LDS part at `ck` (followed by a wave_sync:
+// both wavefronts of a helper-mode block do this, writing identical values)
+__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane);
+
+__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane) {
     c.N = p.N; c.rp = p.reference_point; c.M = s.M; c.L = s.L; c.T = s.T; c.tick = tick;
-    c.max_iter = p.max_iter;
+    c.max_iter = p.max_iter; c.pad = 0;
     c.dt = p.dt; c.wb = p.wheelbase; c.half_wb = 0.5 * p.wheelbase;
-    c.w_pos = p.w_pos; c.w_vel = p.w_vel; c.w_yaw = p.w_yaw; c.w_acc = p.w_acc; c.w_stl = p.w_stl;
-    c.sq1 = p.state_exp_q1; c.sq2 = p.state_exp_q2; c.oq1 = p.obstacle_exp_q1; c.oq2 = p.obstacle_exp_q2;
-    c.acc_max = p.acc_max; c.acc_min = p.acc_min; c.stl_lim = p.stl_lim;
-    c.velo_max = p.velo_max; c.velo_min = p.velo_min;
-    c.pos_up_b = s.border_hi - p.width / 2; // cs:239
-    c.pos_lo_b = s.border_lo + p.width / 2; // cs:241
-    // ut:387-393 with obs_attr = {width, length, d_safe} (cs:78) and ego_pnt_radius = 0.5*width (cs:330)
-    double a = 0.5 * p.length + p.d_safe * 6 + 0.5 * p.width;
-    double b = 0.5 * p.width + p.d_safe + 0.5 * p.width;
-    c.ell_a2 = a * a;
-    c.ell_b2 = b * b;
-    c.ref_velo = s.ref_velo;
-    c.cert_rcap = s.cert_rcap; c.cert_smax = s.cert_smax;
-    c.init_lamb = p.init_lamb; c.lamb_decay = p.lamb_decay; c.lamb_amplify = p.lamb_amplify;
-    c.max_lamb = p.max_lamb; c.conv_thr = p.convergence_threshold; c.accept_thr = p.accept_step_threshold;
-    c.alm_rho_init = p.alm_rho_init; c.alm_gamma = p.alm_gamma; c.max_rho = p.max_rho; c.max_mu = p.max_mu;
     c.lane_xy = (gdouble*)s.lane_xy; c.lane_aux = (gdouble*)s.lane_aux; c.obs = (gdouble*)s.obs;
+    c.k = ck;
+    if (lane == 0) {
+        CstK k;
+        k.w_pos = p.w_pos; k.w_vel = p.w_vel; k.w_yaw = p.w_yaw; k.w_acc = p.w_acc; k.w_stl = p.w_stl;
+        k.sq1 = p.state_exp_q1; k.sq2 = p.state_exp_q2; k.oq1 = p.obstacle_exp_q1; k.oq2 = p.obstacle_exp_q2;
+        k.acc_max = p.acc_max; k.acc_min = p.acc_min; k.stl_lim = p.stl_lim;
+        k.velo_max = p.velo_max; k.velo_min = p.velo_min;
+        k.pos_up_b = s.border_hi - p.width / 2; // cs:239
+        k.pos_lo_b = s.border_lo + p.width / 2; // cs:241
+        // ut:387-393 with obs_attr = {width, length, d_safe} (cs:78) and ego_pnt_radius = 0.5*width (cs:330)
+        double a = 0.5 * p.length + p.d_safe * 6 + 0.5 * p.width;
+        double b = 0.5 * p.width + p.d_safe + 0.5 * p.width;
+        k.ell_a2 = a * a;
+        k.ell_b2 = b * b;
+        k.ref_velo = s.ref_velo;
+        k.cert_rcap = s.cert_rcap; k.cert_smax = s.cert_smax;
+        k.init_lamb = p.init_lamb; k.lamb_decay = p.lamb_decay; k.lamb_amplify = p.lamb_amplify;
+        k.max_lamb = p.max_lamb; k.conv_thr = p.convergence_threshold; k.accept_thr = p.accept_step_threshold;
+        k.alm_rho_init = p.alm_rho_init; k.alm_gamma = p.alm_gamma; k.max_rho = p.max_rho; k.max_mu = p.max_mu;
+        k.pad = 0.0;
+        *ck = k;
+    }
+    wave_sync();
 }
 
 // LDS carve-out for one trajectory (offsets in doubles).  l_xx keeps the 7 entries that can be
@@ -111,6 +131,7 @@ struct Lds {
     double* lxx; // [(N+1)][lxs]: 7 packed entries (barrier mode: symmetric) or 16 dense (ALM mode)
     int lxs;
     double* luu; // [N][2]
+    CstK* ck;    // the cost model's constants (see Cst)
     double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
     double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier.  ALIASES kd: the gains
                  // are dead once the rollout has produced the trial trajectories, and costs are only summed then
@@ -136,7 +157,7 @@ struct Lds {
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
-    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + 4;
+    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + 4 + CILQR_CSTK_DOUBLES;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
     return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
@@ -155,6 +176,7 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.xch = p; p += CILQR_XCH;
     l.cs = l.kd; // 10 N doubles >= CILQR_NT * 3 * (N + 1) for every N >= 2
     l.ctld = p; p += 4;
+    l.ck = reinterpret_cast<CstK*>(p); p += CILQR_CSTK_DOUBLES;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
     l.tidx = l.ridx + (N + 2);
@@ -196,26 +218,58 @@ __host__ __device__ inline size_t scratch_doubles(int N) {
 
 // ---------------------------------------------------------------------------------------------
 // ut:262-283 kinematic_propagate
-template <int RP>
+// TRIG = flavour of the elementary functions (detmath.h: DM_PIN, DM_NOSHORT, DM_SMALL)
+template <int RP, int TRIG = 0>
 __device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4]) {
     if (RP == 0) {
         double sn, cs;
-        dm_sincos<1>(x[3], &sn, &cs);
-        double tn = dm_tan<1>(u[1]);
+        dm_sincos<TRIG>(x[3], &sn, &cs);
+        double tn = dm_tan<TRIG>(u[1]);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
         xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
     } else {
-        double beta = dm_atan(dm_tan<1>(u[1]) / 2);
+        double beta = dm_atan<TRIG>(dm_tan<TRIG>(u[1]) / 2);
         double sn, cs;
-        dm_sincos<1>(beta + x[3], &sn, &cs);
-        double sb = dm_sin<1>(beta);
+        dm_sincos<TRIG>(beta + x[3], &sn, &cs);
+        double sb = dm_sin<TRIG>(beta);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
         xn[3] = x[3] + 2 * x[2] * sb * c.dt / c.wb;
     }
+}
+
+// The same step for small angles on every active lane, straight-line: all range reductions and
+// interval selections are known to be the identity (detmath.h, DM_SMALL).  The caller has checked
+// |yaw| < 0.785 and |steer| < 0.7 (so |tan(steer)| / 2 < 0.4375 and |beta| < 0.42); for the CoG model the
+// angle beta + yaw is only known here: returns false, with xn untouched, when it is not small on
+// some lane — the caller then redoes the step the general way.
+template <int RP>
+__device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4]) {
+    constexpr int T = DM_PIN | DM_SMALL;
+    if (RP == 0) {
+        double sn, cs;
+        dm_sincos<T>(x[3], &sn, &cs);
+        double tn = dm_tan<T>(u[1]);
+        xn[0] = x[0] + x[2] * cs * c.dt;
+        xn[1] = x[1] + x[2] * sn * c.dt;
+        xn[2] = x[2] + u[0] * c.dt;
+        xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
+    } else {
+        double beta = dm_atan<T>(dm_tan<T>(u[1]) / 2);
+        const double ang = beta + x[3];
+        if (!DM_WAVE_ALL(__builtin_fabs(ang) < 0.785)) return false;
+        double sn, cs;
+        dm_sincos<T>(ang, &sn, &cs);
+        double sb = dm_sin<T>(beta);
+        xn[0] = x[0] + x[2] * cs * c.dt;
+        xn[1] = x[1] + x[2] * sn * c.dt;
+        xn[2] = x[2] + u[0] * c.dt;
+        xn[3] = x[3] + 2 * x[2] * sb * c.dt / c.wb;
+    }
+    return true;
 }
 
 // cs:295-311 for row 0 (start_index = 0): all 64 lanes evaluate consecutive candidates.
@@ -369,7 +423,7 @@ __device__ inline bool verify_window_fast(const Lds& l, double px, double py, in
 // their square roots (2^-50), so the reference's comparison hypot(j+1) < hypot(j) holds at every j in
 // [a, b-2] without being evaluated.  A `false` only means "not proven this way" (kinked lane, far point, NaN).
 __device__ inline bool convex_interior(const Cst& c, double q_b, int a, int b) {
-    const double lim = c.cert_rcap - (double)(b - a + 1) * c.cert_smax;
+    const double lim = c.k->cert_rcap - (double)(b - a + 1) * c.k->cert_smax;
     return (lim > 0.0) && (q_b <= lim * lim);
 }
 
@@ -422,11 +476,11 @@ __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double s
     double drx = rx - ob[0], dry = ry - ob[1];
     double fX = co * dfx + so * dfy, fY = (-so) * dfx + co * dfy;
     double rX = co * drx + so * dry, rY = (-so) * drx + co * dry;
-    o.mf = 1 - ((fX * fX) / c.ell_a2 + (fY * fY) / c.ell_b2);
-    o.mr = 1 - ((rX * rX) / c.ell_a2 + (rY * rY) / c.ell_b2);
+    o.mf = 1 - ((fX * fX) / c.k->ell_a2 + (fY * fY) / c.k->ell_b2);
+    o.mr = 1 - ((rX * rX) / c.k->ell_a2 + (rY * rY) / c.k->ell_b2);
     if (GRAD) {
-        double f0 = -2 * fX / c.ell_a2, f1 = -2 * fY / c.ell_b2;
-        double r0 = -2 * rX / c.ell_a2, r1 = -2 * rY / c.ell_b2;
+        double f0 = -2 * fX / c.k->ell_a2, f1 = -2 * fY / c.k->ell_b2;
+        double r0 = -2 * rX / c.k->ell_a2, r1 = -2 * rY / c.k->ell_b2;
         double gfx = co * f0 + (-so) * f1, gfy = so * f0 + co * f1;
         double grx = co * r0 + (-so) * r1, gry = so * r0 + co * r1;
         double f30, f31, r30, r31;
@@ -471,19 +525,19 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
     lane_point(c, l, ridx, rx, ry);
     gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
     const double ryaw = aux[0], sr = aux[1], cr = aux[2];
-    double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.ref_velo, e3 = xk[3] - ryaw;
-    sd = (((e0 * c.w_pos) * e0 + (e1 * c.w_pos) * e1) + (e2 * c.w_vel) * e2) + (e3 * c.w_yaw) * e3;
+    double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.k->ref_velo, e3 = xk[3] - ryaw;
+    sd = (((e0 * c.k->w_pos) * e0 + (e1 * c.k->w_pos) * e1) + (e2 * c.k->w_vel) * e2) + (e3 * c.k->w_yaw) * e3;
     ce = 0.0;
-    if (k < c.N) ce = (uk[0] * c.w_acc) * uk[0] + (uk[1] * c.w_stl) * uk[1];
+    if (k < c.N) ce = (uk[0] * c.k->w_acc) * uk[0] + (uk[1] * c.k->w_stl) * uk[1];
     jb = 0.0;
     if (k >= 1) {
-        double acc_up = ukm1[0] - c.acc_max, acc_lo = c.acc_min - ukm1[0];
-        double stl_up = ukm1[1] - c.stl_lim, stl_lo = -c.stl_lim - ukm1[1];
-        double vel_up = xk[2] - c.velo_max, vel_lo = c.velo_min - xk[2];
+        double acc_up = ukm1[0] - c.k->acc_max, acc_lo = c.k->acc_min - ukm1[0];
+        double stl_up = ukm1[1] - c.k->stl_lim, stl_lo = -c.k->stl_lim - ukm1[1];
+        double vel_up = xk[2] - c.k->velo_max, vel_lo = c.k->velo_min - xk[2];
         double d_sign = e1 * cr - e0 * sr;
         double hyp = dm_hypot(e0, e1);
         double cur_d = (d_sign < 0) ? -hyp : hyp;
-        double pos_up = cur_d - c.pos_up_b, pos_lo = c.pos_lo_b - cur_d;
+        double pos_up = cur_d - c.k->pos_up_b, pos_lo = c.k->pos_lo_b - cur_d;
         const double* mu = ALM ? (al.mu + (size_t)(k - 1) * al.C) : nullptr;
         double j;
         if (ALM) {
@@ -495,19 +549,19 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
             j = j + alm_item(pos_up, al.rho, mu[6]);
             j = j + alm_item(pos_lo, al.rho, mu[7]);
         } else {
-            j = c.sq1 * dm_exp(c.sq2 * acc_up) + c.sq1 * dm_exp(c.sq2 * acc_lo);
+            j = c.k->sq1 * dm_exp(c.k->sq2 * acc_up) + c.k->sq1 * dm_exp(c.k->sq2 * acc_lo);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * stl_up);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * stl_up);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * stl_lo);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * stl_lo);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * vel_up);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * vel_up);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * vel_lo);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * vel_lo);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * pos_up);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * pos_up);
             CILQR_SCHED_FENCE();
-            j = j + c.sq1 * dm_exp(c.sq2 * pos_lo);
+            j = j + c.k->sq1 * dm_exp(c.k->sq2 * pos_lo);
             CILQR_SCHED_FENCE();
         }
         double sy, cy;
@@ -519,8 +573,8 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
                 j = j + alm_item(t.mf, al.rho, mu[8 + 2 * o]);
                 j = j + alm_item(t.mr, al.rho, mu[9 + 2 * o]);
             } else {
-                j = j + c.oq1 * dm_exp(c.oq2 * t.mf);
-                j = j + c.oq1 * dm_exp(c.oq2 * t.mr);
+                j = j + c.k->oq1 * dm_exp(c.k->oq2 * t.mf);
+                j = j + c.k->oq1 * dm_exp(c.k->oq2 * t.mr);
             }
         }
         jb = j;
@@ -807,42 +861,88 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
         const size_t CS = (size_t)R * CILQR_MAX_ALPHA_TRIALS; // component stride
         double* tx = &TR(t, 0, 1);   // x' components at strides CS
         double* tu = &TR(t, 4, 0);   // u' components
-        // the gains and the nominal point of step i + 1 are fetched from LDS while step i computes
-        double kq[CILQR_KD], xq[4], uq[2];
-#pragma unroll
-        for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xq[e] = xi[e];
-        uq[0] = ui[0]; uq[1] = ui[1];
-        for (int i = 0; i < N; ++i) {
-            double kk[CILQR_KD], xr[4], ur[2];
-#pragma unroll
-            for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xr[e] = xq[e];
-            ur[0] = uq[0]; ur[1] = uq[1];
-            if (i + 1 < N) { Ki += CILQR_KD; xi += 4; ui += 2; }
+        // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
+        // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
+        // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
+        // general loop, which finishes the horizon.
+        // In both, the gains and the nominal point of step i + 1 are fetched from LDS while step i computes.
+        int i = 0;
+        {
+            double kq[CILQR_KD], xq[4], uq[2];
 #pragma unroll
             for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[e];
 #pragma unroll
             for (int e = 0; e < 4; ++e) xq[e] = xi[e];
             uq[0] = ui[0]; uq[1] = ui[1];
-            double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
-            double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
-            double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
-            double un[2];
-            un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
-            un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
-            double xn[4];
-            propagate<RP>(c, xc, un, xn);
-            tu[0] = un[0];
-            tu[CS] = un[1];
-            tx[0] = xn[0];
-            tx[CS] = xn[1];
-            tx[2 * CS] = xn[2];
-            tx[3 * CS] = xn[3];
-            xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-            tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+            for (; i < N; ++i) {
+                double kk[CILQR_KD], xr[4], ur[2];
+#pragma unroll
+                for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[e] = xq[e];
+                ur[0] = uq[0]; ur[1] = uq[1];
+                const int nx = (i + 1 < N) ? i + 1 : i;
+#pragma unroll
+                for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * nx + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xq[e] = xi[4 * nx + e];
+                uq[0] = ui[2 * nx]; uq[1] = ui[2 * nx + 1];
+                double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
+                double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
+                double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
+                double un[2];
+                un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
+                un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
+                if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) break;
+                double xn[4];
+                if (!propagate_small<RP>(c, xc, un, xn)) break;
+                tu[0] = un[0];
+                tu[CS] = un[1];
+                tx[0] = xn[0];
+                tx[CS] = xn[1];
+                tx[2 * CS] = xn[2];
+                tx[3 * CS] = xn[3];
+                xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+                tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+            }
+        }
+        if (i < N) {
+            double kq[CILQR_KD], xq[4], uq[2];
+#pragma unroll
+            for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * i + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = xi[4 * i + e];
+            uq[0] = ui[2 * i]; uq[1] = ui[2 * i + 1];
+            for (; i < N; ++i) {
+                double kk[CILQR_KD], xr[4], ur[2];
+#pragma unroll
+                for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[e] = xq[e];
+                ur[0] = uq[0]; ur[1] = uq[1];
+                const int nx = (i + 1 < N) ? i + 1 : i;
+#pragma unroll
+                for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * nx + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xq[e] = xi[4 * nx + e];
+                uq[0] = ui[2 * nx]; uq[1] = ui[2 * nx + 1];
+                double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
+                double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
+                double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
+                double un[2];
+                un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
+                un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
+                double xn[4];
+                propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn);
+                tu[0] = un[0];
+                tu[CS] = un[1];
+                tx[0] = xn[0];
+                tx[CS] = xn[1];
+                tx[2 * CS] = xn[2];
+                tx[3 * CS] = xn[3];
+                xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+                tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+            }
         }
     }
     wave_sync();
@@ -884,7 +984,7 @@ __device__ inline double alm_slope(double cv, double rho, double mu) {
 __device__ inline double alm_next_mu(const Cst& c, double mu, double rho, double cv) {
     double v = mu + rho * cv;
     v = (v > 0.0) ? v : 0.0;
-    v = (c.max_mu < v) ? c.max_mu : v;
+    v = (c.k->max_mu < v) ? c.k->max_mu : v;
     return v;
 }
 
@@ -952,9 +1052,9 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
         lane_point(c, l, ridx, rx, ry);
         gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
         const double ryaw = aux[0], sr = aux[1], cr = aux[2];
-        double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.ref_velo, e3 = xk[3] - ryaw;
+        double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.k->ref_velo, e3 = xk[3] - ryaw;
         // prime parts (cs:493-494)
-        double lx0 = (2 * e0) * c.w_pos, lx1 = (2 * e1) * c.w_pos, lx2 = (2 * e2) * c.w_vel, lx3 = (2 * e3) * c.w_yaw;
+        double lx0 = (2 * e0) * c.k->w_pos, lx1 = (2 * e1) * c.k->w_pos, lx2 = (2 * e2) * c.k->w_vel, lx3 = (2 * e3) * c.k->w_yaw;
         double h00 = 0, h01 = 0, h03 = 0, h11 = 0, h13 = 0, h33 = 0, h22 = 0; // barrier Hessian
         double b0 = 0, b1 = 0, b2 = 0, b3 = 0;                                 // barrier gradient
         double sy, cy;
@@ -968,18 +1068,18 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             const double d_sign = e1 * cr - e0 * sr;
             const double hyp = dm_hypot(e0, e1);
             const double cur_d = (d_sign < 0) ? -hyp : hyp;
-            const double cv[8] = {um0 - c.acc_max, c.acc_min - um0, um1 - c.stl_lim, -c.stl_lim - um1,
-                                  xk[2] - c.velo_max, c.velo_min - xk[2], cur_d - c.pos_up_b, c.pos_lo_b - cur_d};
+            const double cv[8] = {um0 - c.k->acc_max, c.k->acc_min - um0, um1 - c.k->stl_lim, -c.k->stl_lim - um1,
+                                  xk[2] - c.k->velo_max, c.k->velo_min - xk[2], cur_d - c.k->pos_up_b, c.k->pos_lo_b - cur_d};
             double sl[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 sl[j] = alm_slope(cv[j], rho, mu[j]);
                 mun[j] = alm_next_mu(c, mu[j], rho, cv[j]);
             }
-            l.lu[2 * (k - 1)] = 2 * (um0 * c.w_acc) + (sl[0] - sl[1]);
-            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.w_stl) + (sl[2] - sl[3]);
-            l.luu[2 * (k - 1)] = 2 * c.w_acc + (sl[0] + sl[1]);
-            l.luu[2 * (k - 1) + 1] = 2 * c.w_stl + (sl[2] + sl[3]);
+            l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + (sl[0] - sl[1]);
+            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + (sl[2] - sl[3]);
+            l.luu[2 * (k - 1)] = 2 * c.k->w_acc + (sl[0] + sl[1]);
+            l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + (sl[2] + sl[3]);
             double px = e0 / hyp, py = e1 / hyp;
             if (d_sign < 0) { px = -px; py = -py; }
             const double nx = -px, ny = -py;
@@ -1021,59 +1121,59 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             // control bounds (cs:510-513, 537-558)
             // (the scheduling fences keep the eight independent exp chains from being interleaved: that
             //  would only raise the register count — the wave is issue-bound, not latency-bound, here)
-            double b_au = c.sq1 * dm_exp(c.sq2 * (um0 - c.acc_max));
+            double b_au = c.k->sq1 * dm_exp(c.k->sq2 * (um0 - c.k->acc_max));
             CILQR_SCHED_FENCE();
-            double b_al = c.sq1 * dm_exp(c.sq2 * (c.acc_min - um0));
+            double b_al = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->acc_min - um0));
             CILQR_SCHED_FENCE();
-            double b_su = c.sq1 * dm_exp(c.sq2 * (um1 - c.stl_lim));
+            double b_su = c.k->sq1 * dm_exp(c.k->sq2 * (um1 - c.k->stl_lim));
             CILQR_SCHED_FENCE();
-            double b_sl = c.sq1 * dm_exp(c.sq2 * (-c.stl_lim - um1));
+            double b_sl = c.k->sq1 * dm_exp(c.k->sq2 * (-c.k->stl_lim - um1));
             CILQR_SCHED_FENCE();
-            double q22 = c.sq2 * c.sq2;
-            double lub0 = (c.sq2 * b_au) - (c.sq2 * b_al);
-            double lub1 = (c.sq2 * b_su) - (c.sq2 * b_sl);
+            double q22 = c.k->sq2 * c.k->sq2;
+            double lub0 = (c.k->sq2 * b_au) - (c.k->sq2 * b_al);
+            double lub1 = (c.k->sq2 * b_su) - (c.k->sq2 * b_sl);
             double luub0 = (q22 * b_au) + (q22 * b_al);
             double luub1 = (q22 * b_su) + (q22 * b_sl);
             // l_u = 2 (u R) + barrier, l_uu = 2 R + barrier (cs:491-492, 686-687)
-            l.lu[2 * (k - 1)] = 2 * (um0 * c.w_acc) + lub0;
-            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.w_stl) + lub1;
-            l.luu[2 * (k - 1)] = 2 * c.w_acc + luub0;
-            l.luu[2 * (k - 1) + 1] = 2 * c.w_stl + luub1;
+            l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + lub0;
+            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + lub1;
+            l.luu[2 * (k - 1)] = 2 * c.k->w_acc + luub0;
+            l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + luub1;
             // velocity bounds and road borders (cs:507-533, 560-580)
-            double b_vu = c.sq1 * dm_exp(c.sq2 * (xk[2] - c.velo_max));
+            double b_vu = c.k->sq1 * dm_exp(c.k->sq2 * (xk[2] - c.k->velo_max));
             CILQR_SCHED_FENCE();
-            double b_vl = c.sq1 * dm_exp(c.sq2 * (c.velo_min - xk[2]));
+            double b_vl = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->velo_min - xk[2]));
             CILQR_SCHED_FENCE();
             double d_sign = e1 * cr - e0 * sr;
             double hyp = dm_hypot(e0, e1);
             double cur_d = (d_sign < 0) ? -hyp : hyp;
-            double b_pu = c.sq1 * dm_exp(c.sq2 * (cur_d - c.pos_up_b));
+            double b_pu = c.k->sq1 * dm_exp(c.k->sq2 * (cur_d - c.k->pos_up_b));
             CILQR_SCHED_FENCE();
-            double b_pl = c.sq1 * dm_exp(c.sq2 * (c.pos_lo_b - cur_d));
+            double b_pl = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->pos_lo_b - cur_d));
             CILQR_SCHED_FENCE();
             double px = e0 / hyp, py = e1 / hyp;
             if (d_sign < 0) { px = -px; py = -py; }
             double nx = -px, ny = -py; // pos_lo_constr_over_x = -1 * pos_up_constr_over_x
-            double d_pu = c.sq2 * b_pu, d_pl = c.sq2 * b_pl;
+            double d_pu = c.k->sq2 * b_pu, d_pl = c.k->sq2 * b_pl;
             double s_pu = q22 * b_pu, s_pl = q22 * b_pl;
             b0 = d_pu * px + d_pl * nx;
             b1 = d_pu * py + d_pl * ny;
-            b2 = (c.sq2 * b_vu) - (c.sq2 * b_vl);
+            b2 = (c.k->sq2 * b_vu) - (c.k->sq2 * b_vl);
             b3 = 0.0;
             h00 = s_pu * (px * px) + s_pl * (nx * nx);
             h01 = s_pu * (px * py) + s_pl * (nx * ny);
             h11 = s_pu * (py * py) + s_pl * (ny * ny);
             h22 = (q22 * b_vu) + (q22 * b_vl);
             // obstacles (cs:647-683)
-            double oq22 = c.oq2 * c.oq2;
+            double oq22 = c.k->oq2 * c.k->oq2;
             for (int o = 0; o < c.M; ++o) {
                 ObsOut t;
                 obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
-                double bf = c.oq1 * dm_exp(c.oq2 * t.mf);
+                double bf = c.k->oq1 * dm_exp(c.k->oq2 * t.mf);
                 CILQR_SCHED_FENCE();
-                double br = c.oq1 * dm_exp(c.oq2 * t.mr);
+                double br = c.k->oq1 * dm_exp(c.k->oq2 * t.mr);
                 CILQR_SCHED_FENCE();
-                double df = c.oq2 * bf, dr = c.oq2 * br;
+                double df = c.k->oq2 * bf, dr = c.k->oq2 * br;
                 double sf = oq22 * bf, srr = oq22 * br;
                 b0 = b0 + (df * t.gf[0] + dr * t.gr[0]);
                 b1 = b1 + (df * t.gf[1] + dr * t.gr[1]);
@@ -1092,19 +1192,19 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
         l.lx[4 * k + 3] = lx3 + b3;
         if (ALM) {
             double* hx = l.lxx + 16 * k;
-            hx[0] = 2 * c.w_pos + h00; hx[1] = 0.0 + h01; hx[2] = 0.0; hx[3] = 0.0 + h03;
-            hx[4] = 0.0 + g10; hx[5] = 2 * c.w_pos + h11; hx[6] = 0.0; hx[7] = 0.0 + h13;
-            hx[8] = 0.0; hx[9] = 0.0; hx[10] = 2 * c.w_vel + h22; hx[11] = 0.0;
-            hx[12] = 0.0 + g30; hx[13] = 0.0 + g31; hx[14] = 0.0; hx[15] = 2 * c.w_yaw + h33;
+            hx[0] = 2 * c.k->w_pos + h00; hx[1] = 0.0 + h01; hx[2] = 0.0; hx[3] = 0.0 + h03;
+            hx[4] = 0.0 + g10; hx[5] = 2 * c.k->w_pos + h11; hx[6] = 0.0; hx[7] = 0.0 + h13;
+            hx[8] = 0.0; hx[9] = 0.0; hx[10] = 2 * c.k->w_vel + h22; hx[11] = 0.0;
+            hx[12] = 0.0 + g30; hx[13] = 0.0 + g31; hx[14] = 0.0; hx[15] = 2 * c.k->w_yaw + h33;
         } else {
             double* hx = l.lxx + 7 * k;
-            hx[0] = 2 * c.w_pos + h00;
+            hx[0] = 2 * c.k->w_pos + h00;
             hx[1] = 0.0 + h01;
             hx[2] = 0.0 + h03;
-            hx[3] = 2 * c.w_pos + h11;
+            hx[3] = 2 * c.k->w_pos + h11;
             hx[4] = 0.0 + h13;
-            hx[5] = 2 * c.w_yaw + h33;
-            hx[6] = 2 * c.w_vel + h22;
+            hx[5] = 2 * c.k->w_yaw + h33;
+            hx[6] = 2 * c.k->w_vel + h22;
         }
         if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
     }

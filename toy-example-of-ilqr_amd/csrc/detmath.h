@@ -30,19 +30,26 @@
 
 #define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
-/* DM_K(constant): the trigonometric functions exist in two device flavours, selected by a template
- * argument that only the HIP compilation sees — dm_sincos(x, ..) keeps its coefficients as literals
- * (scalar registers), dm_sincos<1>(x, ..) pins them to vector registers.  Inside the rollout loop the
- * literals (two SGPRs each, ~40 in dm_sincos + dm_tan) overflow the scalar file and are re-materialised
- * and spilled every step; pinned, they are loaded once before the loop.  Same operations, same bits.
- * For the C oracle build all of this expands to the plain function. */
+/* Device flavours of the trigonometric functions, selected by a template argument that only the HIP
+ * compilation sees (for the C oracle build everything below expands to the plain function):
+ *   bit 0 (DM_PIN): coefficients pinned to vector registers instead of scalar-register literals.  Inside
+ *       the rollout loop the literals (two SGPRs each, ~40 in dm_sincos + dm_tan) overflow the scalar file
+ *       and are re-materialised and spilled every step; pinned, they are loaded once before the loop.
+ *   bit 1 (DM_NOSHORT): no wave-uniform small-argument shortcut (see DM_WAVE_ALL below) — for loops that
+ *       have already made that decision themselves and want straight-line code.
+ *   bit 2 (DM_SMALL): the caller guarantees the shortcut's precondition on every active lane (|x| < 0.785
+ *       for sin/cos/tan, |x| < 7/16 for atan): take it without asking.
+ * Same operations, same bits, in every flavour. */
+#define DM_PIN 1
+#define DM_NOSHORT 2
+#define DM_SMALL 4
 #if defined(__HIPCC__)
 #define DM_TFN template <int VK = 0> DM_FN
 #define DM_T(fn) fn<VK>
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int VK>
 static __device__ inline double dm_const(double k) {
-    if (VK) __asm__("" : "+v"(k));
+    if (VK & DM_PIN) __asm__("" : "+v"(k));
     return k;
 }
 #define DM_K(x) dm_const<VK>(x)
@@ -53,6 +60,16 @@ static __device__ inline double dm_const(double k) {
 #define DM_TFN DM_FN
 #define DM_T(fn) fn
 #define DM_K(x) (x)
+#endif
+
+/* Wave-uniform shortcuts (device only).  A shortcut is taken when EVERY active lane qualifies, and it
+ * returns exactly what the general path returns for such arguments — the general path's selects and
+ * range reduction degenerate to the identity there — so host and device still agree bit for bit.
+ * The host always takes the general path. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_WAVE_ALL(cond) (__builtin_amdgcn_ballot_w64(!(cond)) == 0ULL)
+#else
+#define DM_WAVE_ALL(cond) (cond) /* only so that __device__ code parses in hipcc's host pass */
 #endif
 
 DM_FN double dm_from_bits(unsigned long long u) {
@@ -193,6 +210,14 @@ DM_FN double dm_negate_if(double d, int cond) {
 }
 
 DM_TFN void dm_sincos(double x, double* s_out, double* c_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* |x| < 0.785 < pi/4 on every lane: x * (2/pi) < 0.49975, so nd = (v + MAGIC) - MAGIC = 0, r = fma(-0, P, x)
+     * = x (also for x = +-0), quadrant 0, and the quadrant selection / sign flips below are the identity */
+    if ((VK & DM_SMALL) || (!(VK & DM_NOSHORT) && DM_WAVE_ALL(__builtin_fabs(x) < 0.785))) {
+        DM_T(dm_ksincos)(x, s_out, c_out);
+        return;
+    }
+#endif
     int q;
     double r = DM_T(dm_trig_reduce)(x, &q);
     double s, c;
@@ -216,6 +241,13 @@ DM_TFN double dm_cos(double x) {
 }
 
 DM_TFN double dm_tan(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((VK & DM_SMALL) || (!(VK & DM_NOSHORT) && DM_WAVE_ALL(__builtin_fabs(x) < 0.785))) { /* as in dm_sincos: r = x, quadrant 0, tan = sin / cos */
+        double s0, c0;
+        DM_T(dm_ksincos)(x, &s0, &c0);
+        return s0 / c0;
+    }
+#endif
     int q;
     double r = DM_T(dm_trig_reduce)(x, &q);
     double s, c;
@@ -225,7 +257,7 @@ DM_TFN double dm_tan(double x) {
     return dm_negate_if(num, q & 1) / den;
 }
 
-DM_FN double dm_atan(double x) {
+DM_TFN double dm_atan(double x) {
     const double aT0 = 3.33333333333329318027e-01;
     const double aT1 = -1.99999999998764832476e-01;
     const double aT2 = 1.42857142725034663711e-01;
@@ -238,13 +270,21 @@ DM_FN double dm_atan(double x) {
     const double aT9 = -3.65315727442169155270e-02;
     const double aT10 = 1.62858201153657823623e-02;
     double ax = (x < 0.0) ? -x : x;
-    /* interval selection (fdlibm s_atan.c): 7/16, 11/16, 19/16, 39/16 */
     int id = -1;
+    double hi = 0.0, lo = 0.0, t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* every lane below 7/16: the general path selects id = -1, num = ax, den = 1, t = ax / 1 = ax */
+    if ((VK & DM_SMALL) || (!(VK & DM_NOSHORT) && DM_WAVE_ALL(ax < 0.4375))) {
+        t = ax;
+    } else
+#endif
+    {
+    /* interval selection (fdlibm s_atan.c): 7/16, 11/16, 19/16, 39/16 */
     id = (ax >= 0.4375) ? 0 : id;
     id = (ax >= 0.6875) ? 1 : id;
     id = (ax >= 1.1875) ? 2 : id;
     id = (ax >= 2.4375) ? 3 : id;
-    double num = ax, den = 1.0, hi = 0.0, lo = 0.0;
+    double num = ax, den = 1.0;
     num = (id == 0) ? (2.0 * ax - 1.0) : num;
     den = (id == 0) ? (2.0 + ax) : den;
     hi = (id == 0) ? 4.63647609000806093515e-01 : hi;
@@ -261,7 +301,8 @@ DM_FN double dm_atan(double x) {
     den = (id == 3) ? ax : den;
     hi = (id == 3) ? 1.57079632679489655800e+00 : hi;
     lo = (id == 3) ? 6.12323399573676603587e-17 : lo;
-    double t = num / den; /* for id == -1 this is ax / 1.0 == ax exactly */
+    t = num / den; /* for id == -1 this is ax / 1.0 == ax exactly */
+    }
     double z = t * t;
     double w = z * z;
     double s1 = DM_FMA(w, aT10, aT8);
