@@ -1434,6 +1434,24 @@ __device__ inline double dpp_move(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
 }
+// the same move, taken only by the lanes of the banks in BANKS (bank = (lane % 16) / 4); the others keep v
+template <int CTRL, int BANKS>
+__device__ inline double dpp_move_banks(double v) {
+    const unsigned long long u = dm_to_bits(v);
+    int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, BANKS, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, BANKS, false);
+    return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// LDS byte address of a pointer into the block's LDS, made opaque to the optimiser: kept in a register and
+// stepped there, instead of being rebuilt every step as (relocated base + offset)
+typedef const double __attribute__((address_space(3))) lds_cdouble;
+__device__ inline unsigned lds_addr(const double* p) {
+    unsigned a = (unsigned)(size_t)(lds_cdouble*)p;
+    __asm__("" : "+v"(a));
+    return a;
+}
+__device__ inline double lds_load(unsigned a) { return *(lds_cdouble*)(size_t)a; }
 // value of lane `src` (any lane of the wave, per-lane choice): ds_bpermute, no LDS memory involved
 __device__ inline double lane_gather(double v, int src) {
     const unsigned long long u = dm_to_bits(v);
@@ -1478,31 +1496,33 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     const int r4 = rp & 3;
     const int src_c0 = 32 + wc, src_c1 = 40 + wc;   // (Q_ux | Q_u)[0][c], [1][c]
     const int src_r0 = 32 + r4, src_r1 = 40 + r4;   // Q_ux[0][r], [1][r]
-    // this lane's ten coefficient addresses walk backwards with the step
-    const double* pm1[4];
-    const double* pm2[4];
+    // this lane's ten coefficient addresses (LDS byte addresses) walk backwards with the step
+    unsigned am1[4], am2[4], dm1[4], dm2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pm1[k] = base + mp.m1[k] + mp.s1[k] * (N - 1);
-        pm2[k] = base + mp.m2[k] + mp.s2[k] * (N - 1);
+        am1[k] = lds_addr(base + mp.m1[k] + mp.s1[k] * (N - 1));
+        am2[k] = lds_addr(base + mp.m2[k] + mp.s2[k] * (N - 1));
+        dm1[k] = 8u * (unsigned)mp.s1[k];
+        dm2[k] = 8u * (unsigned)mp.s2[k];
     }
-    const double* plq = base + mp.lq + mp.slq * (N - 1);
-    const double* plv = base + mp.lv + mp.slv * (N - 1);
+    unsigned alq = lds_addr(base + mp.lq + mp.slq * (N - 1));
+    unsigned alv = lds_addr(base + mp.lv + mp.slv * (N - 1));
+    const unsigned dlq = 8u * (unsigned)mp.slq, dlv = 8u * (unsigned)mp.slv;
     for (int i = N - 1; i >= 0; --i) {
         // per-lane coefficients of this step (issued together with the cross-lane moves of pass 1, whose
         // latency they share; fetching them a step ahead was measured and is slower)
         double m1[4], m2[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m1[k] = *pm1[k];
-            m2[k] = *pm2[k];
-            pm1[k] -= mp.s1[k];
-            pm2[k] -= mp.s2[k];
+            m1[k] = lds_load(am1[k]);
+            m2[k] = lds_load(am2[k]);
+            am1[k] -= dm1[k];
+            am2[k] -= dm2[k];
         }
-        const double Lq = *plq;
-        const double lv = *plv;
-        plq -= mp.slq;
-        plv -= mp.slv;
+        const double Lq = lds_load(alq);
+        const double lv = lds_load(alv);
+        alq -= dlq;
+        alv -= dlv;
         // pass 1: column wc of W from the lanes 8 k + wc
         const double w0 = lane_gather(wn, wc), w1 = lane_gather(wn, 8 + wc);
         const double w2 = lane_gather(wn, 16 + wc), w3 = lane_gather(wn, 24 + wc);
@@ -1510,8 +1530,7 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double Zv = lv + X; // (Q_x, Q_u) on the lanes of column 4
         // pass 2: row r' of X[:, 0:4] sits in lanes 8 r' + 0..3; bring it to both quads of the row, then
         // broadcast inside each quad
-        const double Xsh = dpp_move<0x114>(X);            // row_shr:4
-        const double Xq = (cc < 4) ? X : Xsh;
+        const double Xq = dpp_move_banks<0x114, 0xA>(X);  // row_shr:4 on the lanes with cc >= 4 (banks 1 and 3)
         const double x0 = dpp_move<0x00>(Xq), x1 = dpp_move<0x55>(Xq);
         const double x2 = dpp_move<0xAA>(Xq), x3 = dpp_move<0xFF>(Xq);
         const double Y = ((x0 * m2[0] + x1 * m2[1]) + x2 * m2[2]) + x3 * m2[3];
