@@ -129,6 +129,9 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         }
         return;
     }
+    // the main wavefront carries the serial chain of the solve: it wins issue arbitration against the helper
+    // wavefront (of another block) it shares its SIMD with
+    if (HELP) __builtin_amdgcn_s_setprio(2);
     if (ALM && last_u == nullptr) {
         // cs:88-93: fresh multipliers unless this call continues a previous solution
         al.rho = c.k->alm_rho_init;

@@ -594,12 +594,22 @@ __device__ inline void sum_stage_costs_multi(const Lds& l, int N, int lane, doub
     const int last = (row == 1) ? N - 1 : N;
     double acc = (row == 2) ? 0.0 : v[0];
     int k = 1;
-    for (; k + 7 <= last; k += 8) {
-        double a[8];
+    if (k + 7 <= last) {
+        // the chain of additions is the critical path: the next eight terms are fetched while eight are added
+        double a[8], b[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) a[t] = v[k + t];
+        for (; k + 15 <= last; k += 8) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b[t] = v[k + 8 + t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = acc + a[t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] = b[t];
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc = acc + a[t];
+        k += 8;
     }
     for (; k <= last; ++k) acc = acc + v[k];
 #pragma unroll
