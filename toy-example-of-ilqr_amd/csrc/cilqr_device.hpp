@@ -869,8 +869,13 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
         const double* xi = l.x;
         const double* ui = l.u;
         const size_t CS = (size_t)R * CILQR_MAX_ALPHA_TRIALS; // component stride
-        double* tx = &TR(t, 0, 1);   // x' components at strides CS
-        double* tu = &TR(t, 4, 0);   // u' components
+        // stores go through a wave-uniform row pointer plus this lane's byte offset (scalar base + 32-bit
+        // vector offset addressing: no per-store 64-bit address arithmetic in vector registers)
+        char* tx = reinterpret_cast<char*>(scr + CILQR_MAX_ALPHA_TRIALS);   // row 1 of component 0
+        char* tu = reinterpret_cast<char*>(scr + 4 * CS);                   // row 0 of component 4
+        const unsigned lane_off = 8u * (unsigned)lane;
+        const size_t CSB = CS * sizeof(double), ROWB = CILQR_MAX_ALPHA_TRIALS * sizeof(double);
+#define CILQR_SLAB_ST(base, comp, val) (*reinterpret_cast<double*>((base) + (comp) * CSB + lane_off) = (val))
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
         // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
@@ -906,14 +911,14 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
                 if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) break;
                 double xn[4];
                 if (!propagate_small<RP>(c, xc, un, xn)) break;
-                tu[0] = un[0];
-                tu[CS] = un[1];
-                tx[0] = xn[0];
-                tx[CS] = xn[1];
-                tx[2 * CS] = xn[2];
-                tx[3 * CS] = xn[3];
+                CILQR_SLAB_ST(tu, 0, un[0]);
+                CILQR_SLAB_ST(tu, 1, un[1]);
+                CILQR_SLAB_ST(tx, 0, xn[0]);
+                CILQR_SLAB_ST(tx, 1, xn[1]);
+                CILQR_SLAB_ST(tx, 2, xn[2]);
+                CILQR_SLAB_ST(tx, 3, xn[3]);
                 xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-                tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+                tx += ROWB; tu += ROWB;
             }
         }
         if (i < N) {
@@ -944,17 +949,18 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
                 un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
                 double xn[4];
                 propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn);
-                tu[0] = un[0];
-                tu[CS] = un[1];
-                tx[0] = xn[0];
-                tx[CS] = xn[1];
-                tx[2 * CS] = xn[2];
-                tx[3 * CS] = xn[3];
+                CILQR_SLAB_ST(tu, 0, un[0]);
+                CILQR_SLAB_ST(tu, 1, un[1]);
+                CILQR_SLAB_ST(tx, 0, xn[0]);
+                CILQR_SLAB_ST(tx, 1, xn[1]);
+                CILQR_SLAB_ST(tx, 2, xn[2]);
+                CILQR_SLAB_ST(tx, 3, xn[3]);
                 xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-                tx += CILQR_MAX_ALPHA_TRIALS; tu += CILQR_MAX_ALPHA_TRIALS;
+                tx += ROWB; tu += ROWB;
             }
         }
     }
+#undef CILQR_SLAB_ST
     wave_sync();
 }
 
