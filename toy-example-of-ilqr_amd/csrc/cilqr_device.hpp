@@ -10,8 +10,10 @@
 //   * the backward Riccati-like sweep is serial over the horizon; inside a step lane = matrix
 //     element of a 6x8 grid, operands move between lanes with DPP / ds_bpermute / v_readlane
 //     (backward_sweep_lanes); a wave-uniform form (backward_sweep_uniform) is kept as a testing aid;
-//   * x, u, K, d, l_*, A, B and a window of the lane table live in LDS; the 20 trial trajectories
-//     live in an L2-resident scratch slab; obstacle routes are read through L1/L2 (shared by the batch).
+//   * x, u, l_*, the Jacobians A, B and — in the same array, once a step's Jacobians are consumed — the
+//     gains K, d, the cost model's constants and a window of the lane table live in LDS; the 20 trial
+//     trajectories live in an L2-resident scratch slab; obstacle routes are read through L1/L2 (shared
+//     by the batch).
 //
 // Arithmetic contract: every value is computed with the same IEEE operations in the same order
 // as oracle/cilqr_oracle.c (which restates the reference's Eigen expressions); where structural
