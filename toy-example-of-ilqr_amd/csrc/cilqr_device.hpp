@@ -800,6 +800,51 @@ __device__ inline double total_cost_trial(const Cst& c, const Lds& l, const AlmS
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reference points of the trajectory held in LDS x, rows in parallel: candidate per row from a guess
+// (distance travelled from row 0 over the lane's sample spacing at idx0 — only speed depends on it), then
+// the same proof as for the trial trajectories (see total_cost_trials).  false = not proven, l.ridx undefined.
+__device__ inline bool ref_indices_parallel(const Cst& c, const Lds& l, int lane, int idx0) {
+    const int N = c.N;
+    double ds = 1.0;
+    if (idx0 + 1 < c.L) {
+        double ax, ay, bx, by;
+        lane_point(c, l, idx0, ax, ay);
+        lane_point(c, l, idx0 + 1, bx, by);
+        ds = dm_hypot(bx - ax, by - ay);
+    }
+    const double x0 = l.x[0], y0 = l.x[1];
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        int m = idx0;
+        double q = 0.0;
+        if (k > 0) {
+            const double px = l.x[4 * k], py = l.x[4 * k + 1];
+            const double gd = dm_hypot(px - x0, py - y0) / ds;
+            int g = idx0 + ((gd < 1.0e6) ? (int)gd : 0); // NaN / inf / absurd: start at idx0
+            g = (g < idx0) ? idx0 : g;
+            g = (g > c.L - 1) ? c.L - 1 : g;
+            m = local_min_near(c, l, px, py, g, idx0, &q);
+        }
+        l.ridx[k] = m;
+        l.cs[k] = q; // the stage-cost scratch is free here
+    }
+    wave_sync();
+    bool ok = true;
+    for (int k = lane; k <= N; k += CILQR_WAVE) {
+        if (k >= 1) {
+            const int lo = l.ridx[k - 1], hi = l.ridx[k];
+            bool good = (lo <= hi);
+            if (good && hi - lo >= 2 && !convex_interior(c, l.cs[k], lo, hi)) {
+                const double px = l.x[4 * k], py = l.x[4 * k + 1];
+                if (!verify_window_fast(l, px, py, lo, hi)) good = verify_interval(c, l, px, py, lo, hi);
+            }
+            ok = ok && good;
+        }
+    }
+    const bool proven = (__ballot(!ok) == 0ULL);
+    wave_sync();
+    return proven;
+}
+
 // Initial trajectory (cs:155-197): cold start u = 0, or warm start from last_u shifted by one step;
 // fills LDS x, u, ridx.  Wave-uniform serial rollout.
 __device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4], const double* last_u,
@@ -818,26 +863,34 @@ __device__ inline void init_trajectory(const Cst& c, Lds& l, const double x0[4],
     wave_sync();
     idx0 = ref_scan_row0(c, x0[0], x0[1], lane);
     stage_window(c, l, idx0, Wcap, lane);
+    // the rollout is one serial chain (wave-uniform); the reference points do not feed back into it, so they
+    // are found afterwards for all rows at once
     double xc[4] = {x0[0], x0[1], x0[2], x0[3]};
-    int s = idx0;
     if (lane == 0) {
         l.x[0] = xc[0]; l.x[1] = xc[1]; l.x[2] = xc[2]; l.x[3] = xc[3];
-        l.ridx[0] = s;
     }
     for (int i = 0; i < N; ++i) {
         double ui[2] = {l.u[2 * i], l.u[2 * i + 1]};
         double xn[4];
         if (c.rp == 0) propagate<0>(c, xc, ui, xn);
         else propagate<1>(c, xc, ui, xn);
-        s = ref_scan_from(c, l, xn[0], xn[1], s);
         if (lane == 0) {
             l.x[4 * (i + 1)] = xn[0]; l.x[4 * (i + 1) + 1] = xn[1];
             l.x[4 * (i + 1) + 2] = xn[2]; l.x[4 * (i + 1) + 3] = xn[3];
-            l.ridx[i + 1] = s;
         }
         xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
     }
     wave_sync();
+    if (!ref_indices_parallel(c, l, lane, idx0)) {
+        // the serial chain of cs:289-314
+        int s = idx0;
+        if (lane == 0) l.ridx[0] = s;
+        for (int i = 1; i <= N; ++i) {
+            s = ref_scan_from(c, l, l.x[4 * i], l.x[4 * i + 1], s);
+            if (lane == 0) l.ridx[i] = s;
+        }
+        wave_sync();
+    }
 }
 
 // ridx for a trajectory already staged in LDS x (used by the piecewise kernels)
