@@ -30,7 +30,8 @@ def hipcc_path():
 
 def build_library(force=False, verbose=False):
     srcs = [CSRC / "cilqr_amd.hip", CSRC / "scenario.cpp"]
-    deps = srcs + [CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h"]
+    deps = srcs + [CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
+                   pathlib.Path(__file__)]  # the flags live in this file
     if not force and _newer(LIB, deps):
         return LIB
     cmd = [hipcc_path()] + HIP_FLAGS + [str(s) for s in srcs] + ["-o", str(LIB)]
