@@ -574,6 +574,28 @@ def test_edge_start_on_the_reference_line_and_wild_states(pkg, orc_det, scenario
     assert np.isnan(out["res"]["J_final"][3])
 
 
+@pytest.mark.parametrize("N", [63, 64, 127])
+def test_horizon_boundaries(pkg, orc_det, scenarios, N):
+    """N + 1 = 64 is the last horizon with one row per lane, N = 64 the first with two, N = 127 the largest
+    the library accepts; both vehicle models, with and without the helper wavefront."""
+    for name in ("two_straight", "three_bend"):
+        cfg, sc = scenarios[name]
+        if sc.obstacles.shape[1] < N + 1:
+            pytest.skip("obstacle routes shorter than the horizon")
+        p = pkg.params_from_config(cfg, N=N, max_iter=12)
+        tab = pkg.SceneTable.from_scenario(sc)
+        x0 = pkg.workloads.perturbed_starts(sc.ego_state, 6, 1000 + N)
+        out, refs = solve_both(pkg, orc_det, p, tab, x0)
+        compare_solves(out, refs, f"{name} N={N}")
+        eng = pkg.BatchedCILQR(p, tab)
+        eng.set_helper_mode(0)
+        out0 = eng.solve_batch(x0, trace_cap=128)
+        eng.close()
+        compare_solves(out0, refs, f"{name} N={N} (no helper)")
+    with pytest.raises(Exception):
+        pkg.BatchedCILQR(pkg.params_from_config(cfg, N=128), tab)
+
+
 def test_irregular_lane_tables_reference_search(pkg, orc_det, scenarios):
     """The reference-point proof leans on a per-lane convexity certificate; on lane tables that cannot be
     certified (a sharp corner, jittered or very uneven sampling, a lane that doubles back, a gap) it must
