@@ -88,7 +88,11 @@ enum { CTL_MODE = 0, CTL_DONE = 1, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W
 
 // WPS = waves per SIMD the register allocation must allow (2 for big batches: more resident
 // trajectories at the price of a few spills)
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1>
+// NTP = trials costed per pass after the first when there is no helper wavefront: 2 overlaps the two
+// trials' latencies inside one wavefront (pays while SIMDs hold one or two wavefronts: +5 % at B = 1536-2048);
+// 1 keeps fewer values live (27 instead of 68 spilled registers) and is the faster choice once every SIMD
+// holds two wavefronts anyway (+1.5 % at B >= 3072)
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -196,7 +200,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             // (usually accepted), then CILQR_NT trials per pass — and consumed strictly in order
             for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
                 double Jp[CILQR_NT];
-                int nt = (t0 == 0) ? 1 : CILQR_NT;
+                int nt = (t0 == 0) ? 1 : NTP;
                 if (HELP) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
                 if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
                 if (HELP) {
@@ -211,7 +215,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
                                                         (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                     Jp[0] = J1[0];
-                } else {
+                } else if (NTP > 1) {
                     total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, scr, t0, nt, lane, idx0, a.flags, &n_fallback,
                                                                Jp, (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                 }
@@ -582,6 +586,7 @@ struct cilqr_handle {
     int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
     int helper_max_batch = 1024;
     int occ2_min_batch = 1024; // above this the 2-waves-per-SIMD build of the solve kernel is used
+    int single_trial_min_batch = 2560; // above this trials are costed one per pass (see k_solve's NTP)
     int prof_B = 0;
     DevBuf st[16];
 };
@@ -1011,6 +1016,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         else if (a.prof) kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
                                      : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
         else if (help) kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
+        else if (B > h->single_trial_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
         else if (B > h->occ2_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2> : k_solve<false, 1, false, false, false, 2>;
         else kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         const bool helped = help && (a.alm || a.flags == 0);
