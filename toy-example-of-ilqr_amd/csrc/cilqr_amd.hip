@@ -1017,7 +1017,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
                                      : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
         else if (help) kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
         else if (B > h->single_trial_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
-        else if (B > h->occ2_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2> : k_solve<false, 1, false, false, false, 2>;
+        else if (B > h->occ2_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2>; // two rows per lane: paired trials spill too much
         else kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         const bool helped = help && (a.alm || a.flags == 0);
         hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
