@@ -623,7 +623,6 @@ static void update_window(cilqr_handle* h) {
     // batches that fill the chip several times over: occupancy (two wavefronts per SIMD hide each other's
     // latencies) is worth more than the far end of the window, which only the last rows at full speed reach
     h->win_occ = pick(std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8));
-    if (const char* e = getenv("CILQR_EXP_WINDOW")) h->win = h->win_occ = atoi(e);
 }
 
 static int check_ready(cilqr_handle* h) {
