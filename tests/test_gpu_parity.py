@@ -466,6 +466,28 @@ def test_config2_full_batch_bitexact(pkg, orc_det):
     eng.close()
 
 
+def test_full_size_configs_bitexact(pkg, orc_det):
+    """BASELINE configs[2], [3] (rank 0's shard of 8) and [4] at their full sizes: every trajectory, every
+    output field, bit for bit against the oracle (OpenMP over the host cores the box grants)."""
+    import os
+    from oracle import Scene
+    threads = max(1, min(16, os.cpu_count() or 1))
+    cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5())
+    for wl in cases:
+        eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+        out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+        eng.close()
+        scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs if s.obs.shape[0] else None, s.road_borders, s.ref_velo)
+                  for s in wl.scenes]
+        ref = orc_det.solve_batch(wl.params, scenes, wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=threads)
+        eq_bits(out["u"], ref["u"], f"{wl.name} u")
+        eq_bits(out["x"], ref["x"], f"{wl.name} x")
+        for f in ("J_init", "J_final"):
+            eq_bits(out["res"][f], ref["res"][f], f"{wl.name} {f}")
+        for f in ("iters", "end_reason", "final_status", "ls_trials", "cost_evals"):
+            assert np.array_equal(out["res"][f], ref["res"][f]), (wl.name, f)
+
+
 def test_config3_and_config5_properties_at_scale(pkg, orc_det):
     """configs[2] (8192 x three_bend) and configs[4] (barrier sweep): size-independent properties on the
     full batch + oracle parity on a strided sample."""
