@@ -194,6 +194,18 @@ def main():
             if pmc.get("workload") == wl.name and world == 1:
                 traffic = pmc["hbm_bytes_per_launch_corrected"]
                 traffic_src = "profiles/r01_pmc_config2.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        # the bound that actually applies: vector-instruction issue.  Wave instructions per launch from the SQ
+        # counter pass (profiles/), 4 cycles of a SIMD each at best, against all SIMD-cycles of the live kernel time
+        valu = None
+        sq_path = os.path.join(ROOT, "profiles", "r01_pmc_sq_config2.json")
+        if os.path.exists(sq_path) and traffic is not None:
+            sq = json.load(open(sq_path))
+            if "SQ_INSTS_VALU" in sq:
+                simds, clock_hz = 256 * 4, 2.4e9
+                valu = {"wave_instructions_per_launch": sq["SQ_INSTS_VALU"],
+                        "frac_of_issue_slots": sq["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * kernel_ms * 1e-3),
+                        "source": "profiles/r01_pmc_sq_config2.json (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per "
+                                  "wave64 instruction, 2.4 GHz"}
         out = {
             "metric": "iLQR iterations/sec (batch x horizon)", "value": value, "unit": "iLQR iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,6 +218,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_solve", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "valu_issue": valu,
                          "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"},
             "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
                       "line_search_trials_per_step": float(total_trials),
