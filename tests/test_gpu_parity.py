@@ -703,10 +703,12 @@ def test_fuzz_random_parameter_sets(pkg, orc_det, scenarios):
     """randomised parameter sets (weights, barrier shapes, bounds, lambda schedule, horizon, vehicle
     model, solve type) on all four scenarios: whole solves incl. decision traces stay bit-exact."""
     from oracle import Scene
-    rng = np.random.default_rng(20250829)
+    import os
+    # CILQR_FUZZ_SEED / CILQR_FUZZ_TRIALS widen the search for soak runs; the defaults are what the suite runs
+    rng = np.random.default_rng(int(os.environ.get("CILQR_FUZZ_SEED", "20250829")))
     names = list(scenarios)
     total_iters = 0
-    for trial in range(28):
+    for trial in range(int(os.environ.get("CILQR_FUZZ_TRIALS", "28"))):
         name = names[trial % 4]
         cfg, sc = scenarios[name]
         N = int(rng.choice([3, 7, 20, 30, 45, 63, 64, 80, 110]))
