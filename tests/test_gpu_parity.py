@@ -618,36 +618,50 @@ def test_horizon_boundaries(pkg, orc_det, scenarios, N):
         pkg.BatchedCILQR(pkg.params_from_config(cfg, N=128), tab)
 
 
-def test_concurrent_handles_on_separate_streams(pkg):
+_CONCURRENT_SCRIPT = r"""
+import sys, numpy as np
+import torch                      # first: the process then has ONE HIP runtime (torch's), as in bench.py
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import cilqr_amd as pkg
+dev = torch.device("cuda", 0)
+wl = pkg.workloads.config2(B=256)
+N, B = wl.N, wl.B
+ref_eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+ref = ref_eng.solve_batch(wl.x0)
+ref_eng.close()
+S = 3
+engs = [pkg.BatchedCILQR(wl.params, wl.scenes) for _ in range(S)]
+strs = [torch.cuda.Stream(dev) for _ in range(S)]
+d_x0 = torch.from_numpy(wl.x0).to(dev)
+outs = [(torch.empty((B, N, 2), dtype=torch.float64, device=dev), torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev),
+         torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)) for _ in range(S)]
+torch.cuda.synchronize(dev)
+for rep in range(4):
+    for i in range(S):
+        u, x, r = outs[i]
+        engs[i].solve_batch_device(B, d_x0.data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, 0,
+                                   strs[i].cuda_stream)
+torch.cuda.synchronize(dev)
+for u, x, r in outs:
+    assert np.array_equal(u.cpu().numpy(), ref["u"]) and np.array_equal(x.cpu().numpy(), ref["x"])
+    res = np.frombuffer(r.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+    assert (res == ref["res"]).all()
+print("CONCURRENT-OK")
+"""
+
+
+def test_concurrent_handles_on_separate_streams():
     """Independent batches overlap when each has its own handle and stream: the results are
-    those of running them one after the other."""
-    torch = pytest.importorskip("torch")
-    dev = torch.device("cuda", 0)
-    wl = pkg.workloads.config2(B=256)
-    N, B = wl.N, wl.B
-    ref_eng = pkg.BatchedCILQR(wl.params, wl.scenes)
-    ref = ref_eng.solve_batch(wl.x0)
-    ref_eng.close()
-    S = 3
-    engs = [pkg.BatchedCILQR(wl.params, wl.scenes) for _ in range(S)]
-    strs = [torch.cuda.Stream(dev) for _ in range(S)]
-    d_x0 = torch.from_numpy(wl.x0).to(dev)
-    outs = [(torch.empty((B, N, 2), dtype=torch.float64, device=dev), torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev),
-             torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)) for _ in range(S)]
-    torch.cuda.synchronize(dev)
-    for rep in range(4):
-        for i in range(S):
-            u, x, r = outs[i]
-            engs[i].solve_batch_device(B, d_x0.data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, 0,
-                                       strs[i].cuda_stream)
-    torch.cuda.synchronize(dev)
-    for u, x, r in outs:
-        eq_bits(u.cpu().numpy(), ref["u"], "u")
-        eq_bits(x.cpu().numpy(), ref["x"], "x")
-        res = np.frombuffer(r.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
-        assert (res == ref["res"]).all()
-    for e in engs:
-        e.close()
+    those of running them one after the other.  Runs in its own process with torch imported first — torch
+    ships its own HIP runtime, and a process that loaded the system one before cannot bring up a second."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CONCURRENT_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CONCURRENT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_irregular_lane_tables_reference_search(pkg, orc_det, scenarios):
