@@ -80,7 +80,10 @@ __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l,
 // HELP = true: the block has a second wavefront that does nothing but cost every other trial of the
 // line search (slot 1) while the main wavefront costs the ones in between (slot 0); used when the
 // batch is too small to fill the chip with one wavefront per trajectory.  Control words in LDS:
-enum { CTL_MODE = 0, CTL_DONE = 1, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W = 5 };
+enum { CTL_MODE = 0, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W = 5 };
+// doubles: the helper's / the main wave's cost of the current pass (two slots each, alternating), and what the
+// helper needs to reach the main wave's verdicts on its own
+enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 #define BLOCK_BAR()            \
     do {                       \
         if (HELP) __syncthreads(); \
@@ -118,14 +121,18 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         for (int itr = 0; itr < c.max_iter; ++itr) {
             __syncthreads(); // B1: K, d, trial slab of this iteration are ready (or the backward pass failed)
             if (l.ctli[CTL_MODE]) {
-                if (ALM) al.rho = l.ctld[1];
-                for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2) {
+                if (ALM) al.rho = l.ctld[CTLD_RHO];
+                const double Jc = l.ctld[CTLD_JCUR], dV0 = l.ctld[CTLD_DV], dV1 = l.ctld[CTLD_DV + 1];
+                const double conv_thr = c.k->conv_thr, accept_thr = c.k->accept_thr;
+                for (int t0 = 0, par = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2, par ^= 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0 + 1, 1, lane, idx0h, a.flags, &nfb, J1, nullptr, 1);
-                    if (lane == 0) l.ctld[0] = J1[0];
-                    __syncthreads(); // B2
-                    __syncthreads(); // B3: the main wave has decided
-                    if (l.ctli[CTL_DONE]) break;
+                    if (lane == 0) l.ctld[CTLD_JH + par] = J1[0];
+                    __syncthreads(); // B2: both costs of this pass are in LDS (slots alternate between passes)
+                    // the same verdict the main wave reaches (trial_verdict is a pure function of these numbers)
+                    const double J0 = l.ctld[CTLD_JM + par];
+                    if (trial_verdict(Jc, J0, t0, dV0, dV1, conv_thr, accept_thr) != 0) break;
+                    if (trial_verdict(Jc, J1[0], t0 + 1, dV0, dV1, conv_thr, accept_thr) != 0) break;
                 }
             }
             __syncthreads(); // B4
@@ -192,12 +199,16 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
             PROF_ADD(PH_ROLLOUT);
             if (HELP) {
-                if (lane == 0) { l.ctli[CTL_MODE] = 1; l.ctld[1] = al.rho; }
+                if (lane == 0) {
+                    l.ctli[CTL_MODE] = 1;
+                    l.ctld[CTLD_RHO] = al.rho; l.ctld[CTLD_JCUR] = J_cur; l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1];
+                }
                 __syncthreads(); // B1
             }
             bool done = false;
             // the line search of cs:354-372; the costs are produced pass by pass — alpha = 1 alone
             // (usually accepted), then CILQR_NT trials per pass — and consumed strictly in order
+            int par = 0; // helper mode: which pair of cost slots this pass uses
             for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
                 double Jp[CILQR_NT];
                 int nt = (t0 == 0) ? 1 : NTP;
@@ -208,8 +219,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
                                                         (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0);
                     Jp[0] = J1[0];
+                    if (lane == 0) l.ctld[CTLD_JM + par] = J1[0];
                     __syncthreads(); // B2
-                    Jp[1] = l.ctld[0];
+                    Jp[1] = l.ctld[CTLD_JH + par];
+                    par ^= 1;
                 } else if (nt == 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
@@ -222,33 +235,24 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 PROF_ADD(PH_TRIAL_COST);
                 for (int tt = 0; tt < nt && !done; ++tt) {
                     const int t = t0 + tt;
-                    const double alpha = dm_pow2i(-t);
                     new_J = Jp[tt];
                     trials++;
-                    const double decay = J_cur - new_J;
-                    const double adecay = (decay < 0) ? -decay : decay;
-                    if (t == 0 && adecay < c.k->conv_thr) {
+                    const int verdict = trial_verdict(J_cur, new_J, t, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
+                    if (verdict == 1) {
                         status = CILQR_CONVERGED;
                         alpha_idx = t;
                         done = true;
-                    } else {
-                        const double approx = -(alpha * alpha * dV[0] + alpha * dV[1]);
-                        if (decay > 0.0 && (approx < 0.0 || decay / approx > c.k->accept_thr)) {
-                            if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
-                            flag = 1;
-                            alpha_idx = t;
-                            accept_trial(c, l, scr, t, tt, lane);
-                            PROF_ADD(PH_ACCEPT);
-                            J_cur = new_J;
-                            done = true;
-                        }
+                    } else if (verdict == 2) {
+                        if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
+                        flag = 1;
+                        alpha_idx = t;
+                        accept_trial(c, l, scr, t, tt, lane);
+                        PROF_ADD(PH_ACCEPT);
+                        J_cur = new_J;
+                        done = true;
                     }
                 }
                 t0 += nt;
-                if (HELP) {
-                    if (lane == 0) l.ctli[CTL_DONE] = (done || t0 >= CILQR_MAX_ALPHA_TRIALS) ? 1 : 0;
-                    __syncthreads(); // B3
-                }
             }
             if (!done) {
                 status = CILQR_FORWARD_PASS_FAIL;

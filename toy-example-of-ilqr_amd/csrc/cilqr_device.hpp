@@ -141,7 +141,7 @@ struct Lds {
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
     int* tidx;   // [CILQR_NT][(N+2)] the same for the trial trajectories being costed
     int* ctli;   // [8]  control words shared by the main and the helper wavefront of a block
-    double* ctld; // [4]
+    double* ctld; // [CILQR_CTLD]
     int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
     int W;
 };
@@ -156,10 +156,11 @@ struct Lds {
 #define CILQR_KD_ROW 5
 #define CILQR_KD_K(e) ((e) < 4 ? (e) : (e) + 1) /* K[e / 4][e % 4], e = 0..7 */
 #define CILQR_KD_D(j) (4 + CILQR_KD_ROW * (j))  /* d[j] */
+#define CILQR_CTLD 8 /* doubles shared by the main and the helper wavefront (k_solve) */
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 __host__ __device__ inline int lds_doubles(int N, int alm) {
-    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + 4 + CILQR_CSTK_DOUBLES;
+    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
     return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
@@ -177,7 +178,7 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.luu = p; p += 2 * N;
     l.xch = p; p += CILQR_XCH;
     l.cs = l.kd; // 10 N doubles >= CILQR_NT * 3 * (N + 1) for every N >= 2
-    l.ctld = p; p += 4;
+    l.ctld = p; p += CILQR_CTLD;
     l.ck = reinterpret_cast<CstK*>(p); p += CILQR_CSTK_DOUBLES;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
@@ -1676,6 +1677,21 @@ __device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, i
                                       int* fail_step = nullptr) {
     if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV, fail_step);
     return backward_sweep_lanes(c, l, lamb, lane, dV, fail_step);
+}
+
+
+// The line search's verdict on one trial (cs:356-371): 0 = go on, 1 = converged (first trial only),
+// 2 = accepted.  A pure function of its arguments: the main and the helper wavefront both evaluate it on the
+// same numbers and so agree on when a search ends without a second hand-shake.
+__device__ inline int trial_verdict(double J_cur, double new_J, int t, double dV0, double dV1, double conv_thr,
+                                    double accept_thr) {
+    const double alpha = dm_pow2i(-t);
+    const double decay = J_cur - new_J;
+    const double adecay = (decay < 0) ? -decay : decay;
+    if (t == 0 && adecay < conv_thr) return 1;
+    const double approx = -(alpha * alpha * dV0 + alpha * dV1);
+    if (decay > 0.0 && (approx < 0.0 || decay / approx > accept_thr)) return 2;
+    return 0;
 }
 
 } // namespace cilqr
