@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the configuration's own)")
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="batches in flight for the extra.pipelined figure (1 = skip it; never the headline value)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="> 1: also measure the same steps with that many batches in flight (one handle and HIP stream "
+                         "each) and report it under extra.pipelined — never the headline value.  Off by default so that "
+                         "every k_solve launch of the default command is a sequential one (rocprofv3 averages agree).")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 

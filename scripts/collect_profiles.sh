@@ -34,6 +34,9 @@ for b in 512 2048 4096 16384; do
     $BENCH --config 2 --batch $b --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_config2_B$b.json" 2>/dev/null
 done
 
+# 4b. four batches in flight (extra.pipelined)
+$BENCH --streams 4 --steps 40 --warmup 3 --no-cpu-baseline > "$OUT/bench_pipelined.json" 2>/dev/null
+
 # 5. in-kernel phase accounting
 $PY $ROOT/scripts/phase_profile.py --config 2 > "$OUT/phase_config2.json" 2> "$OUT/phase_config2.err"
 $PY $ROOT/scripts/phase_profile.py --config 3 --batch 8192 > "$OUT/phase_config3.json" 2> "$OUT/phase_config3.err"

@@ -86,6 +86,13 @@ for path in sorted(glob.glob(os.path.join(src, "bench_config*.json"))):
         "max_lamb": e["max_lamb"], "max_iter": e["max_iter"], "hbm_frac": round(b["roofline"]["frac"], 5)}
 json.dump(other, open(os.path.join(dst, f"{tag}_other_configs.json"), "w"), indent=1)
 
+pp = os.path.join(src, "bench_pipelined.json")
+if os.path.exists(pp) and os.path.getsize(pp):
+    b = json.loads(open(pp).read().strip().splitlines()[-1])
+    json.dump({"command": "python bench.py --streams 4 --steps 40 --warmup 3 --no-cpu-baseline",
+               "sequential_value": b["value"], "pipelined": b["extra"]["pipelined"]},
+              open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
+
 for c in (2, 3):
     p = os.path.join(src, f"phase_config{c}.json")
     if os.path.exists(p) and os.path.getsize(p):
