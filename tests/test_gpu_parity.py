@@ -301,6 +301,46 @@ def test_error_codes(pkg, engines):
     assert e.value.code == -1
 
 
+def test_api_contract_details(pkg, orc_det, scenarios):
+    """Small print of the C-ABI: a trace buffer shorter than the solve keeps the first records and reports its
+    own length; parameter sets of one handle must share N and the solve type; tables can be replaced between
+    calls of the same handle; B = 1 works like any other batch."""
+    cfg, sc = scenarios["two_straight"]
+    p = pkg.params_from_config(cfg, N=30)
+    tab = pkg.SceneTable.from_scenario(sc)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 5, 4711)
+    eng = pkg.BatchedCILQR(p, tab)
+    full = eng.solve_batch(x0, trace_cap=128)
+    short = eng.solve_batch(x0, trace_cap=3)
+    assert (full["res"]["iters"] > 3).any()
+    for b in range(5):
+        n = int(full["res"]["iters"][b])
+        assert full["res"]["trace_len"][b] == n
+        assert short["res"]["trace_len"][b] == min(n, 3)
+        assert (short["trace"][b][:min(n, 3)] == full["trace"][b][:min(n, 3)]).all()
+    eq_bits(short["x"], full["x"], "x with a short trace buffer")
+    one = eng.solve_batch(x0[2:3], trace_cap=128)
+    eq_bits(one["x"][0], full["x"][2], "B = 1")
+    assert (one["res"] == full["res"][2:3]).all()
+    # new parameter table and new scenario table on the same handle
+    cfg2, sc2 = scenarios["three_bend"]
+    p2 = pkg.params_from_config(cfg2, N=40)
+    eng.set_params(p2)
+    eng.set_scenarios(pkg.SceneTable.from_scenario(sc2))
+    y0 = pkg.workloads.perturbed_starts(sc2.ego_state, 4, 4712)
+    out = eng.solve_batch(y0, trace_cap=128)
+    from oracle import Scene
+    t2 = pkg.SceneTable.from_scenario(sc2)
+    scene2 = Scene(t2.lane_x, t2.lane_y, t2.lane_yaw, t2.obs, t2.road_borders, t2.ref_velo)
+    compare_solves(out, [orc_det.solver(p2).solve(x, scene2) for x in y0], "tables replaced")
+    # mixed N / mixed solve type in one table are refused
+    for bad in ([p2, pkg.copy_params(p2, N=41)], [p2, pkg.copy_params(p2, solve_type=1)]):
+        with pytest.raises(pkg.CilqrError) as e:
+            eng.set_params(bad)
+        assert e.value.code == -1
+    eng.close()
+
+
 def test_serial_and_parallel_reference_search_agree(pkg, orc_det, engines):
     """the lane-parallel reference-point search (+ proof) and the serial chain of cs:289-314 give the
     same solves; with wild gains the proof must fail sometimes and the fallback must take over."""
