@@ -507,12 +507,16 @@ def test_config2_full_batch_bitexact(pkg, orc_det):
 
 
 def test_full_size_configs_bitexact(pkg, orc_det):
-    """BASELINE configs[2], [3] (rank 0's shard of 8) and [4] at their full sizes: every trajectory, every
-    output field, bit for bit against the oracle (OpenMP over the host cores the box grants)."""
+    """BASELINE configs[2], [3] (rank 0's shard of 8) and [4] at their full sizes, and the benchmark batch of
+    configs[1] once more with the augmented-Lagrangian solve type: every trajectory, every output field, bit
+    for bit against the oracle (OpenMP over the host cores the box grants)."""
     import os
     from oracle import Scene
     threads = max(1, min(16, os.cpu_count() or 1))
-    cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5())
+    alm2 = pkg.workloads.config2()
+    alm2 = pkg.workloads.Workload("config2_alm", [pkg.copy_params(q, solve_type=1) for q in alm2.params], alm2.scenes, alm2.x0,
+                                  alm2.scenario_id, alm2.param_id, alm2.tick)   # the benchmark batch, augmented Lagrangian
+    cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5(), alm2)
     for wl in cases:
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)
         out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
