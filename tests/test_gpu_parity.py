@@ -220,6 +220,35 @@ def test_solve_ticks_and_warm_start(pkg, orc_det, engines):
         x0 = out["x"][0, 1].copy()
 
 
+def test_batched_closed_loop_with_warm_starts(pkg, orc_det, scenarios):
+    """The step after the path (motion_planning.cpp:180-197) for a whole batch: 24 egos, 40 ticks, every ego
+    advances to row 1 of its own solution and warm-starts from it (cs:163-180); each tick's batch is compared
+    with 24 stateful oracle solvers."""
+    cfg, sc = scenarios["three_straight"]
+    p = pkg.params_from_config(cfg, N=30)
+    assert p.use_last_solution == 1
+    tab = pkg.SceneTable.from_scenario(sc)
+    B, ticks = 24, 40
+    assert sc.routes.shape[1] >= ticks + p.N + 1
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 31337)
+    eng = pkg.BatchedCILQR(p, tab)
+    solvers = [orc_det.solver(p) for _ in range(B)]
+    for s_ in solvers:
+        s_.reset()
+    last_u = None
+    iters = 0
+    for tick in range(ticks):
+        scene = oracle_scene(sc, tick)
+        out = eng.solve_batch(x0, tick=np.full(B, tick, np.int32), last_u=last_u, trace_cap=128)
+        refs = [solvers[b].solve(x0[b], scene) for b in range(B)]
+        compare_solves(out, refs, f"closed loop tick {tick}")
+        last_u = out["u"].copy()
+        x0 = out["x"][:, 1].copy()
+        iters += int(out["res"]["iters"].sum())
+    assert iters > ticks * B  # more than one iteration per solve on average: the loop did real work
+    eng.close()
+
+
 def test_solve_param_sweep_and_mixed_scenarios(pkg, orc_det):
     """param_id / scenario_id indirection (BASELINE configs 4 and 5) at reduced size."""
     wl = pkg.workloads.config5(B_base=4, N=30)
