@@ -588,7 +588,12 @@ struct cilqr_handle {
     bool profiling = false;
     int debug_flags = 0;
     int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
-    int helper_max_batch = 1024;
+    // Largest batch that gets helper wavefronts.  Up to 1024 trajectories a lone wavefront per trajectory leaves
+    // SIMD slots empty.  Beyond that the blocks take a second round, which pays while the batch's stragglers
+    // dominate: measured +20 % at 1536 straight-lane trajectories, +3 % / -13 % at 2048 (straight / bend), and
+    // +45 % at 2048 with two rows per lane (N = 100), whose lone-wavefront kernel is the slower one
+    int helper_max_batch = 1536;
+    int helper_max_batch_two_rows = 2048;
     int occ2_min_batch = 1024; // above this the 2-waves-per-SIMD build of the solve kernel is used
     int single_trial_min_batch = 2560; // above this trials are costed one per pass (see k_solve's NTP)
     int prof_B = 0;
@@ -929,6 +934,12 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
     return CILQR_OK;
 }
 
+static bool wants_helper(const cilqr_handle* h, int B) {
+    const bool two = !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE;
+    return (h->helper_mode == 1) ||
+           (h->helper_mode < 0 && B <= (two ? h->helper_max_batch_two_rows : h->helper_max_batch));
+}
+
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     BatchArgs a;
     a.params = static_cast<const cilqr_params*>(h->d_params.p);
@@ -943,7 +954,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.flags = h->debug_flags;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
-    const bool occ2 = B > h->occ2_min_batch && !a.alm && a.flags == 0 && !h->profiling && h->helper_mode != 1;
+    const bool occ2 = B > h->occ2_min_batch && !a.alm && a.flags == 0 && !h->profiling && !wants_helper(h, B);
     a.W = occ2 ? h->win_occ : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
@@ -1011,7 +1022,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     {
         const bool two = (a.N + 1 > CILQR_WAVE);
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
-        const bool help = (h->helper_mode == 1) || (h->helper_mode < 0 && B <= h->helper_max_batch);
+        const bool help = wants_helper(h, B);
         auto kern = k_solve<false, 1, false, false, false>;
         if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>)
                                 : (two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>);
