@@ -954,7 +954,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.flags = h->debug_flags;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
-    const bool occ2 = B > h->occ2_min_batch && !a.alm && a.flags == 0 && !h->profiling && !wants_helper(h, B);
+    const bool occ2 = B > h->occ2_min_batch && (a.alm || a.flags == 0) && !h->profiling && !wants_helper(h, B);
     a.W = occ2 ? h->win_occ : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
@@ -1025,7 +1025,9 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool help = wants_helper(h, B);
         auto kern = k_solve<false, 1, false, false, false>;
         if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>)
-                                : (two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>);
+                          : (B > h->occ2_min_batch)
+                              ? (two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>)
+                              : (two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>);
         else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
         else if (a.prof) kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
                                      : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
