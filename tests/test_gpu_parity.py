@@ -545,7 +545,10 @@ def test_full_size_configs_bitexact(pkg, orc_det):
     alm2 = pkg.workloads.config2()
     alm2 = pkg.workloads.Workload("config2_alm", [pkg.copy_params(q, solve_type=1) for q in alm2.params], alm2.scenes, alm2.x0,
                                   alm2.scenario_id, alm2.param_id, alm2.tick)   # the benchmark batch, augmented Lagrangian
-    cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5(), alm2)
+    alm3 = pkg.workloads.config3(B=3072)  # large enough for the lone-wavefront, two-per-SIMD kernels, ALM flavour
+    alm3 = pkg.workloads.Workload("config3_alm_B3072", [pkg.copy_params(q, solve_type=1) for q in alm3.params], alm3.scenes,
+                                  alm3.x0, alm3.scenario_id, alm3.param_id, alm3.tick)
+    cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5(), alm2, alm3)
     for wl in cases:
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)
         out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
