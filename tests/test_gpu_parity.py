@@ -549,8 +549,14 @@ def test_full_size_configs_bitexact(pkg, orc_det):
     alm3 = pkg.workloads.Workload("config3_alm_B3072", [pkg.copy_params(q, solve_type=1) for q in alm3.params], alm3.scenes,
                                   alm3.x0, alm3.scenario_id, alm3.param_id, alm3.tick)
     cases = (pkg.workloads.config3(), pkg.workloads.config4().shard(0, 8), pkg.workloads.config5(), alm2, alm3)
+    alm4 = pkg.workloads.config4(B=1100)  # two rows per lane, ALM, lone wavefronts two per SIMD (helper switched off below)
+    alm4 = pkg.workloads.Workload("config4_alm_B1100_nohelper", [pkg.copy_params(q, solve_type=1) for q in alm4.params],
+                                  alm4.scenes, alm4.x0, alm4.scenario_id, alm4.param_id, alm4.tick)
+    cases = cases + (alm4,)
     for wl in cases:
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+        if wl.name.endswith("_nohelper"):
+            eng.set_helper_mode(0)
         out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
         eng.close()
         scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs if s.obs.shape[0] else None, s.road_borders, s.ref_velo)
