@@ -5,9 +5,19 @@
 
 A "step" is one pass of the hot path — one cilqr_solve_batch_device call, i.e. CILQRSolver::solve
 for every trajectory of the batch — over one batch of synthetic input that is already resident in
-HBM.  Workload at N = 1: BASELINE.json configs[1] (batch = 1024 synthetic straight-lane scenarios,
-horizon 50).  With N GPUs every rank solves its own 1024-trajectory shard of a 1024*N batch (weak
-scaling, no data-path collective; RCCL only reduces the statistics afterwards).
+HBM.
+
+Workload (BASELINE.json `configs`):
+  * N = 1 (default): config 5 — 4096 perturbed three_bend starts x 16 barrier settings = 65 536 solves of
+    horizon 50, the largest single-GPU configuration (north_star: ">= 10k trajectories x 50-step horizon on
+    1 x MI355X").  Config 2 (1024 straight-lane trajectories, one launch = a latency measurement: its wall
+    time is the slowest trajectory's) is timed in the same run and reported under `extra.config2_latency`.
+  * N > 1 (default): config 4 — 65 536 mixed scenarios, horizon 100, sharded 8 x 8192: every rank solves
+    its own 8192-trajectory block (weak scaling when N < 8: 8192 per GPU), no data-path collective; RCCL
+    only reduces the statistics afterwards.  Config 2's weak scaling (1024 per GPU) is under `extra`.
+  * --config 1: the reference's own case (scenario_two_straight, single ego, horizon 50) as a 10 Hz closed
+    loop through the drop-in CILQRSolver.solve(), B = 1: per-tick latency next to the oracle on one core.
+  * --config 2|3|4|5 selects any of them explicitly.
 
 metric = iLQR iterations/s = (sum over trajectories of executed iterations of the loop at
 /root/reference/src/cilqr_solver.cpp:110) * steps / wall time, whole job.
@@ -25,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")  # written by scripts/summarize_profiles.py
 
 
 def parse():
@@ -32,20 +43,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
-                    help="BASELINE.json configuration (default 2 = configs[1], the headline)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="BASELINE.json configuration (0 = default: 5 on one GPU, 4 on several)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the configuration's own)")
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline workload (profiling passes: every k_solve launch is then the headline's)")
     ap.add_argument("--streams", type=int, default=1,
                     help="> 1: also measure the same steps with that many batches in flight (one handle and HIP stream "
                          "each) and report it under extra.pipelined — never the headline value.  Off by default so that "
                          "every k_solve launch of the default command is a sequential one (rocprofv3 averages agree).")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--ticks", type=int, default=120, help="--config 1: closed-loop ticks")
     return ap.parse_args()
 
 
-def make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank, world):
+def make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank):
     wl = pkg.workloads
     if cfg_id == 2:
         B = per_gpu_batch or 1024
@@ -81,13 +95,19 @@ def usable_cores():
     return n, note
 
 
+def oracle_scenes(wl):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Scene
+    return [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
+
+
 def cpu_baseline(pkg, wl, threads):
     """The oracle (CPU restatement of the reference path, glibc libm build, -O3 -ffp-contract=off)
     timed on this box's host cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from oracle import Oracle, Scene
+    from oracle import Oracle
     orc = Oracle("libm")
-    scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
+    scenes = oracle_scenes(wl)
     nb = min(wl.B, 1024)
     x0, sid, pid, tk = wl.x0[:nb], wl.scenario_id[:nb], wl.param_id[:nb], wl.tick[:nb]
     # single thread on a 128-trajectory sub-sample
@@ -112,14 +132,216 @@ def cpu_baseline(pkg, wl, threads):
         best = dt if best is None else min(best, dt)
     its = float(r["res"]["iters"].sum())
     return {"value": its / best, "unit": "iLQR iterations/s", "cores": threads, "kind": "port",
-            "sample": f"{nb} trajectories of {wl.name} x {tiles} copies, cold-start solves, OpenMP over trajectories, "
-                      f"best of 3 passes (~{work_one * tiles:.0f} s of single-core work per pass)",
+            "sample": f"first {nb} trajectories of {wl.name} x {tiles} copies, cold-start solves, OpenMP over "
+                      f"trajectories, best of 3 passes (~{work_one * tiles:.0f} s of single-core work per pass)",
             "one_core_value": one_core, "math": "glibc libm", "flags": "-O3 -ffp-contract=off",
             "first_pass_value_untiled": float(rs["res"]["iters"].sum()) / t_first}, rs
 
 
+def parity_check(gpu_u, gpu_x, gpu_res, ref, tol=1e-5):
+    """The run that was just timed against the libm oracle (the oracle is only the checker here).  The GPU
+    path is bit-identical to the oracle's detmath build (tests); against glibc's libm the elementary functions
+    differ by an ulp, which moves a discrete decision (line-search accept, |dJ| < threshold, nearest lane
+    sample) on a small fraction of trajectories — tests/test_gpu_parity.py::test_libm_divergences_are_near_ties
+    shows every such trajectory sits on a near-tie."""
+    nb = ref["res"].shape[0]
+    du = np.abs(gpu_u[:nb] - ref["u"]).reshape(nb, -1).max(axis=1)
+    dx = np.abs(gpu_x[:nb] - ref["x"]).reshape(nb, -1).max(axis=1)
+    dJ = np.abs(gpu_res["J_final"][:nb] - ref["res"]["J_final"])
+    bad = ~((du <= tol) & (dx <= tol) & (dJ <= tol))  # NaN counts as outside
+    same_path = (gpu_res["iters"][:nb] == ref["res"]["iters"]) & (gpu_res["ls_trials"][:nb] == ref["res"]["ls_trials"])
+    return {"trajectories": int(nb), "tolerance": tol,
+            "within_1e-5_frac": float(1.0 - bad.mean()),
+            "outside_1e-5": int(bad.sum()),
+            "same_iterations": int((gpu_res["iters"][:nb] == ref["res"]["iters"]).sum()),
+            "same_decision_path": int(same_path.sum()),
+            "outside_1e-5_among_same_decision_path": int((bad & same_path).sum()),
+            "max_abs_du_same_path": float(du[same_path].max()) if same_path.any() else None,
+            "max_abs_dx_same_path": float(dx[same_path].max()) if same_path.any() else None,
+            "max_abs_dJ_same_path": float(dJ[same_path].max()) if same_path.any() else None,
+            "max_abs_dJ_final": float(np.nanmax(dJ))}
+
+
+class GpuRun:
+    """One workload resident in HBM + the timed loop over it."""
+
+    def __init__(self, pkg, torch, wl, B, local_rank):
+        self.pkg, self.torch, self.wl, self.B = pkg, torch, wl, B
+        N = self.N = wl.N
+        self.dev = dev = torch.device("cuda", local_rank)
+        self.eng = pkg.BatchedCILQR(wl.params, wl.scenes, device=local_rank)
+        self.d_x0 = torch.from_numpy(wl.x0).to(dev)
+        self.d_sid = torch.from_numpy(wl.scenario_id).to(dev)
+        self.d_pid = torch.from_numpy(wl.param_id).to(dev)
+        self.d_tick = torch.from_numpy(wl.tick).to(dev)
+        self.d_u = torch.empty((B, N, 2), dtype=torch.float64, device=dev)
+        self.d_x = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
+        self.d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.current_stream(dev)
+
+    def step(self, eng=None, outs=None, stream=None):
+        e = eng or self.eng
+        ou, ox, orr = outs or (self.d_u, self.d_x, self.d_res)
+        st = stream or self.stream
+        e.solve_batch_device(self.B, self.d_x0.data_ptr(), self.d_sid.data_ptr(), self.d_pid.data_ptr(),
+                             self.d_tick.data_ptr(), 0, ou.data_ptr(), ox.data_ptr(), orr.data_ptr(), 0, 0,
+                             st.cuda_stream)
+
+    def timed(self, steps, warmup, barrier):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; HIP events on
+        the launch stream around every launch give the kernel's own duration."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev0[i].record(self.stream)
+            self.step()
+            ev1[i].record(self.stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        res = np.frombuffer(self.d_res.cpu().numpy().tobytes(), dtype=self.pkg.RESULT_DTYPE)
+        return elapsed, kernel_ms, res
+
+    def pipelined(self, steps, S):
+        """Not the headline: the same K steps with several batches in flight (one handle + HIP stream each)."""
+        torch, pkg, wl = self.torch, self.pkg, self.wl
+        engs = [self.eng] + [pkg.BatchedCILQR(wl.params, wl.scenes, device=self.dev.index) for _ in range(S - 1)]
+        strs = [torch.cuda.Stream(self.dev) for _ in range(S)]
+        outs = [(self.d_u, self.d_x, self.d_res)] + [
+            (torch.empty_like(self.d_u), torch.empty_like(self.d_x), torch.zeros_like(self.d_res)) for _ in range(S - 1)]
+        ref_x, ref_res = self.d_x.clone(), self.d_res.clone()
+        for i in range(S):
+            self.step(engs[i % S], outs[i % S], strs[i % S])
+        torch.cuda.synchronize(self.dev)
+        tp = time.perf_counter()
+        for i in range(steps):
+            self.step(engs[i % S], outs[i % S], strs[i % S])
+        torch.cuda.synchronize(self.dev)
+        tp = time.perf_counter() - tp
+        same = all(bool(torch.equal(o[1], ref_x)) and bool(torch.equal(o[2], ref_res)) for o in outs)
+        res = np.frombuffer(ref_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+        for e in engs[1:]:
+            e.close()
+        return {"streams": S, "value": float(res["iters"].sum()) * steps / tp,
+                "ms_per_step": tp / steps * 1e3, "results_identical_to_sequential": same}
+
+    def close(self):
+        self.eng.close()
+
+
+def counters_for(workload):
+    """HBM bytes and wave-instruction counts per launch from the PMC passes of this same command on this
+    workload (rocprofv3 cannot be nested inside the benchmark): profiles/pmc_current.json, keyed by workload
+    name, written by scripts/summarize_profiles.py together with how they were collected."""
+    if not os.path.exists(PMC_FILE):
+        return None
+    try:
+        return json.load(open(PMC_FILE)).get(workload)
+    except Exception:
+        return None
+
+
+def roofline_block(pkg, wl, res, kernel_ms, world):
+    N, M_of = wl.N, wl.M_of
+    alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
+    achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+    pmc = counters_for(wl.name) if world == 1 else None
+    traffic = traffic_src = valu = None
+    if pmc:
+        traffic = pmc.get("hbm_bytes_per_launch_corrected")
+        traffic_src = pmc.get("source")
+        if pmc.get("SQ_INSTS_VALU"):
+            # the bound that actually applies: vector-instruction issue.  Wave instructions per launch from the
+            # SQ counter pass, 4 cycles of a SIMD each at best, against all SIMD-cycles of the live kernel time
+            simds, clock_hz = 256 * 4, 2.4e9
+            valu = {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+                    "frac_of_issue_slots": pmc["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * kernel_ms * 1e-3),
+                    "source": "SQ_INSTS_VALU of the same file; 256 CUs x 4 SIMDs, 4 cycles per wave64 "
+                              "instruction, 2.4 GHz"}
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "k_solve", "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",
+            "valu_issue": valu,
+            "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"}
+
+
+def config1_closed_loop(args):
+    """BASELINE configs[0]: scenario_two_straight, single ego, horizon 50, as the reference runs it — one
+    CILQRSolver instance, solve() once per 0.1 s tick, ego <- row 1 of the plan (motion_planning.cpp:178-197) —
+    through the drop-in class (B = 1 per call, host buffers in and out: the PCIe-inclusive path)."""
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the CILQR solve path has no CPU fallback")
+    import cilqr_amd as pkg
+    cfg = pkg.GlobalConfig.get_instance("two_straight")
+    sc = pkg.build_scenario(cfg, "two_straight")
+    N = args.horizon or 50
+    ticks = min(args.ticks, sc.routes.shape[1] - N - 1)
+    solver = pkg.CILQRSolver(cfg, N=N)
+    obs_full = sc.obstacles
+    x0 = sc.ego_state.copy()
+    lat, its, states = [], [], [x0.copy()]
+    for t in range(ticks):
+        t0 = time.perf_counter()
+        u, x = solver.solve(x0, sc.lane, sc.target_velocity, obs_full[:, t:], sc.road_borders)
+        lat.append(time.perf_counter() - t0)
+        its.append(int(solver.last_result["iters"]))
+        x0 = x[1].copy()
+        states.append(x0.copy())
+    lat, its = np.array(lat), np.array(its)
+    out = {"metric": "iLQR iterations/sec (batch x horizon)", "value": float(its[1:].sum() / lat[1:].sum()),
+           "unit": "iLQR iterations/s", "n_gpus": 1, "steps": int(ticks), "warmup": 1,
+           "ms_per_step": float(lat[1:].mean() * 1e3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "scenario_two_straight.yaml values, noise-free obstacle routes",
+           "config": {"workload": f"config1_two_straight_single_ego_N{N}_closed_loop", "baseline_config": 1,
+                      "batch_per_gpu": 1, "horizon": N, "ticks": int(ticks),
+                      "parallelism": "one ego, one wavefront (+ helper wavefront)"},
+           "extra": {"us_per_iteration_gpu": float(lat[1:].sum() / its[1:].sum() * 1e6),
+                     "solve_latency_ms": {"first_tick_incl_setup": float(lat[0] * 1e3), "mean": float(lat[1:].mean() * 1e3),
+                                          "p50": float(np.median(lat[1:]) * 1e3), "max": float(lat[1:].max() * 1e3)},
+                     "iterations_per_tick_mean": float(its.mean()), "iterations_total": int(its.sum()),
+                     "note": "latency of the drop-in solve(): scenario tables re-used across ticks when unchanged, "
+                             "host buffers in/out, one stream synchronisation per tick"}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle, Scene
+        for mode in ("libm", "det"):
+            orc = Oracle(mode)
+            s = orc.solver(solver.params)
+            s.reset()
+            scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, obs_full, sc.road_borders, sc.target_velocity)
+            x0 = sc.ego_state.copy()
+            tl, ti, same = [], [], 0
+            for t in range(ticks):
+                t0 = time.perf_counter()
+                r = s.solve(x0, scene, tick=t)
+                tl.append(time.perf_counter() - t0)
+                ti.append(int(r["res"]["iters"]))
+                x0 = r["x"][1].copy()
+                same += int(np.array_equal(x0, states[t + 1]))
+            tl, ti = np.array(tl), np.array(ti)
+            if mode == "libm":
+                out["cpu_baseline"] = {"value": float(ti[1:].sum() / tl[1:].sum()), "unit": "iLQR iterations/s", "cores": 1,
+                                       "kind": "port", "sample": f"the same {ticks}-tick closed loop, one thread, glibc libm",
+                                       "us_per_iteration": float(tl[1:].sum() / ti[1:].sum() * 1e6),
+                                       "solve_latency_ms_mean": float(tl[1:].mean() * 1e3),
+                                       "iterations_total": int(ti.sum())}
+            else:
+                out["extra"]["closed_loop_ticks_bit_identical_to_det_oracle"] = same
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.config == 1:
+        return config1_closed_loop(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         # called directly with --gpus N: re-launch as one process per GPU, the way the driver does
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -137,130 +359,80 @@ def main():
     if world > 1 or os.environ.get("CILQR_FORCE_DIST") == "1":  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     import cilqr_amd as pkg
-
-    wl, B = make_workload(pkg, args.config, args.batch, args.horizon, rank, world)
-    N = wl.N
-    eng = pkg.BatchedCILQR(wl.params, wl.scenes, device=local_rank)
+    from importlib import import_module
+    st_mod = import_module("toy-example-of-ilqr_amd.stats")
     dev = torch.device("cuda", local_rank)
-    d_x0 = torch.from_numpy(wl.x0).to(dev)
-    d_sid = torch.from_numpy(wl.scenario_id).to(dev)
-    d_pid = torch.from_numpy(wl.param_id).to(dev)
-    d_tick = torch.from_numpy(wl.tick).to(dev)
-    d_u = torch.empty((B, N, 2), dtype=torch.float64, device=dev)
-    d_x = torch.empty((B, N + 1, 4), dtype=torch.float64, device=dev)
-    d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        eng.solve_batch_device(B, d_x0.data_ptr(), d_sid.data_ptr(), d_pid.data_ptr(), d_tick.data_ptr(), 0,
-                               d_u.data_ptr(), d_x.data_ptr(), d_res.data_ptr(), 0, 0, stream.cuda_stream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev0[i].record(stream)
-        step()
-        ev1[i].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    cfg_id = args.config or (5 if world == 1 else 4)
+    wl, B = make_workload(pkg, cfg_id, args.batch, args.horizon, rank)
+    N = wl.N
+    run = GpuRun(pkg, torch, wl, B, local_rank)
+    elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier)
+    stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, dev if dist is not None else None)
+    value = stats[0] * args.steps / tmax
+    gpu_u = gpu_x = None
+    if rank == 0 and not args.no_cpu_baseline:
+        nb = min(B, 1024)
+        gpu_u, gpu_x = run.d_u[:nb].cpu().numpy(), run.d_x[:nb].cpu().numpy()
+    pipelined = run.pipelined(args.steps, args.streams) if (world == 1 and args.streams > 1) else None
+    run.close()
 
-    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
-    M_of = wl.M_of
-
-    # Not the headline: the same K steps with several batches in flight (one handle + HIP stream each).  A 1024
-    # batch leaves most wave slots idle while its slowest trajectories finish; independent batches on other
-    # streams fill them.  Reported under extra.pipelined, next to the strictly sequential headline value.
-    pipelined = None
-    if world == 1 and args.streams > 1:
-        S = args.streams
-        engs = [eng] + [pkg.BatchedCILQR(wl.params, wl.scenes, device=local_rank) for _ in range(S - 1)]
-        strs = [torch.cuda.Stream(dev) for _ in range(S)]
-        outs = [(d_u, d_x, d_res)] + [(torch.empty_like(d_u), torch.empty_like(d_x), torch.zeros_like(d_res))
-                                      for _ in range(S - 1)]
-
-        def pstep(i):
-            e, st, (ou, ox, orr) = engs[i % S], strs[i % S], outs[i % S]
-            e.solve_batch_device(B, d_x0.data_ptr(), d_sid.data_ptr(), d_pid.data_ptr(), d_tick.data_ptr(), 0,
-                                 ou.data_ptr(), ox.data_ptr(), orr.data_ptr(), 0, 0, st.cuda_stream)
-
-        for i in range(S):
-            pstep(i)
-        torch.cuda.synchronize(dev)
-        tp = time.perf_counter()
-        for i in range(args.steps):
-            pstep(i)
-        torch.cuda.synchronize(dev)
-        tp = time.perf_counter() - tp
-        same = all(bool(torch.equal(o[1], d_x)) and bool(torch.equal(o[2], d_res)) for o in outs[1:])
-        pipelined = {"streams": S, "value": float(res["iters"].sum()) * args.steps / tp,
-                     "ms_per_step": tp / args.steps * 1e3, "results_identical_to_sequential": same}
-        for e in engs[1:]:
-            e.close()
-    from importlib import import_module
-    st_mod = import_module("toy-example-of-ilqr_amd.stats")
-    stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, M_of), elapsed, dist, dev if dist is not None else None)
-    total_iters, total_trials = stats[0], stats[1]
-    value = total_iters * args.steps / tmax
+    # the other workload of the default command: config 2 (1024 trajectories per GPU), a latency measurement
+    second = None
+    if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
+        wl2, B2 = make_workload(pkg, 2, 0, 0, rank)
+        run2 = GpuRun(pkg, torch, wl2, B2, local_rank)
+        steps2 = max(args.steps, 20)
+        el2, kms2, res2 = run2.timed(steps2, min(args.warmup, 3), barrier)
+        st2, tmax2 = st_mod.reduce_stats(st_mod.local_stats(res2, wl2.N, wl2.M_of), el2, dist, dev if dist is not None else None)
+        run2.close()
+        if rank == 0:
+            rl2 = roofline_block(pkg, wl2, res2, kms2, world)
+            second = {"workload": wl2.name, "baseline_config": 2, "batch_per_gpu": B2, "steps": steps2,
+                      "value": st2[0] * steps2 / tmax2, "unit": "iLQR iterations/s", "ms_per_step": tmax2 / steps2 * 1e3,
+                      "kernel_ms": kms2, "iterations_per_launch_rank0": float(res2["iters"].sum()),
+                      "slowest_trajectory_iterations": int(res2["iters"].max()),
+                      "hbm_frac": rl2["frac"], "traffic": rl2["traffic"], "valu_issue": rl2["valu_issue"],
+                      "note": "one launch of 1024 trajectories occupies a quarter of the chip's wave slots; its wall "
+                              "time is the slowest trajectory's (DESIGN.md)"}
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
-        alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot be nested
-        # inside the benchmark); recorded under profiles/ together with how it was collected
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_config2.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == wl.name and world == 1:
-                traffic = pmc["hbm_bytes_per_launch_corrected"]
-                traffic_src = "profiles/r01_pmc_config2.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-        # the bound that actually applies: vector-instruction issue.  Wave instructions per launch from the SQ
-        # counter pass (profiles/), 4 cycles of a SIMD each at best, against all SIMD-cycles of the live kernel time
-        valu = None
-        sq_path = os.path.join(ROOT, "profiles", "r01_pmc_sq_config2.json")
-        if os.path.exists(sq_path) and traffic is not None:
-            sq = json.load(open(sq_path))
-            if "SQ_INSTS_VALU" in sq:
-                simds, clock_hz = 256 * 4, 2.4e9
-                valu = {"wave_instructions_per_launch": sq["SQ_INSTS_VALU"],
-                        "frac_of_issue_slots": sq["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * kernel_ms * 1e-3),
-                        "source": "profiles/r01_pmc_sq_config2.json (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per "
-                                  "wave64 instruction, 2.4 GHz"}
         out = {
             "metric": "iLQR iterations/sec (batch x horizon)", "value": value, "unit": "iLQR iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl.name, "baseline_config": args.config, "batch_per_gpu": B,
+            "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B,
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
                        "parallelism": f"trajectory-sharded x{world}, one wavefront per trajectory"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_solve", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "valu_issue": valu,
-                         "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"},
+            "roofline": roofline_block(pkg, wl, res, kernel_ms, world),
             "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
-                      "line_search_trials_per_step": float(total_trials),
+                      "line_search_trials_per_step": float(stats[1]),
                       "solves_per_s": stats[8] * args.steps / tmax,
                       "step_updates_per_s": value * N,
+                      "timed_region_s": tmax,
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
-                      "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined},
+                      "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
+                      ("config2_latency" if world == 1 else "config2_weak_scaling"): second},
         }
+        if cfg_id == 5:
+            # convergence-vs-throughput view of the sweep: per barrier setting, over its 4096 solves
+            pid = wl.param_id
+            out["extra"]["per_setting"] = [
+                {"obstacle_exp_q1": float(wl.params[s].obstacle_exp_q1), "obstacle_exp_q2": float(wl.params[s].obstacle_exp_q2),
+                 "iterations_mean": float(res["iters"][pid == s].mean()),
+                 "converged_frac": float((res["end_reason"][pid == s] == 0).mean()),
+                 "J_final_median": float(np.nanmedian(res["J_final"][pid == s]))} for s in range(len(wl.params))]
         if not args.no_cpu_baseline:
             cores, cores_note = usable_cores()
             threads = args.cpu_threads or cores
@@ -268,18 +440,11 @@ def main():
             if cores_note:
                 cb["cores_note"] = cores_note
             out["cpu_baseline"] = cb
-            # parity of the run that was just timed (the oracle is only the checker here)
-            nb = r["res"].shape[0]
-            out["extra"]["cpu_check"] = {
-                "trajectories": nb,
-                "same_iterations": int((r["res"]["iters"] == res["iters"][:nb]).sum()),
-                "max_abs_dJ_final": float(np.nanmax(np.abs(r["res"]["J_final"] - res["J_final"][:nb]))),
-            }
+            out["extra"]["cpu_check"] = parity_check(gpu_u, gpu_x, res, r)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

@@ -64,7 +64,17 @@ enum {
 };
 
 /* why solve() left its loop (src/cilqr_solver.cpp:127-148) */
-enum { CILQR_END_CONVERGED = 0, CILQR_END_MAX_LAMB = 1, CILQR_END_MAX_ITER = 2 };
+enum {
+    CILQR_END_CONVERGED = 0,
+    CILQR_END_MAX_LAMB = 1,
+    CILQR_END_MAX_ITER = 2,
+    /* not solved: scenario_id / param_id outside the tables, tick < 0, or an obstacle route shorter than
+     * tick + N + 1 (upstream: RoutingLine::operator[] throws std::out_of_range, src/utils.cpp:52-58).  Only the
+     * device-pointer entry point reports it this way (its index arrays cannot be checked on the host): u, x
+     * and the costs of that trajectory are NaN, iters = 0.  The host-pointer entry points return
+     * CILQR_ERR_BAD_ARG / CILQR_ERR_OBSTACLE_HORIZON before launching anything. */
+    CILQR_END_BAD_INPUT = 3
+};
 
 /* The non-ego arguments of one solve() call, shared by many trajectories of a batch:
  * ref_waypoints (.x/.y/.yaw of a ReferenceLine, include/utils.hpp:32-51), the full obstacle
@@ -130,8 +140,21 @@ int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0, const int32_
                       double* u_out, double* x_out, cilqr_result* res_out,
                       cilqr_trace_rec* trace_out, int32_t trace_cap);
 
-/* Same with every array already resident in HBM; enqueues on `stream` (hipStream_t) and returns
- * without synchronising. */
+/* CILQRSolver::solve exactly as main() calls it (include/cilqr_solver.hpp:37-41, src/motion_planning.cpp:194-196):
+ * ONE ego, every argument handed over on every call.  x0[4]; sc = (ref_waypoints, obs_preds from the current tick
+ * on, road_boaders, ref_velo); last_u NULL or [N][2] (warm start, cs:163-180); u_out[N][2], x_out[N+1][4].
+ * The tables stay in HBM between calls and are uploaded again only when their contents differ bitwise from what
+ * is there; obstacle predictions that are the tail of the routes uploaded earlier — what
+ * utils::get_sub_routing_lines (src/utils.cpp:88-103) hands over tick after tick — only move a tick offset.
+ * Uses scenario slot 0 of the handle (replacing whatever cilqr_set_scenarios put there) and parameter set 0. */
+int cilqr_solve(cilqr_handle* h, const double* x0, const cilqr_scenario_desc* sc, const double* last_u,
+                double* u_out, double* x_out, cilqr_result* res_out);
+/* how often cilqr_solve uploaded tables / re-used the resident ones (either pointer may be NULL) */
+int cilqr_solve_cache_stats(cilqr_handle* h, int64_t* uploads, int64_t* reuses);
+
+/* Same as cilqr_solve_batch with every array already resident in HBM; enqueues on `stream` (hipStream_t) and
+ * returns without synchronising.  The index arrays are checked on the device: a trajectory with an id outside the
+ * tables or too short an obstacle route is not solved and ends with CILQR_END_BAD_INPUT. */
 int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
                              const int32_t* d_scenario_id, const int32_t* d_param_id,
                              const int32_t* d_tick, const double* d_last_u, double* d_u_out,

@@ -94,10 +94,9 @@ class CILQRSolver {
         sc.M = M; sc.obs = obs; sc.T = T;
         sc.road_borders[0] = road_boaders[0]; sc.road_borders[1] = road_boaders[1];
         sc.ref_velo = ref_velo;
-        check(cilqr_set_scenarios(h_, &sc, 1), "cilqr_set_scenarios");
+        // the tables stay resident in HBM from tick to tick (cilqr_solve uploads only what changed)
         const bool warm = !is_first_solve_ && params_.use_last_solution;
-        check(cilqr_solve_batch(h_, 1, x0, nullptr, nullptr, nullptr, warm ? last_solve_u_.data() : nullptr, u_out,
-                                x_out, res, nullptr, 0), "cilqr_solve_batch");
+        check(cilqr_solve(h_, x0, &sc, warm ? last_solve_u_.data() : nullptr, u_out, x_out, res), "cilqr_solve");
         is_first_solve_ = false;
         last_solve_u_.assign(u_out, u_out + 2 * params_.N);
     }

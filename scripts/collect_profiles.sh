@@ -1,43 +1,56 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): collects everything profiles/ and DESIGN.md quote for one build.
-#   scripts/collect_profiles.sh TAG      ->  gpurun_out/TAG/...
+#   scripts/collect_profiles.sh TAG [quick]     ->  gpurun_out/TAG/...
 # rocprofv3 counter passes are separate runs with --kernel-trace only (no sys/hip/hsa trace next to --pmc).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+QUICK=${2:-}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PY=python
 BENCH="$PY $ROOT/bench.py"
+ONLY="--no-cpu-baseline --no-extras"
 
-# 1. the benchmark line as the driver runs it (includes the CPU baseline leg)
+# 1. the benchmark line as the driver runs it (headline = config 5, config 2 under extra, CPU baseline leg)
 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
 
-# 2. kernel trace + stats of the same command (without the CPU leg)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --no-cpu-baseline > "$OUT/stats.log" 2>&1
+# 2. kernel trace + stats of the same command (headline workload only: every k_solve launch is the headline's)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config5" -- $BENCH $ONLY > "$OUT/stats_config5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config2" -- $BENCH --config 2 $ONLY > "$OUT/stats_config2.log" 2>&1
 
-# 3. HBM traffic and SQ counters, one small group per pass
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" \
-           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
-    name=$(echo $grp | tr ' ' '+')
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$name" -- $BENCH --steps 3 --warmup 1 --no-cpu-baseline \
-        > "$OUT/pmc_$name.log" 2>&1
+# 3. HBM traffic and SQ counters per workload, one small counter group per pass
+wl_args() { case $1 in c5) echo "--config 5";; c3) echo "--config 3";; c2) echo "--config 2";; c2b16k) echo "--config 2 --batch 16384";; c4) echo "--config 4";; esac; }
+for wl in c5 c3 c2 c2b16k c4; do
+    for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" \
+               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
+        name=$(echo $grp | tr ' ' '+')
+        rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_${wl}_$name" -- \
+            $BENCH $(wl_args $wl) --steps 3 --warmup 1 $ONLY > "$OUT/pmc_${wl}_$name.log" 2>&1
+    done
 done
 
-# 4. the other BASELINE configurations (parity-test cases, one bench line each)
-for c in 3 4 5; do
-    $BENCH --config $c --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.err"
+# 4. the other BASELINE configurations (one bench line each) and a batch sweep of config 2
+for c in 2 3 4; do
+    $BENCH --config $c --steps 5 --warmup 1 $ONLY > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.err"
 done
-# batch sweep of config 2 (how much of the chip one launch fills)
+if [ -z "$QUICK" ]; then
 for b in 512 2048 4096 16384; do
-    $BENCH --config 2 --batch $b --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_config2_B$b.json" 2>/dev/null
+    $BENCH --config 2 --batch $b --steps 3 --warmup 1 $ONLY > "$OUT/bench_config2_B$b.json" 2>/dev/null
 done
-
-# 4b. four batches in flight (extra.pipelined)
-$BENCH --streams 4 --steps 40 --warmup 3 --no-cpu-baseline > "$OUT/bench_pipelined.json" 2>/dev/null
+# 4b. four batches in flight (extra.pipelined), config 2
+$BENCH --config 2 --streams 4 --steps 40 --warmup 3 $ONLY > "$OUT/bench_pipelined.json" 2>/dev/null
+fi
 
 # 5. in-kernel phase accounting
-$PY $ROOT/scripts/phase_profile.py --config 2 > "$OUT/phase_config2.json" 2> "$OUT/phase_config2.err"
-$PY $ROOT/scripts/phase_profile.py --config 3 --batch 8192 > "$OUT/phase_config3.json" 2> "$OUT/phase_config3.err"
-ls -R "$OUT" | head -50
+for c in 2 3 5; do
+    $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
+done
+
+# 6. the RCCL branch of bench.py on one rank (init_process_group("nccl") + the two all-reduces + barrier)
+CILQR_FORCE_DIST=1 $BENCH --config 4 --steps 2 --warmup 1 $ONLY > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+
+# 7. BASELINE configs[0]: single ego, closed loop through the drop-in solve()
+$BENCH --config 1 > "$OUT/bench_config1.json" 2> "$OUT/bench_config1.err"
+ls "$OUT" | head -80

@@ -12,15 +12,22 @@ import cilqr_amd as pkg
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
-ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--horizon", type=int, default=50)
 args = ap.parse_args()
-wl = {2: pkg.workloads.config2, 3: pkg.workloads.config3}[args.config](B=args.batch, N=args.horizon)
+W = pkg.workloads
+if args.config == 2:
+    wl = W.config2(B=args.batch or 1024, N=args.horizon)
+elif args.config == 3:
+    wl = W.config3(B=args.batch or 8192, N=args.horizon)
+else:
+    wl = W.config5(B_base=args.batch or 4096, N=args.horizon)
 eng = pkg.BatchedCILQR(wl.params, wl.scenes)
-eng.solve_batch(wl.x0)
+ids = dict(scenario_id=wl.scenario_id, param_id=wl.param_id, tick=wl.tick)
+eng.solve_batch(wl.x0, **ids)
 eng.set_phase_profiling(True)
 eng.set_timing(True)
-out = eng.solve_batch(wl.x0)
+out = eng.solve_batch(wl.x0, **ids)
 ms = eng.last_kernel_ms()
 cyc = eng.phase_cycles(wl.B)
 names = ["init", "derivs", "backward", "rollout", "trial_cost", "accept", "total", "iters"]

@@ -2,7 +2,8 @@
 """Turn gpurun_out/TAG (written by scripts/collect_profiles.sh on the GPU box) into the small, tracked
 summaries under profiles/.   usage: scripts/summarize_profiles.py TAG [--current]
 
---current also rewrites profiles/r01_pmc_config2.json, the file bench.py reads `roofline.traffic` from.
+--current also rewrites profiles/pmc_current.json, the file bench.py reads `roofline.traffic` and
+`roofline.valu_issue` from (keyed by workload name).
 """
 import csv
 import glob
@@ -18,67 +19,94 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
 
+def last_json(path):
+    if not os.path.exists(path) or not os.path.getsize(path):
+        return None
+    try:
+        return json.loads(open(path).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def counters(pattern):
     """per-launch value of every counter in the pass (summed over the dispatch's rows, averaged over launches)"""
     out = {}
     for path in glob.glob(os.path.join(src, pattern, "*", "*_counter_collection.csv")):
         per = defaultdict(lambda: defaultdict(float))
+        kern = None
         for r in csv.DictReader(open(path)):
             if "k_solve" in r["Kernel_Name"]:
                 per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+                kern = r["Kernel_Name"]
         for name, d in per.items():
             out[name] = sum(d.values()) / len(d)
             out[name + "_launches"] = len(d)
+        if kern:
+            out["kernel"] = kern
     return out
 
 
-bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-json.dump(bench, open(os.path.join(dst, f"{tag}_config2_bench.json"), "w"), indent=1)
+bench = last_json(os.path.join(src, "bench.json"))
+if bench:
+    json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
+for c in ("config5", "config2"):
+    stats = glob.glob(os.path.join(src, f"stats_{c}", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_{c}_kernel_stats.csv"))
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_config2_kernel_stats.csv"))
-
-f = counters("pmc_FETCH_SIZE")
-w = counters("pmc_WRITE_SIZE")
-alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-raw = (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0
-cor = (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0
-pmc = {
-    "workload": bench["config"]["workload"],
-    "command": "rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
-               "--no-cpu-baseline (scripts/collect_profiles.sh: one small counter group per pass, no other trace domain)",
-    "kernel": "k_solve<false, 1, false, true, false, 1> (main + helper wavefront per trajectory)",
-    "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request "
-                 "for wide coalesced streams (MI355X_MICROARCH.md HBM section), so the read side is doubled as an upper "
-                 "bound; this kernel's reads are mostly 8-byte gathers, for which the factor is uncalibrated",
-    "FETCH_SIZE_KiB_per_launch": f["FETCH_SIZE"],
-    "WRITE_SIZE_KiB_per_launch": w["WRITE_SIZE"],
-    "hbm_bytes_per_launch_raw": raw,
-    "hbm_bytes_per_launch_corrected": cor,
-    "algorithmic_bytes_per_launch": alg,
-    "note": "the excess over the algorithmic bytes is the scratch slab of the 20 trial trajectories (49 KB written per "
-            "trajectory-iteration, mostly never read back)",
-}
-json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_config2.json"), "w"), indent=1)
-if "--current" in sys.argv:
-    json.dump(pmc, open(os.path.join(dst, "r01_pmc_config2.json"), "w"), indent=1)
-
-sq = {}
-for pat in glob.glob(os.path.join(src, "pmc_SQ*")):
-    if os.path.isdir(pat):
-        sq.update({k: v for k, v in counters(os.path.basename(pat)).items() if not k.endswith("_launches")})
-sq["note"] = ("per launch of k_solve on config 2 (1024 blocks x 2 wavefronts); SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU "
-              "count quad-cycles")
-json.dump(sq, open(os.path.join(dst, f"{tag}_pmc_sq_config2.json"), "w"), indent=1)
-
-other = {"note": "python bench.py --config C [--batch B] --steps 3 --warmup 1 --no-cpu-baseline on one MI355X; "
-                 "parity-test configurations of BASELINE.json and a batch sweep of config 2, not the benchmark line"}
-for path in sorted(glob.glob(os.path.join(src, "bench_config*.json"))):
-    txt = open(path).read().strip()
-    if not txt:
+# per-workload counters.  The workload name of each pass comes from the bench line the pass printed.
+pmc_all = {}
+for wl in ("c5", "c3", "c2", "c2b16k", "c4"):
+    name = alg = iters = kernel_ms = None
+    for log in glob.glob(os.path.join(src, f"pmc_{wl}_*.log")):
+        for line in open(log, errors="replace"):
+            if line.startswith('{"metric"'):
+                b = json.loads(line)
+                name = b["config"]["workload"]
+                alg = b["roofline"]["algorithmic_bytes_per_launch"]
+                iters = b["extra"]["iterations_per_step_rank0"]
+    if name is None:
         continue
-    b = json.loads(txt.splitlines()[-1])
+    f = counters(f"pmc_{wl}_FETCH_SIZE")
+    w = counters(f"pmc_{wl}_WRITE_SIZE")
+    sq = {}
+    for pat in glob.glob(os.path.join(src, f"pmc_{wl}_SQ*")):
+        if os.path.isdir(pat):
+            sq.update({k: v for k, v in counters(os.path.basename(pat)).items() if not k.endswith("_launches")})
+    if "FETCH_SIZE" not in f or "WRITE_SIZE" not in w:
+        continue
+    ent = {
+        "workload": name,
+        "kernel": f.get("kernel"),
+        "source": f"profiles/{tag}_pmc.json: rocprofv3 --pmc <group> --kernel-trace -- python bench.py <workload> --steps 3 "
+                  "--warmup 1 --no-cpu-baseline --no-extras, one counter group per pass (scripts/collect_profiles.sh); "
+                  "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 tallies 128-B read requests at 64 B "
+                  "(MI355X_MICROARCH.md, HBM section), so the read side is doubled — an upper bound for this kernel's "
+                  "mostly 8-byte gathers; WRITE_SIZE taken as reported",
+        "FETCH_SIZE_KiB_per_launch": f["FETCH_SIZE"],
+        "WRITE_SIZE_KiB_per_launch": w["WRITE_SIZE"],
+        "hbm_bytes_per_launch_raw": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
+        "hbm_bytes_per_launch_corrected": (2.0 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
+        "algorithmic_bytes_per_launch": alg,
+        "iterations_per_launch": iters,
+    }
+    ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch_corrected"] / alg if alg else None
+    ent["hbm_bytes_per_iteration_corrected"] = ent["hbm_bytes_per_launch_corrected"] / iters if iters else None
+    for k, v in sq.items():
+        if k != "kernel":
+            ent[k] = v
+    pmc_all[name] = ent
+if pmc_all:
+    json.dump(pmc_all, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+    if "--current" in sys.argv:
+        json.dump(pmc_all, open(os.path.join(dst, "pmc_current.json"), "w"), indent=1)
+
+other = {"note": "python bench.py --config C [--batch B] --steps 3..5 --warmup 1 --no-cpu-baseline --no-extras on one "
+                 "MI355X: the other BASELINE configurations and a batch sweep of config 2"}
+for path in sorted(glob.glob(os.path.join(src, "bench_config[2-5]*.json"))):
+    b = last_json(path)
+    if not b:
+        continue
     e = b["extra"]
     other[b["config"]["workload"]] = {
         "it_per_s": round(b["value"]), "ms_per_step": round(b["ms_per_step"], 3), "solves_per_s": round(e["solves_per_s"]),
@@ -86,16 +114,29 @@ for path in sorted(glob.glob(os.path.join(src, "bench_config*.json"))):
         "max_lamb": e["max_lamb"], "max_iter": e["max_iter"], "hbm_frac": round(b["roofline"]["frac"], 5)}
 json.dump(other, open(os.path.join(dst, f"{tag}_other_configs.json"), "w"), indent=1)
 
-pp = os.path.join(src, "bench_pipelined.json")
-if os.path.exists(pp) and os.path.getsize(pp):
-    b = json.loads(open(pp).read().strip().splitlines()[-1])
-    json.dump({"command": "python bench.py --streams 4 --steps 40 --warmup 3 --no-cpu-baseline",
+b = last_json(os.path.join(src, "bench_pipelined.json"))
+if b:
+    json.dump({"command": "python bench.py --config 2 --streams 4 --steps 40 --warmup 3 --no-cpu-baseline --no-extras",
                "sequential_value": b["value"], "pipelined": b["extra"]["pipelined"]},
               open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
 
-for c in (2, 3):
+for c in (2, 3, 5):
     p = os.path.join(src, f"phase_config{c}.json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_phase_config{c}.json"))
-print(json.dumps({"bench_value": bench["value"], "kernel_ms": bench["roofline"]["kernel_ms"], "traffic": cor, "sq": sq,
+
+b = last_json(os.path.join(src, "bench_force_dist.json"))
+if b:
+    err = open(os.path.join(src, "bench_force_dist.err"), errors="replace").read().splitlines()[-15:]
+    json.dump({"command": "CILQR_FORCE_DIST=1 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
+               "what": "bench.py's multi-GPU branch on one rank: init_process_group('nccl') = RCCL, dist.barrier(), the SUM "
+                       "and MAX all-reduces of the statistics, destroy_process_group",
+               "bench_line": b, "stderr_tail": err}, open(os.path.join(dst, f"{tag}_force_dist.json"), "w"), indent=1)
+b = last_json(os.path.join(src, "bench_config1.json"))
+if b:
+    json.dump(b, open(os.path.join(dst, f"{tag}_config1.json"), "w"), indent=1)
+
+print(json.dumps({"bench_value": bench and bench["value"], "kernel_ms": bench and bench["roofline"]["kernel_ms"],
+                  "pmc": {k: {"traffic": v["hbm_bytes_per_launch_corrected"], "ratio": v["traffic_over_algorithmic"],
+                              "valu": v.get("SQ_INSTS_VALU")} for k, v in pmc_all.items()},
                   "other": {k: v["it_per_s"] for k, v in other.items() if k != "note"}}, indent=1))

@@ -25,7 +25,7 @@ DBG_UNIFORM_BACKWARD = 2
 
 STATUS_NAMES = {0: "RUNNING", 1: "CONVERGED", 2: "BACKWARD_PASS_FAIL", 3: "FORWARD_PASS_FAIL",
                 4: "FORWARD_PASS_SMALL_STEP"}
-END_NAMES = {0: "CONVERGED", 1: "MAX_LAMB", 2: "MAX_ITER"}
+END_NAMES = {0: "CONVERGED", 1: "MAX_LAMB", 2: "MAX_ITER", 3: "BAD_INPUT"}
 
 
 class CilqrParams(C.Structure):
@@ -96,6 +96,8 @@ SIGNATURES = {
     "cilqr_set_params": (C.c_int, [_P, C.POINTER(CilqrParams), _I]),
     "cilqr_set_scenarios": (C.c_int, [_P, C.POINTER(CilqrScenarioDesc), _I]),
     "cilqr_solve_batch": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "cilqr_solve": (C.c_int, [_P, _P, C.POINTER(CilqrScenarioDesc), _P, _P, _P, _P]),
+    "cilqr_solve_cache_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cilqr_solve_batch_device": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cilqr_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "cilqr_set_timing": (C.c_int, [_P, _I]),

@@ -65,13 +65,14 @@ class SceneTable:
 class BatchedCILQR:
     """A device handle with its parameter table and scenario tables; batch entry points."""
 
-    def __init__(self, params, scenes, device=0):
+    def __init__(self, params, scenes=None, device=0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         check(self._lib.cilqr_create(int(device), C.byref(self._h)), "cilqr_create")
         self.device = int(device)
         self.set_params(params)
-        self.set_scenarios(scenes)
+        if scenes is not None:  # solve_one() brings its scenario with every call
+            self.set_scenarios(scenes)
 
     # -- tables -------------------------------------------------------------------------------
     def set_params(self, params):
@@ -115,6 +116,24 @@ class BatchedCILQR:
         if trace is not None:
             out["trace"] = trace
         return out
+
+    def solve_one(self, x0, scene, last_u=None):
+        """cilqr_solve: CILQRSolver::solve for one ego with all arguments handed over (hpp:37-41); the tables
+        stay resident in HBM between calls when they are unchanged.  Returns (u, x, res)."""
+        N = self.N
+        x0 = _f64(x0).reshape(4)
+        lu = None if last_u is None else _f64(last_u).reshape(N, 2)
+        u = np.empty((N, 2))
+        x = np.empty((N + 1, 4))
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        d = scene.desc()
+        check(self._lib.cilqr_solve(self._h, _p(x0), C.byref(d), _p(lu), _p(u), _p(x), _p(res)), "cilqr_solve")
+        return u, x, res[0]
+
+    def solve_cache_stats(self):
+        up, re = C.c_int64(0), C.c_int64(0)
+        check(self._lib.cilqr_solve_cache_stats(self._h, C.byref(up), C.byref(re)), "cilqr_solve_cache_stats")
+        return int(up.value), int(re.value)
 
     def solve_batch_device(self, B, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u, d_x, d_res,
                            d_trace=0, trace_cap=0, stream=0):
@@ -270,13 +289,10 @@ class CILQRSolver:
                             for r in obs_preds])
         scene = SceneTable(ref_waypoints.x, ref_waypoints.y, ref_waypoints.yaw, obs, road_boaders, ref_velo)
         if self._engine is None:
-            self._engine = BatchedCILQR(self.params, scene, self.device)
-        else:
-            self._engine.set_scenarios(scene)
+            self._engine = BatchedCILQR(self.params, None, self.device)
         warm = (not self.is_first_solve) and bool(self.params.use_last_solution)
-        out = self._engine.solve_batch(np.asarray(x0, dtype=np.float64).reshape(1, 4),
-                                       last_u=self.last_solve_u[None] if warm else None)
+        u, x, res = self._engine.solve_one(x0, scene, last_u=self.last_solve_u if warm else None)
         self.is_first_solve = False
-        self.last_solve_u = out["u"][0].copy()
-        self.last_result = out["res"][0]
-        return out["u"][0], out["x"][0]
+        self.last_solve_u = u.copy()
+        self.last_result = res
+        return u, x
