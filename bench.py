@@ -441,10 +441,15 @@ def main():
                 cb["cores_note"] = cores_note
             out["cpu_baseline"] = cb
             out["extra"]["cpu_check"] = parity_check(gpu_u, gpu_x, res, r)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        # RCCL keeps a version banner in the C library's stdout buffer and emits it at exit, after the JSON
+        # line; leave without running the C exit handlers so that the line above stays the only output
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,11 @@ struct orc_solver {
     double* alm_mu_next; /* [N][alm_cols] */
     int alm_cols;
     int cost_evals;
+    /* optional decision-margin recorder (orc_set_margin_buffer): test infrastructure on top of test
+     * infrastructure — how close every discrete decision of an iteration came to going the other way */
+    orc_margin_rec* mg_buf;
+    int mg_cap;
+    orc_margin_rec mg_cur;
     /* work space, allocated once (keeps the batch driver free of malloc traffic) */
     double *ws_ref, *ws_lub, *ws_luub, *ws_lxb, *ws_lxxb, *ws_dfdx, *ws_dfdu;
     double *ws_u, *ws_x, *ws_nu, *ws_nx, *ws_d, *ws_K;
@@ -282,13 +287,24 @@ void orc_obstacle_constr_derivatives(const orc_params* p, const double ego[4], c
 }
 
 /* ---------- cs:289-314 get_ref_exact_points ---------- */
-void orc_ref_exact_points(const double* x, int32_t rows, const orc_scene* sc, double* ref, int32_t* idx) {
+static void mg_note(double* slot, double m) {
+    if (!(m >= *slot)) *slot = m; /* also takes NaN: a NaN decision is as fragile as it gets */
+}
+
+static void ref_exact_points_mg(const double* x, int32_t rows, const orc_scene* sc, double* ref, int32_t* idx,
+                                double* mg_ref) {
     int start_index = 0;
     for (int i = 0; i < rows; ++i) {
         int min_idx = -1;
         double min_distance = DBL_MAX;
         for (int j = start_index; j < sc->L; ++j) {
             double cur = M_HYPOT(x[i * 4 + 0] - sc->lane_x[j], x[i * 4 + 1] - sc->lane_y[j]);
+            if (mg_ref && min_idx >= 0) {
+                /* the comparison cur < min_distance, relative to the distances compared */
+                double sc_ = (min_distance > cur) ? min_distance : cur;
+                double df = cur - min_distance;
+                mg_note(mg_ref, ((df < 0) ? -df : df) / ((sc_ > 1e-300) ? sc_ : 1e-300));
+            }
             if (min_idx < 0 || cur < min_distance) {
                 min_idx = j;
                 min_distance = cur;
@@ -302,6 +318,10 @@ void orc_ref_exact_points(const double* x, int32_t rows, const orc_scene* sc, do
         if (idx) idx[i] = min_idx;
         start_index = min_idx;
     }
+}
+
+void orc_ref_exact_points(const double* x, int32_t rows, const orc_scene* sc, double* ref, int32_t* idx) {
+    ref_exact_points_mg(x, rows, sc, ref, idx, NULL);
 }
 
 static const double* obs_at(const orc_scene* sc, int j, int k) {
@@ -326,7 +346,7 @@ double orc_total_cost(orc_solver* s, const double* u, const double* x, const orc
     s->cost_evals++;
     if (p->solve_type == 1) ensure_alm(s, 8 + 2 * M);
     double* ref = s->ws_ref;
-    orc_ref_exact_points(x, N + 1, sc, ref, NULL);
+    ref_exact_points_mg(x, N + 1, sc, ref, NULL, s->mg_buf ? &s->mg_cur.ref_margin : NULL);
 
     double W[16] = {0}, R[4] = {0};
     W[0] = p->w_pos; W[5] = p->w_pos; W[10] = p->w_vel; W[15] = p->w_yaw; /* cs:23-27 */
@@ -427,7 +447,7 @@ static void cost_derivatives_and_Hessians(orc_solver* s, const double* u, const 
     s->status = ORC_RUNNING;
 
     double* ref = s->ws_ref;
-    orc_ref_exact_points(x, N + 1, sc, ref, NULL);
+    ref_exact_points_mg(x, N + 1, sc, ref, NULL, s->mg_buf ? &s->mg_cur.ref_margin : NULL);
 
     double W[16] = {0}, R[4] = {0};
     W[0] = p->w_pos; W[5] = p->w_pos; W[10] = p->w_vel; W[15] = p->w_yaw;
@@ -624,12 +644,23 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
         {
             double piv0 = Q_uu[0];
             int fail = 0;
+            if (s->mg_buf) {
+                /* piv0 <= 0 relative to the terms it is the sum of */
+                double a0 = s->l_uu[i * 4 + 0], b0 = prod4[0];
+                double sc0 = ((a0 < 0) ? -a0 : a0) + ((b0 < 0) ? -b0 : b0) + ((lamb < 0) ? -lamb : lamb);
+                mg_note(&s->mg_cur.pd_margin, ((piv0 < 0) ? -piv0 : piv0) / ((sc0 > 1e-300) ? sc0 : 1e-300));
+            }
             if (piv0 <= 0.0) {
                 fail = 1;
             } else {
                 double l00 = M_SQRT(piv0);
                 double l10 = Q_uu[2] / l00;
                 double piv1 = Q_uu[3] - l10 * l10;
+                if (s->mg_buf) {
+                    double q3 = (Q_uu[3] < 0) ? -Q_uu[3] : Q_uu[3];
+                    double sc1 = q3 + l10 * l10;
+                    mg_note(&s->mg_cur.pd_margin, ((piv1 < 0) ? -piv1 : piv1) / ((sc1 > 1e-300) ? sc1 : 1e-300));
+                }
                 if (piv1 <= 0.0) fail = 1;
             }
             if (fail) {
@@ -728,6 +759,28 @@ static iter_out iter_step(orc_solver* s, const double* u, const double* x, doubl
         double am1 = alpha - 1.0;
         am1 = (am1 < 0) ? -am1 : am1;
         double acd_abs = (actual_cost_decay < 0) ? -actual_cost_decay : actual_cost_decay;
+        if (s->mg_buf) {
+            /* every comparison of the verdict on this trial, in evaluation order, relative to the cost level the
+             * compared numbers are differences of */
+            double lvl = (ori_cost < 0) ? -ori_cost : ori_cost;
+            lvl = (lvl > 1e-300) ? lvl : 1e-300;
+            double m;
+            if (am1 < ORC_EPS) {
+                m = acd_abs - p->convergence_threshold;
+                mg_note(&s->mg_cur.ls_margin, ((m < 0) ? -m : m) / lvl);
+            }
+            if (!(am1 < ORC_EPS && acd_abs < p->convergence_threshold)) {
+                mg_note(&s->mg_cur.ls_margin, acd_abs / lvl); /* actual_cost_decay > 0 */
+                if (actual_cost_decay > 0.0) {
+                    double apx = -(alpha * alpha * delta_item[0] + alpha * delta_item[1]);
+                    mg_note(&s->mg_cur.ls_margin, ((apx < 0) ? -apx : apx) / lvl); /* approx < 0 */
+                    if (!(apx < 0.0)) {
+                        m = actual_cost_decay - p->accept_step_threshold * apx; /* decay / approx > threshold */
+                        mg_note(&s->mg_cur.ls_margin, ((m < 0) ? -m : m) / lvl);
+                    }
+                }
+            }
+        }
         if (am1 < ORC_EPS && acd_abs < p->convergence_threshold) {
             s->status = ORC_CONVERGED;
             out.new_J = new_J;
@@ -861,6 +914,7 @@ int orc_solve(orc_solver* s, const double x0[4], const orc_scene* sc, double* u_
         s->is_first_solve = 0;
     }
 
+    s->mg_cur.ls_margin = s->mg_cur.pd_margin = s->mg_cur.ref_margin = DBL_MAX; /* the initial cost's scan joins record 0 */
     double J = orc_total_cost(s, u, x, sc);
     double lamb = p->init_lamb;
     int is_exceed_max_itr = 1;
@@ -880,6 +934,10 @@ int orc_solve(orc_solver* s, const double x0[4], const orc_scene* sc, double* u_
             lamb = (p->lamb_amplify < la) ? la : p->lamb_amplify; /* std::max(lamb_amplify, lamb*lamb_amplify) */
         } else if (s->status == ORC_RUNNING) {
             lamb *= p->lamb_decay;
+        }
+        if (s->mg_buf) {
+            if (tl < s->mg_cap) s->mg_buf[tl] = s->mg_cur;
+            s->mg_cur.ls_margin = s->mg_cur.pd_margin = s->mg_cur.ref_margin = DBL_MAX;
         }
         if (trace && tl < trace_cap) {
             trace[tl].status = s->status;
@@ -953,6 +1011,12 @@ int orc_solve_batch(const orc_params* params, int32_t n_params, const orc_scene*
         free(pool);
     }
     return rc_all;
+}
+
+/* decision-margin recorder: subsequent orc_solve calls write one record per iteration (NULL = off) */
+void orc_set_margin_buffer(orc_solver* s, orc_margin_rec* buf, int32_t cap) {
+    s->mg_buf = buf;
+    s->mg_cap = buf ? cap : 0;
 }
 
 /* test hooks: inject / read the augmented-Lagrangian state of an instance */

@@ -99,6 +99,17 @@ typedef struct orc_result {
 
 typedef struct orc_solver orc_solver;
 
+/* How close the discrete decisions of ONE iteration (one trip of the loop at cs:110) came to going the other
+ * way: the smallest relative distance |a - b| / scale over every comparison a < b of that kind evaluated in the
+ * iteration (DBL_MAX if none was).  ls: the line-search verdicts (cs:358-365: |decay| < threshold, decay > 0,
+ * approx < 0, decay / approx > threshold), scale = |ori_cost|; pd: the two Cholesky pivots of every step
+ * (cs:415-416), scale = sum of the magnitudes of the terms of the pivot; ref: every `cur < min_distance` of the
+ * lane scans (cs:300), scale = the larger distance.  Record 0 also covers the initial trajectory's scan. */
+typedef struct orc_margin_rec {
+    double ls_margin, pd_margin, ref_margin;
+} orc_margin_rec;
+void orc_set_margin_buffer(orc_solver* s, orc_margin_rec* buf, int32_t cap);
+
 int orc_math_mode(void); /* 0 = libm, 1 = detmath */
 
 orc_solver* orc_create(const orc_params* p);

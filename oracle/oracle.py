@@ -49,6 +49,7 @@ RESULT_DTYPE = np.dtype([("J_init", "<f8"), ("J_final", "<f8"), ("iters", "<i4")
                          ("trace_len", "<i4")])
 TRACE_DTYPE = np.dtype([("status", "<i4"), ("trials", "<i4"), ("accepted", "<i4"), ("alpha_idx", "<i4"),
                         ("lamb", "<f8"), ("new_J", "<f8")])
+MARGIN_DTYPE = np.dtype([("ls", "<f8"), ("pd", "<f8"), ("ref", "<f8")])  # orc_margin_rec
 
 
 def ensure_built():
@@ -114,6 +115,7 @@ class Oracle:
             "orc_destroy": (None, [V]),
             "orc_reset": (None, [V]),
             "orc_solve": (C.c_int, [V, V, C.POINTER(OrcScene), V, V, V, V, I]),
+            "orc_set_margin_buffer": (None, [V, V, I]),
             "orc_solve_batch": (C.c_int, [C.POINTER(OrcParams), I, C.POINTER(OrcScene), I, I, V, V, V, V, I, V, V, V]),
             "orc_kinematic_propagate": (None, [V, V, D, D, I, V]),
             "orc_model_derivatives": (None, [V, V, D, D, I, I, V, V]),
@@ -275,16 +277,24 @@ class OracleSolver:
     def reset(self):
         self.o.lib.orc_reset(self.h)
 
-    def solve(self, x0, scene, tick=None, trace_cap=256):
+    def solve(self, x0, scene, tick=None, trace_cap=256, margins=False):
+        """margins=True also returns, per iteration, how close its discrete decisions came to flipping
+        (orc_margin_rec: line-search verdicts, Cholesky pivots, lane-scan comparisons)."""
         N = self.N
         u, x = np.empty((N, 2)), np.empty((N + 1, 4))
         res = np.zeros(1, dtype=RESULT_DTYPE)
         trace = np.zeros(trace_cap, dtype=TRACE_DTYPE)
+        mg = np.zeros(trace_cap, dtype=MARGIN_DTYPE) if margins else None
         s = scene.struct(tick)
+        self.o.lib.orc_set_margin_buffer(self.h, _p(mg), trace_cap if margins else 0)
         rc = self.o.lib.orc_solve(self.h, _p(_f64(x0)), C.byref(s), _p(u), _p(x), _p(res), _p(trace), trace_cap)
+        self.o.lib.orc_set_margin_buffer(self.h, None, 0)
         if rc != 0:
             raise RuntimeError(f"orc_solve rc={rc}")
-        return {"u": u, "x": x, "res": res[0], "trace": trace[:res[0]["trace_len"]]}
+        out = {"u": u, "x": x, "res": res[0], "trace": trace[:res[0]["trace_len"]]}
+        if margins:
+            out["margins"] = mg[:res[0]["trace_len"]]
+        return out
 
     def total_cost(self, u, x, scene, tick=None):
         s = scene.struct(tick)

@@ -22,10 +22,13 @@ dst = os.path.join(ROOT, "profiles")
 def last_json(path):
     if not os.path.exists(path) or not os.path.getsize(path):
         return None
-    try:
-        return json.loads(open(path).read().strip().splitlines()[-1])
-    except Exception:
-        return None
+    for line in reversed(open(path, errors="replace").read().strip().splitlines()):
+        if line.startswith("{"):  # RCCL prints a version banner after the line on some runs
+            try:
+                return json.loads(line)
+            except Exception:
+                pass
+    return None
 
 
 def counters(pattern):
