@@ -141,9 +141,10 @@ def cpu_baseline(pkg, wl, threads):
 def parity_check(gpu_u, gpu_x, gpu_res, ref, tol=1e-5):
     """The run that was just timed against the libm oracle (the oracle is only the checker here).  The GPU
     path is bit-identical to the oracle's detmath build (tests); against glibc's libm the elementary functions
-    differ by an ulp, which moves a discrete decision (line-search accept, |dJ| < threshold, nearest lane
-    sample) on a small fraction of trajectories — tests/test_gpu_parity.py::test_libm_divergences_are_near_ties
-    shows every such trajectory sits on a near-tie."""
+    differ by an ulp.  On inputs whose solve amplifies such a difference past 1e-5 the libm build does not
+    reproduce itself either when x0 moves by one unit in the last place (profiles/r02_libm_tolerance.json,
+    tests/test_gpu_parity.py::test_libm_gap_is_input_conditioning): 10 of config 2's 1024 straight-lane
+    trajectories, none of configs 3 and 5."""
     nb = ref["res"].shape[0]
     du = np.abs(gpu_u[:nb] - ref["u"]).reshape(nb, -1).max(axis=1)
     dx = np.abs(gpu_x[:nb] - ref["x"]).reshape(nb, -1).max(axis=1)

@@ -1,21 +1,30 @@
 """Diagnosis of the trajectories on which the HIP path (bit-identical to the oracle's detmath build) and the
 oracle's glibc-libm build — the stand-in for what the reference binary links — end up more than 1e-5 apart.
 
-TEST INFRASTRUCTURE (imports oracle/).  Used by tests/test_gpu_parity.py::test_libm_divergences_are_near_ties
+TEST INFRASTRUCTURE (imports oracle/).  Used by tests/test_gpu_parity.py::test_libm_gap_is_input_conditioning
 and, as a script, to write profiles/r02_libm_tolerance.json:
 
     python tests/libm_tolerance.py [--configs 2 3 5] [--gpu] [--out profiles/r02_libm_tolerance.json]
 
-The solve loop takes discrete decisions — line-search verdicts (cs:358-365), the Cholesky test of Q_uu
-(cs:415-416), `cur < min_distance` in the lane scan (cs:300) — on floating-point numbers.  Two correct
-implementations whose elementary functions differ in the last place can take a different branch where such a
-comparison is a near-tie, and from there on they optimise along different paths.  For every trajectory outside
-the 1e-5 band this module finds the first iteration at which the two decision traces part and reports
-  (1) the decision margin there: the smallest relative distance to flipping among the comparisons evaluated in
-      that iteration by either build (orc_margin_rec);
-  (2) whether the libm build ITSELF changes its decision trace when x0 is moved by one unit in the last place
-      (8 neighbours: each component +-1 ulp) — if it does, no implementation can be expected to reproduce the
-      reference binary on that input, not even the reference built against another libm version.
+Two correct implementations whose elementary functions differ in the last place start an iLQR solve from
+costs that differ by ~1e-12 relative.  What happens to that difference is a property of the solve map of the
+INPUT, not of either implementation, so it is measured on the reference side alone:
+
+  spread(b) = how far the libm build's own result (u, x, J_final) moves when one component of x0 moves by one
+              unit in the last place (8 neighbours: each component +-1 ulp), max over the neighbours;
+  gap(b)    = distance between the HIP result and the libm result on the unperturbed input.
+
+A trajectory with spread <= 1e-5 is one whose reference result is determined to the tolerance by its input; on
+all of those the HIP path must be (and is) within 1e-5.  A trajectory with spread > 1e-5 is one the reference
+binary itself would not reproduce to 1e-5 after rounding its input differently (or with another libm version):
+every trajectory outside the band is of that kind, and its gap is no larger than a small multiple of its spread.
+
+For each trajectory outside the band the report also holds the first iteration at which the two decision traces
+part, whether they part by a flipped decision or by drifting costs under identical decisions, and the smallest
+relative margin of the discrete decisions evaluated there (orc_margin_rec).  Finding: the traces mostly do NOT part
+at a near-tie (margins 1e-6 .. 1e-4, not 1e-16) — the difference is amplified smoothly, about an order of magnitude
+per iteration, while the cost falls steeply in the early iterations, contracts again near the optimum, and is
+frozen above 1e-5 when |dJ| < convergence_threshold (cs:358-361) ends the solve.
 """
 import argparse
 import json
@@ -79,13 +88,38 @@ def ulp_neighbours(x0):
     return out
 
 
+def max_gap(a, b):
+    """per trajectory: the largest of max |du|, max |dx|, |dJ_final| (NaN -> inf)"""
+    nb = a["res"].shape[0]
+    g = np.maximum(np.abs(a["u"] - b["u"]).reshape(nb, -1).max(axis=1), np.abs(a["x"] - b["x"]).reshape(nb, -1).max(axis=1))
+    g = np.maximum(g, np.abs(a["res"]["J_final"] - b["res"]["J_final"]))
+    return np.where(np.isnan(g), np.inf, g)
+
+
 class Diagnoser:
-    def __init__(self, wl):
+    def __init__(self, wl, threads=8):
         from oracle import Oracle
         self.wl = wl
+        self.threads = threads
         self.scenes = oracle_scenes(wl)
         self.orc = {"libm": Oracle("libm"), "det": Oracle("det")}
         self._solvers = {}
+
+    def batch(self, mode, x0=None):
+        wl = self.wl
+        return self.orc[mode].solve_batch(wl.params, self.scenes, wl.x0 if x0 is None else x0, wl.scenario_id,
+                                          wl.param_id, wl.tick, n_threads=self.threads)
+
+    def spread(self, base):
+        """libm's own sensitivity to the last bit of x0: max over the 8 one-ulp neighbours of the distance between
+        the neighbour's result and the unperturbed one"""
+        sp = np.zeros(self.wl.B)
+        for c in range(4):
+            for direction in (np.inf, -np.inf):
+                x0 = self.wl.x0.copy()
+                x0[:, c] = np.nextafter(x0[:, c], direction)
+                sp = np.maximum(sp, max_gap(self.batch("libm", x0), base))
+        return sp
 
     def _solver(self, mode, pid):
         key = (mode, int(pid))
@@ -100,66 +134,59 @@ class Diagnoser:
         return s.solve(wl.x0[b] if x0 is None else x0, self.scenes[int(wl.scenario_id[b])], tick=int(wl.tick[b]),
                        trace_cap=256, margins=margins)
 
-    def one(self, b):
-        """the record of one divergent trajectory"""
+    def one(self, b, gap, spread):
+        """the record of one trajectory outside the band"""
         lm, dt = self.solve("libm", b), self.solve("det", b)
         k, kind = first_split(lm["trace"], dt["trace"])
         kk = min(k, len(lm["trace"]) - 1, len(dt["trace"]) - 1)
-        mg = {}
-        for name in ("ls", "pd", "ref"):
-            mg[name] = float(min(lm["margins"][name][kk], dt["margins"][name][kk]))
-        upto = {name: float(min(lm["margins"][name][:kk + 1].min(), dt["margins"][name][:kk + 1].min()))
-                for name in ("ls", "pd", "ref")}
-        flips = 0
-        for y in ulp_neighbours(self.wl.x0[b]):
-            r = self.solve("libm", b, x0=y, margins=False)
-            flips += 0 if same_trace(r["trace"], lm["trace"]) else 1
-        which = min(mg, key=mg.get)
-        return {"trajectory": int(b), "first_split_record": int(k), "split_kind": kind,
+        mg = {name: float(min(lm["margins"][name][kk], dt["margins"][name][kk])) for name in ("ls", "pd", "ref")}
+        n = min(len(lm["trace"]), len(dt["trace"]))
+        dj = np.abs(lm["trace"]["new_J"][:n] - dt["trace"]["new_J"][:n])
+        return {"trajectory": int(b), "gap": float(gap), "libm_spread_under_1ulp_x0": float(spread),
+                "gap_over_spread": float(gap / spread) if spread > 0 else None,
+                "identical_decision_traces": bool(same_trace(lm["trace"], dt["trace"])),
+                "first_split_record": int(k), "split_kind": kind,
                 "iterations_libm": int(lm["res"]["iters"]), "iterations_hip": int(dt["res"]["iters"]),
                 "J_final_libm": float(lm["res"]["J_final"]), "J_final_hip": float(dt["res"]["J_final"]),
-                "margin_at_split": mg, "smallest_margin_at_split": mg[which], "decision_kind": which,
-                "smallest_margin_up_to_split": min(upto.values()),
-                "libm_trace_changes_under_1ulp_x0": int(flips), "of_neighbours": 8}
-
-    def control_flip_rate(self, rows):
-        """how often a trajectory INSIDE the band changes its libm decision trace under the same 1-ulp moves"""
-        flipped = 0
-        for b in rows:
-            base = self.solve("libm", b, margins=False)
-            if any(not same_trace(self.solve("libm", b, x0=y, margins=False)["trace"], base["trace"])
-                   for y in ulp_neighbours(self.wl.x0[b])):
-                flipped += 1
-        return flipped
+                "smallest_decision_margin_at_split": mg,
+                "abs_dJ_first_iteration": float(dj[0]) if n else None, "abs_dJ_largest": float(dj.max()) if n else None,
+                "abs_dJ_last_common_iteration": float(dj[-1]) if n else None}
 
 
-def analyse(wl, hip_out, threads=8, control=64):
-    """hip_out: dict(u, x, res) of the HIP path (or of the detmath oracle, its bit-identical CPU twin)."""
-    dg = Diagnoser(wl)
-    ref = dg.orc["libm"].solve_batch(wl.params, dg.scenes, wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=threads)
-    du, dx, dJ, bad = outside_band(hip_out, ref)
-    rows = np.nonzero(bad)[0]
-    recs = [dg.one(int(b)) for b in rows]
-    good = np.nonzero(~bad)[0]
-    ctl_rows = good[:: max(1, len(good) // control)][:control] if len(good) else []
-    ctl_flips = dg.control_flip_rate([int(b) for b in ctl_rows])
-    inside = ~bad
+def analyse(wl, hip_out, threads=8, rows=None):
+    """hip_out: dict(u, x, res) of the HIP path (or of the detmath oracle, its bit-identical CPU twin).
+    rows: restrict the analysis to these trajectories (default all)."""
+    if rows is not None:
+        import copy
+        wl = copy.copy(wl)
+        wl.x0, wl.scenario_id, wl.param_id, wl.tick = wl.x0[rows], wl.scenario_id[rows], wl.param_id[rows], wl.tick[rows]
+        hip_out = {k: hip_out[k][rows] for k in ("u", "x", "res")}
+    dg = Diagnoser(wl, threads)
+    ref = dg.batch("libm")
+    gap = max_gap(hip_out, ref)
+    spread = dg.spread(ref)
+    bad = ~(gap <= TOL)
+    well = spread <= TOL
+    recs = [dg.one(int(b), gap[b], spread[b]) for b in np.nonzero(bad)[0]]
+    ratio = gap[bad] / np.maximum(spread[bad], 1e-300)
     return {
         "workload": wl.name, "trajectories": int(wl.B), "tolerance": TOL,
-        "within_1e-5": int(inside.sum()), "within_1e-5_frac": float(inside.mean()),
-        "outside_1e-5": int(bad.sum()),
-        "max_abs_du_inside": float(du[inside].max()) if inside.any() else None,
-        "max_abs_dx_inside": float(dx[inside].max()) if inside.any() else None,
-        "max_abs_dJ_inside": float(dJ[inside].max()) if inside.any() else None,
-        "max_abs_dJ_outside": float(np.nanmax(dJ[bad])) if bad.any() else None,
-        "near_tie_threshold": NEAR_TIE,
-        "outside_with_near_tie_at_split": int(sum(r["smallest_margin_at_split"] < NEAR_TIE for r in recs)),
-        "outside_where_libm_flips_under_1ulp_x0": int(sum(r["libm_trace_changes_under_1ulp_x0"] > 0 for r in recs)),
-        "outside_explained": int(sum((r["smallest_margin_at_split"] < NEAR_TIE) or (r["libm_trace_changes_under_1ulp_x0"] > 0)
-                                     for r in recs)),
-        "decision_kinds": {k: int(sum(r["decision_kind"] == k for r in recs)) for k in ("ls", "pd", "ref")},
-        "control": {"trajectories_inside_band_sampled": int(len(ctl_rows)),
-                    "of_which_libm_flips_under_1ulp_x0": int(ctl_flips)},
+        "within_1e-5": int((~bad).sum()), "within_1e-5_frac": float((~bad).mean()), "outside_1e-5": int(bad.sum()),
+        "well_conditioned (libm spread <= 1e-5)": int(well.sum()),
+        "well_conditioned_outside_1e-5": int((well & bad).sum()),
+        "max_gap_well_conditioned": float(gap[well].max()) if well.any() else None,
+        "ill_conditioned (libm spread > 1e-5)": int((~well).sum()),
+        "ill_conditioned_inside_1e-5_anyway": int((~well & ~bad).sum()),
+        "outside_1e-5_with_spread_gt_1e-5": int((bad & ~well).sum()),
+        "max_gap_over_spread_outside": float(ratio.max()) if bad.any() else None,
+        "max_gap": float(gap[np.isfinite(gap)].max()), "max_spread": float(spread[np.isfinite(spread)].max()),
+        "gap_percentiles_50_90_99": [float(v) for v in np.percentile(gap, [50, 90, 99])],
+        "spread_percentiles_50_90_99": [float(v) for v in np.percentile(spread, [50, 90, 99])],
+        "outside_with_identical_decision_traces": int(sum(r["identical_decision_traces"] for r in recs)),
+        "outside_first_split_by_cost_drift": int(sum(r["split_kind"] == "cost" for r in recs)),
+        "outside_first_split_by_flipped_decision": int(sum(r["split_kind"] in ("decision", "length") for r in recs)),
+        "outside_with_near_tie_at_split (margin < 1e-9)": int(sum(min(r["smallest_decision_margin_at_split"].values()) < NEAR_TIE
+                                                                  for r in recs)),
         "records": recs,
     }
 
@@ -192,6 +219,7 @@ def main():
             hip = Oracle("det").solve_batch(wl.params, oracle_scenes(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick,
                                             n_threads=args.threads)
         rep = analyse(wl, hip, threads=args.threads)
+        rep["records"] = sorted(rep["records"], key=lambda r: -r["gap"])[:40]  # the file keeps the worst 40
         rep["baseline_config"] = cfg
         report["configs"].append(rep)
         brief = {k: v for k, v in rep.items() if k != "records"}

@@ -2,7 +2,8 @@
 
 Bar: BIT-EXACT against the oracle's detmath build (same elementary functions, same operation
 order) for every stage and for whole solves including the per-iteration decision trace; within
-1e-5 (the tolerance north_star states) against the libm build on well-conditioned starts.
+1e-5 (the tolerance north_star states) against the libm build wherever the libm build's own result is
+determined to 1e-5 by its input (test_libm_gap_is_input_conditioning).
 """
 import numpy as np
 import pytest
@@ -275,24 +276,37 @@ def test_solve_param_sweep_and_mixed_scenarios(pkg, orc_det):
     eng.close()
 
 
-def test_solve_within_tolerance_of_libm_oracle(pkg, orc_libm, engines):
-    """against the oracle built on glibc's libm (what the reference binary links): trajectories and
-    final cost within 1e-5 on well-conditioned (off-the-line) starts."""
-    eng, p, sc = engines("three_bend", 50, use_last_solution=0)
-    scene = oracle_scene(sc)
-    B = 128
-    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC11A0003)
-    out = eng.solve_batch(x0)
-    ref = orc_libm.solve_batch(p, scene, x0, n_threads=8)
-    same_path = (out["res"]["iters"] == ref["res"]["iters"]) & (out["res"]["end_reason"] == ref["res"]["end_reason"])
-    du = np.abs(out["u"] - ref["u"]).reshape(B, -1).max(axis=1)
-    dx = np.abs(out["x"] - ref["x"]).reshape(B, -1).max(axis=1)
-    dJ = np.abs(out["res"]["J_final"] - ref["res"]["J_final"]) / np.maximum(1.0, np.abs(ref["res"]["J_final"]))
-    ok = (du < TOL_LIBM) & (dx < TOL_LIBM) & (dJ < TOL_LIBM)
-    # ulp-level differences between libm and detmath may flip a noise-level line-search decision
-    # on a few trajectories; those are reported, the rest must be within tolerance
-    assert ok.mean() >= 0.95, (ok.mean(), du.max(), dx.max(), dJ.max())
-    assert ok[same_path].all()
+@pytest.mark.parametrize("cfg,rows", [(2, 1024), (3, 2048), (5, 4096)])
+def test_libm_gap_is_input_conditioning(pkg, orc_det, cfg, rows):
+    """Against the oracle built on glibc's libm (what the reference binary links), on BASELINE configs 2 (all 1024
+    trajectories), 3 and 5 (first 2048 / 4096):
+      * every trajectory whose REFERENCE result is determined to 1e-5 by its input — the libm build moves by
+        <= 1e-5 when one component of x0 moves by one unit in the last place — is within 1e-5 on u, x and J_final;
+      * every trajectory outside the 1e-5 band is one the libm build itself does not reproduce to 1e-5 under
+        such a move, and the HIP result is no further from it than 4x what that move does.
+    (tests/libm_tolerance.py holds the diagnosis; VERDICT r01 asked for a near-tie criterion — the traces turn
+    out to part by smooth amplification under mostly identical decisions, not at near-ties)"""
+    import libm_tolerance as lt
+    wl = lt.make_workload(pkg, cfg)
+    sel = np.arange(rows)
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    hip = eng.solve_batch(wl.x0[sel], wl.scenario_id[sel], wl.param_id[sel], wl.tick[sel])
+    eng.close()
+    # the HIP path is the detmath oracle's twin here too
+    twin = orc_det.solve_batch(wl.params, lt.oracle_scenes(wl), wl.x0[sel], wl.scenario_id[sel], wl.param_id[sel],
+                               wl.tick[sel], n_threads=8)
+    eq_bits(hip["x"], twin["x"], "hip vs detmath oracle")
+    hip_full = {k: np.zeros((wl.B,) + hip[k].shape[1:], dtype=hip[k].dtype) for k in ("u", "x", "res")}
+    for k in hip_full:
+        hip_full[k][sel] = hip[k]
+    rep = lt.analyse(wl, hip_full, threads=8, rows=sel)
+    brief = {k: v for k, v in rep.items() if k != "records"}
+    assert rep["well_conditioned_outside_1e-5"] == 0, brief
+    assert rep["outside_1e-5"] == rep["outside_1e-5_with_spread_gt_1e-5"], brief
+    assert rep["max_gap_over_spread_outside"] is None or rep["max_gap_over_spread_outside"] <= 4.0, brief
+    assert rep["within_1e-5_frac"] >= 0.98, brief
+    if cfg in (3, 5):  # the CoG-model bend scenario is well-conditioned throughout
+        assert rep["outside_1e-5"] == 0 and rep["max_gap"] < 1e-7, brief
 
 
 def test_batch_order_invariance(pkg, engines):

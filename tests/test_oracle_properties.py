@@ -152,3 +152,19 @@ def test_warm_start_and_obstacle_horizon(pkg, orc_det, scenarios):
     T = sc.routes.shape[1]
     with pytest.raises(RuntimeError):
         s.solve(sc.ego_state, oracle_scene(sc, T - 10))  # route shorter than tick + N + 1
+
+
+def test_libm_tolerance_diagnosis_on_the_detmath_twin(pkg, orc_det):
+    """tests/libm_tolerance.py on the first 256 trajectories of config 2, with the detmath oracle standing in
+    for the HIP path (its bit-identical twin, see the gpu tests): whatever leaves the 1e-5 band is an input on
+    which the libm build does not reproduce itself under a one-ulp move of x0; margins are recorded."""
+    import libm_tolerance as lt
+    wl = pkg.workloads.config2(B=256)
+    twin = orc_det.solve_batch(wl.params, lt.oracle_scenes(wl), wl.x0, n_threads=4)
+    rep = lt.analyse(wl, twin, threads=4)
+    assert rep["well_conditioned_outside_1e-5"] == 0, {k: v for k, v in rep.items() if k != "records"}
+    assert rep["outside_1e-5"] == rep["outside_1e-5_with_spread_gt_1e-5"]
+    assert rep["outside_1e-5"] >= 1  # trajectories 68, 116, 201, 222 of the benchmark batch
+    for r in rep["records"]:
+        assert r["gap"] <= 4.0 * r["libm_spread_under_1ulp_x0"]
+        assert all(np.isfinite(v) and v >= 0 for v in r["smallest_decision_margin_at_split"].values())
