@@ -179,6 +179,12 @@ int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next,
  * stragglers still outweigh the second round of blocks; 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
 
+/* Line-search rollouts (forward_pass for the step sizes of cs:354): -1 (default) = adaptive — an iteration rolls
+ * out alpha = 1 alone and the other 19 step sizes only once that trial is rejected, unless the previous
+ * iteration's search went beyond its first trial, in which case all 20 are rolled out in one pass; 0 = always all
+ * 20 in one pass; 1 = always the first trial alone first.  Results are identical in every mode. */
+int cilqr_set_rollout_mode(cilqr_handle* h, int32_t mode);
+
 /* Optional in-kernel cycle accounting of the fused solve (development aid): when enabled, the next
  * solve records, per trajectory, shader-clock cycles spent in
  * [0] initial trajectory + cost, [1] cost/model derivatives, [2] backward sweep, [3] trial rollouts,
@@ -186,8 +192,9 @@ int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
  * [8] trial cost evaluations that fell back to the serial reference-point chain, [9] trials,
  * [10..12] split of [4]: reference points, stage costs, ordered sum, [13] trial cost evaluations in which
  * some row's reference-point proof had to sample the lane interval (convexity certificate not
- * applicable).  out[B][14]. */
-#define CILQR_PROF_SLOTS 14
+ * applicable), [14] rollout passes of the first trial alone, [15] rollout passes of all 20 step sizes at once,
+ * [16] of those, second passes after a rejected first trial.  out[B][17]. */
+#define CILQR_PROF_SLOTS 17
 int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
 /* Testing aid.  bit 0: always use the serial reference-point chain (cs:289-314 as written) instead
  * of the lane-parallel search + proof; bit 1: wave-uniform backward sweep instead of the

@@ -41,6 +41,10 @@ rep = {"workload": wl.name, "kernel_ms": ms, "iters_sum": int(res["iters"].sum()
        "cycles_per_iteration": {n: float(cyc[:, i].sum() / res["iters"].sum()) for i, n in enumerate(names[1:6], start=1)},
        "cycles_per_trial_cost": float(cyc[:, 4].sum() / max(1, res["ls_trials"].sum())),
        "trial_cost_split_cycles_per_eval": {n: float(cyc[:, i].sum() / max(1, cyc[:, 9].sum())) for n, i in (("ref_points", 10), ("stage_costs", 11), ("ordered_sum", 12))},
+       "rollout_passes": {"first_trial_alone": int(cyc[:, 14].sum()), "all_20_at_once": int(cyc[:, 15].sum()),
+                          "second_pass_after_rejected_first_trial": int(cyc[:, 16].sum()),
+                          "slab_written_frac_of_line_searches": float((cyc[:, 15].sum() + cyc[:, 16].sum())
+                                                                      / max(1, cyc[:, 14].sum() + cyc[:, 15].sum()))},
        "ref_scan_fallbacks": int(cyc[:, 8].sum()), "ref_sampled_proofs": int(cyc[:, 13].sum()), "trial_cost_evals": int(cyc[:, 9].sum()),
        "slowest": {"iters": int(res["iters"][tot.argmax()]), "trials": int(res["ls_trials"][tot.argmax()]),
                    "phases": {n: int(cyc[tot.argmax(), i]) for i, n in enumerate(names[:6])}}}

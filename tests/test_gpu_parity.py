@@ -619,24 +619,59 @@ def test_config3_and_config5_properties_at_scale(pkg, orc_det):
         eng.close()
 
 
-def test_helper_wavefront_mode_is_transparent(pkg, orc_det, engines):
-    """one wavefront per trajectory vs main + helper wavefront: identical results and traces
-    (barrier and ALM, one and two rows per lane)."""
+def test_helper_wavefront_and_rollout_modes_are_transparent(pkg, orc_det, engines):
+    """one wavefront per trajectory vs main + helper wavefront, and the three line-search rollout policies (all 20
+    step sizes in one pass / the first trial alone first / adaptive): identical results and decision traces, and
+    identical to the oracle (barrier and ALM, one and two rows per lane, both vehicle models)."""
     for name, N, over in (("three_bend", 50, dict(use_last_solution=0)), ("two_straight", 100, dict(use_last_solution=0)),
+                          ("two_straight", 50, dict(use_last_solution=0)),
                           ("three_bend", 30, dict(use_last_solution=0, solve_type=1))):
         eng, p, sc = engines(name, N, **over)
         x0 = pkg.workloads.perturbed_starts(sc.ego_state, 48, 1234 + N)
-        eng.set_helper_mode(0)
-        a = eng.solve_batch(x0, trace_cap=128)
-        eng.set_helper_mode(1)
-        b = eng.solve_batch(x0, trace_cap=128)
+        scene = oracle_scene(sc)
+        refs = [orc_det.solver(p).solve(x, scene) for x in x0]
+        base = None
+        for helper in (0, 1):
+            for rollout in (0, 1, -1):
+                eng.set_helper_mode(helper)
+                eng.set_rollout_mode(rollout)
+                b = eng.solve_batch(x0, trace_cap=128)
+                what = f"{name} N={N} helper={helper} rollout={rollout}"
+                compare_solves(b, refs, what)
+                if base is None:
+                    base = b
+                eq_bits(base["u"], b["u"], what + " u")
+                eq_bits(base["x"], b["x"], what + " x")
+                assert (base["res"] == b["res"]).all(), what
+                for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+                    eq_bits(base["trace"][f], b["trace"][f], what + " trace." + f)
         eng.set_helper_mode(-1)
-        eq_bits(a["u"], b["u"], "helper u")
-        eq_bits(a["x"], b["x"], "helper x")
-        assert (a["res"] == b["res"]).all()
-        for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
-            eq_bits(a["trace"][f], b["trace"][f], "helper trace." + f)
-        assert (a["res"]["ls_trials"] > a["res"]["iters"]).any()  # some multi-trial line searches were exercised
+        eng.set_rollout_mode(-1)
+        res = base["res"]
+        assert (res["ls_trials"] > res["iters"]).any()  # some multi-trial line searches were exercised
+        assert (base["trace"]["trials"] == 20).any() and (base["trace"]["trials"] == 1).any()
+
+
+def test_rollout_policy_statistics(pkg, engines):
+    """the adaptive policy's bookkeeping (in-kernel counters): every line search starts with exactly one rollout
+    pass, second passes happen only after a rejected first trial, and on the benchmark-like batch the slab is
+    written in a minority of the iterations."""
+    eng, p, sc = engines("two_straight", 50, use_last_solution=0)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 256, 0xC11A0002)
+    eng.set_phase_profiling(True)
+    for helper in (0, 1):
+        eng.set_helper_mode(helper)
+        out = eng.solve_batch(x0, trace_cap=128)
+        cyc = eng.phase_cycles(256)
+        first, allp, second = cyc[:, 14], cyc[:, 15], cyc[:, 16]
+        tr = out["trace"]
+        searched = np.array([(tr["status"][b][:out["res"]["trace_len"][b]] != 2).sum() for b in range(256)])
+        assert np.array_equal(first + allp, searched)
+        deeper = np.array([((tr["trials"][b][:out["res"]["trace_len"][b]] > 1)).sum() for b in range(256)])
+        assert (second <= deeper).all() and (second <= first).all()
+        assert (allp + second).sum() < 0.3 * searched.sum(), ((allp + second).sum(), searched.sum())
+    eng.set_phase_profiling(False)
+    eng.set_helper_mode(-1)
 
 
 # ---- edge cases ----------------------------------------------------------------------------------
@@ -760,6 +795,146 @@ def test_concurrent_handles_on_separate_streams():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _CONCURRENT_SCRIPT, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CONCURRENT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_DEVICE_IDS_SCRIPT = r"""
+import sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import cilqr_amd as pkg
+dev = torch.device("cuda", 0)
+wl = pkg.workloads.config4(B=64, N=30)
+N, B = wl.N, wl.B
+eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+ref = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+T_of = np.array([s.obs.shape[1] for s in wl.scenes])[wl.scenario_id]
+sid, pid, tk = wl.scenario_id.copy(), wl.param_id.copy(), wl.tick.copy()
+bad = np.zeros(B, bool)
+sid[3] = 4; sid[7] = -1; pid[11] = 9; pid[12] = -5; tk[20] = -1; bad[[3, 7, 11, 12, 20]] = True
+tk[30] = T_of[30] - N           # route one sample too short: tick + N + 1 > T
+bad[30] = True
+tk[31] = T_of[31] - N - 1       # exactly long enough: solved
+to = lambda a: torch.from_numpy(a).to(dev)
+d = [to(wl.x0), to(sid), to(pid), to(tk)]
+u = torch.zeros((B, N, 2), dtype=torch.float64, device=dev)
+x = torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev)
+r = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+for helper in (0, 1):
+    eng.set_helper_mode(helper)
+    eng.solve_batch_device(B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, u.data_ptr(), x.data_ptr(),
+                           r.data_ptr(), 0, 0, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    res = np.frombuffer(r.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+    U, X = u.cpu().numpy(), x.cpu().numpy()
+    assert (res["end_reason"][bad] == 3).all() and (res["iters"][bad] == 0).all(), res[bad]
+    assert np.isnan(U[bad]).all() and np.isnan(X[bad]).all() and np.isnan(res["J_final"][bad]).all()
+    ok = ~bad
+    ok[31] = False
+    assert np.array_equal(U[ok], ref["u"][ok]) and np.array_equal(X[ok], ref["x"][ok]) and (res[ok] == ref["res"][ok]).all()
+    assert res["end_reason"][31] != 3 and np.isfinite(X[31]).all()
+# a negative trace capacity is refused
+try:
+    eng.solve_batch_device(B, d[0].data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, -1, 0)
+    raise SystemExit("negative trace_cap accepted")
+except pkg.CilqrError as e:
+    assert e.code == -1
+print("DEVICE-IDS-OK")
+"""
+
+
+def test_device_pointer_entry_checks_its_ids_on_the_device():
+    """cilqr_solve_batch_device cannot validate scenario_id / param_id / tick on the host: trajectories with an id
+    outside the tables, a negative tick or an obstacle route that ends before tick + N + 1 (upstream:
+    std::out_of_range, ut:52-58) come back unsolved — NaN, end_reason BAD_INPUT — and do not disturb the others."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DEVICE_IDS_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DEVICE-IDS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_alm_state_follows_the_parameter_table(pkg, orc_det, scenarios):
+    """The multiplier arrays are [B][N][8 + 2M]: replacing the parameter table of a live ALM handle by one with a
+    longer horizon re-lays them out (the old arrays would have been indexed past their end); growing
+    the batch keeps the rows that exist; a warm-started call continues from its multipliers."""
+    cfg, sc = scenarios["three_bend"]
+    tab = pkg.SceneTable.from_scenario(sc)
+    scene = oracle_scene(sc)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 24, 777)
+    p30 = pkg.params_from_config(cfg, N=30, solve_type=1, use_last_solution=1)
+    eng = pkg.BatchedCILQR(p30, tab)
+    out = eng.solve_batch(x0[:8], trace_cap=128)
+    compare_solves(out, [orc_det.solver(p30).solve(x, scene) for x in x0[:8]], "alm N=30")
+    # longer horizon, same handle, bigger batch than the slack of the old allocation would have covered
+    p60 = pkg.params_from_config(cfg, N=60, solve_type=1, use_last_solution=1)
+    eng.set_params(p60)
+    out = eng.solve_batch(x0, trace_cap=128)
+    compare_solves(out, [orc_det.solver(p60).solve(x, scene) for x in x0], "alm N=60 after N=30")
+    mu, mun, rho = eng.get_alm_state(24)
+    assert mu.shape == (24, 60, 8 + 2 * tab.obs.shape[0])
+    eng.close()
+    # growing the arrays keeps the rows that exist: a warm-started tick after the growth continues from them
+    eng = pkg.BatchedCILQR(p30, tab)
+    solvers = [orc_det.solver(p30) for _ in range(8)]
+    for s_ in solvers:
+        s_.reset()
+    t0 = eng.solve_batch(x0[:8], trace_cap=128)
+    compare_solves(t0, [solvers[b].solve(x0[b], scene) for b in range(8)], "alm tick 0")
+    mu8, _, rho8 = eng.get_alm_state(8)
+    from ctypes import c_void_p
+    pkg._lib.check(eng._lib.cilqr_set_alm_state(eng._h, 200, None, None), "grow")  # 200 rows: beyond any slack
+    mu200, _, rho200 = eng.get_alm_state(200)
+    eq_bits(mu200[:8], mu8, "multipliers kept while growing")
+    eq_bits(rho200[:8], rho8, "rho kept while growing")
+    assert (mu200[8:] == 0).all() and (rho200[8:] == p30.alm_rho_init).all()
+    x1 = t0["x"][:, 1].copy()
+    t1 = eng.solve_batch(x1, tick=np.ones(8, np.int32), last_u=t0["u"], trace_cap=128)
+    compare_solves(t1, [solvers[b].solve(x1[b], oracle_scene(sc, 1)) for b in range(8)], "alm tick 1 after growth")
+    eng.close()
+
+
+def test_single_ego_entry_keeps_tables_resident(pkg, orc_det, scenarios):
+    """cilqr_solve (the drop-in solve() of one ego): a closed loop whose obstacle predictions are the tail of the
+    routes from the current tick on re-uses the tables in HBM (one upload), any other change uploads again, and
+    every tick equals the oracle's stateful solver."""
+    cfg, sc = scenarios["three_straight"]
+    solver = pkg.CILQRSolver(cfg, N=30)
+    assert solver.params.use_last_solution == 1
+    ref = orc_det.solver(solver.params)
+    ref.reset()
+    x0 = sc.ego_state.copy()
+    obs = sc.obstacles
+    ticks = 12
+    for t in range(ticks):
+        preds = [pkg.RoutingLine(r[t:, 0], r[t:, 1], r[t:, 2]) for r in obs]  # utils::get_sub_routing_lines
+        u, x = solver.solve(x0, sc.lane, sc.target_velocity, preds, sc.road_borders)
+        r = ref.solve(x0, oracle_scene(sc, t))
+        eq_bits(u, r["u"], f"tick {t} u")
+        eq_bits(x, r["x"], f"tick {t} x")
+        x0 = x[1].copy()
+    up, re = solver._engine.solve_cache_stats()
+    assert (up, re) == (1, ticks - 1), (up, re)
+    # a prediction window of fixed length (N + 1 rows from the current tick) is recognised too
+    t = ticks
+    u, x = solver.solve(x0, sc.lane, sc.target_velocity, obs[:, t:t + 31], sc.road_borders)
+    r = ref.solve(x0, oracle_scene(sc, t))
+    eq_bits(x, r["x"], "fixed window x")
+    assert solver._engine.solve_cache_stats() == (1, ticks)
+    # changed borders: uploaded again, still the oracle's result
+    x0 = x[1].copy()
+    borders = sc.road_borders + np.array([0.25, 0.0])
+    u, x = solver.solve(x0, sc.lane, sc.target_velocity, obs[:, t + 1:], borders)
+    sc2 = oracle_scene(sc, t + 1)
+    sc2.road_borders = np.ascontiguousarray(borders)
+    eq_bits(x, ref.solve(x0, sc2)["x"], "new borders x")
+    assert solver._engine.solve_cache_stats() == (2, ticks)
+    # too short a prediction is refused like upstream's out_of_range
+    with pytest.raises(pkg.CilqrError) as e:
+        solver.solve(x0, sc.lane, sc.target_velocity, obs[:, :20], sc.road_borders)
+    assert e.value.code == -2
 
 
 def test_irregular_lane_tables_reference_search(pkg, orc_det, scenarios):

@@ -19,7 +19,7 @@ ERR_NO_DEVICE = -5
 
 MAX_HORIZON = 127
 MAX_ALPHA_TRIALS = 20
-PROF_SLOTS = 14
+PROF_SLOTS = 17
 DBG_SERIAL_REF_SCAN = 1
 DBG_UNIFORM_BACKWARD = 2
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "cilqr_get_phase_cycles": (C.c_int, [_P, _P, _I]),
     "cilqr_set_debug_flags": (C.c_int, [_P, _I]),
     "cilqr_set_helper_mode": (C.c_int, [_P, _I]),
+    "cilqr_set_rollout_mode": (C.c_int, [_P, _I]),
     "cilqr_set_alm_state": (C.c_int, [_P, _I, _P, _P]),
     "cilqr_get_alm_state": (C.c_int, [_P, _I, _P, _P, _P, C.POINTER(_I)]),
     "cilqr_init_traj_batch": (C.c_int, [_P, _I, _P, _P, _P]),

@@ -39,6 +39,8 @@ struct BatchArgs {
     int n_params, n_scenes;     // table sizes: the fused solve checks its ids against them
     int W;                      // capacity (samples) of the per-trajectory LDS lane window
     int flags;                  // CILQR_DBG_* (testing aids)
+    int tier;                   // line-search rollouts: -1 adaptive (default), 0 always all 20 step sizes in one
+                                // pass, 1 always the first trial alone first (cilqr_set_rollout_mode)
     // augmented-Lagrangian state kept by the handle (solve_type alm): [B][N][alm_C], [B]
     double* alm_mu;
     double* alm_mu_next;
@@ -57,7 +59,7 @@ __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
 }
 
 // phase ids of the optional in-kernel cycle accounting
-enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12, PH_TC_SAMPLED = 13 };
+enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12, PH_TC_SAMPLED = 13, PH_ROLL_FIRST = 14, PH_ROLL_ALL = 15, PH_ROLL_SECOND = 16 };
 #define PROF_T0() long long t_ph_ = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0
 #define PROF_ADD(ph)                                                  \
     do {                                                              \
@@ -93,6 +95,8 @@ __device__ inline bool ids_valid(const BatchArgs& a, int b) {
 // HELP = true: the block has a second wavefront that does nothing but cost every other trial of the
 // line search (slot 1) while the main wavefront costs the ones in between (slot 0); used when the
 // batch is too small to fill the chip with one wavefront per trajectory.  Control words in LDS:
+// CTL_MODE of an iteration: 0 = no line search (the backward pass failed), 1 = the slab holds all 20 trial
+// trajectories, 2 = only the first trial exists so far (in the first-trial buffer; the main wave costs it alone)
 enum { CTL_MODE = 0, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W = 5 };
 // doubles: the helper's / the main wave's cost of the current pass (two slots each, alternating), and what the
 // helper needs to reach the main wave's verdicts on its own
@@ -133,10 +137,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         return;
     }
     Lds l;
-    carve(l, g_lds, N, a.W, ALM ? 1 : 0);
+    constexpr int SLOTS = (HELP || NTP == 2) ? 2 : 1; // trials costed concurrently (the host sizes the LDS block alike)
+    carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS);
     Cst c;
     load_cst(c, a, b, l, lane);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    double* first = scr + slab_doubles(N); // the first-trial buffer
     AlmSt al = load_alm(a, b, N);
     if (HELP && wave == 1) {
         // ---- helper wavefront: costs trial 2p + 1 of every pass p, mirrors the main wave's control flow ----
@@ -147,19 +153,33 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         int nfb = 0;
         for (int itr = 0; itr < c.max_iter; ++itr) {
             __syncthreads(); // B1: K, d, trial slab of this iteration are ready (or the backward pass failed)
-            if (l.ctli[CTL_MODE]) {
+            const int mode = l.ctli[CTL_MODE];
+            if (mode) {
                 if (ALM) al.rho = l.ctld[CTLD_RHO];
                 const double Jc = l.ctld[CTLD_JCUR], dV0 = l.ctld[CTLD_DV], dV1 = l.ctld[CTLD_DV + 1];
                 const double conv_thr = c.k->conv_thr, accept_thr = c.k->accept_thr;
-                for (int t0 = 0, par = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2, par ^= 1) {
-                    double J1[1];
-                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0 + 1, 1, lane, idx0h, a.flags, &nfb, J1, nullptr, 1);
-                    if (lane == 0) l.ctld[CTLD_JH + par] = J1[0];
-                    __syncthreads(); // B2: both costs of this pass are in LDS (slots alternate between passes)
-                    // the same verdict the main wave reaches (trial_verdict is a pure function of these numbers)
-                    const double J0 = l.ctld[CTLD_JM + par];
-                    if (trial_verdict(Jc, J0, t0, dV0, dV1, conv_thr, accept_thr) != 0) break;
-                    if (trial_verdict(Jc, J1[0], t0 + 1, dV0, dV1, conv_thr, accept_thr) != 0) break;
+                int t0 = 0;
+                bool over = false;
+                if (mode == 2) {
+                    // the main wave costs the first trial on its own; if the search goes on it rolls the others out
+                    __syncthreads(); // B2s: its cost is in LDS
+                    if (trial_verdict(Jc, l.ctld[CTLD_JM], 0, dV0, dV1, conv_thr, accept_thr) != 0) over = true;
+                    else { __syncthreads(); /* B3: the slab is filled */ t0 = 1; }
+                }
+                if (!over) {
+                    for (int par = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2, par ^= 1) {
+                        double J1[1] = {0.0};
+                        const bool mine = (t0 + 1 < CILQR_MAX_ALPHA_TRIALS);
+                        if (mine) {
+                            total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0 + 1, 1, lane, idx0h, a.flags, &nfb, J1, nullptr, 1);
+                            if (lane == 0) l.ctld[CTLD_JH + par] = J1[0];
+                        }
+                        __syncthreads(); // B2: both costs of this pass are in LDS (slots alternate between passes)
+                        // the same verdict the main wave reaches (trial_verdict is a pure function of these numbers)
+                        const double J0 = l.ctld[CTLD_JM + par];
+                        if (trial_verdict(Jc, J0, t0, dV0, dV1, conv_thr, accept_thr) != 0) break;
+                        if (mine && trial_verdict(Jc, J1[0], t0 + 1, dV0, dV1, conv_thr, accept_thr) != 0) break;
+                    }
                 }
             }
             __syncthreads(); // B4
@@ -177,7 +197,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         wave_sync();
     }
 
-    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
@@ -197,6 +217,13 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     int end_reason = CILQR_END_MAX_ITER;
     int flag = 0;
     int n_fallback = 0;
+    // Line-search rollouts.  88 % / 71 % of the iterations of BASELINE configs 2 / 5 accept the first trial
+    // (profiles/r02_trial_depth_histogram.json), 6-14 % try all 20 and the rest is spread evenly between.  An
+    // iteration therefore either rolls out alpha = 1 alone into the small first-trial buffer and only on
+    // rejection all step sizes into the slab ("shallow"), or all of them at once ("deep") when the previous
+    // iteration's search went beyond its first trial — failed searches come in runs.  One extra rollout pass on
+    // ~2 % of the iterations buys slab writes on 13-30 % of them instead of all.
+    bool deep_next = false;
     for (int itr = 0; itr < c.max_iter; ++itr) {
         // ---- iter_step ----
         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
@@ -223,20 +250,57 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             }
         } else {
             flag = 0;
-            rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
+            const bool deep = (a.tier == 0) || (a.tier < 0 && deep_next);
+            if (deep) rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
+            else rollout_trials(c, l, first, lane, 1, 1);
             PROF_ADD(PH_ROLLOUT);
+            if (PROF && a.prof) ph_acc[deep ? PH_ROLL_ALL : PH_ROLL_FIRST] += 1;
             if (HELP) {
                 if (lane == 0) {
-                    l.ctli[CTL_MODE] = 1;
+                    l.ctli[CTL_MODE] = deep ? 1 : 2;
                     l.ctld[CTLD_RHO] = al.rho; l.ctld[CTLD_JCUR] = J_cur; l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1];
                 }
                 __syncthreads(); // B1
             }
             bool done = false;
+            int t0 = 0;
+            if (!deep) {
+                // the first trial on its own, from the first-trial buffer
+                double J1[1];
+                total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, first, 0, 1, lane, idx0, a.flags, &n_fallback, J1,
+                                                    (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0, 1);
+                PROF_ADD(PH_TRIAL_COST);
+                if (HELP) {
+                    if (lane == 0) l.ctld[CTLD_JM] = J1[0];
+                    __syncthreads(); // B2s
+                }
+                new_J = J1[0];
+                trials = 1;
+                const int verdict = trial_verdict(J_cur, new_J, 0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
+                if (verdict == 1) {
+                    status = CILQR_CONVERGED;
+                    alpha_idx = 0;
+                    done = true;
+                } else if (verdict == 2) {
+                    flag = 1;
+                    alpha_idx = 0;
+                    accept_trial(c, l, first, 0, 0, lane, 1);
+                    PROF_ADD(PH_ACCEPT);
+                    J_cur = new_J;
+                    done = true;
+                } else {
+                    // rejected: now the other step sizes (lane 0 repeats the first trial: the same bits)
+                    rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
+                    PROF_ADD(PH_ROLLOUT);
+                    if (PROF && a.prof) ph_acc[PH_ROLL_SECOND] += 1;
+                    if (HELP) __syncthreads(); // B3
+                    t0 = 1;
+                }
+            }
             // the line search of cs:354-372; the costs are produced pass by pass — alpha = 1 alone
-            // (usually accepted), then CILQR_NT trials per pass — and consumed strictly in order
+            // (usually accepted), then NTP trials per pass (two with a helper wavefront) — and consumed strictly in order
             int par = 0; // helper mode: which pair of cost slots this pass uses
-            for (int t0 = 0; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
+            for (; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
                 double Jp[CILQR_NT];
                 int nt = (t0 == 0) ? 1 : NTP;
                 if (HELP) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
@@ -281,6 +345,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 }
                 t0 += nt;
             }
+            deep_next = (trials > 1);
             if (!done) {
                 status = CILQR_FORWARD_PASS_FAIL;
                 if (ALM) { // cs:377-378
@@ -357,7 +422,7 @@ __global__ void __launch_bounds__(CILQR_WAVE)
 k_init_traj(BatchArgs a, const double* __restrict__ x0, double* __restrict__ x_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
@@ -370,7 +435,7 @@ k_ref_points(BatchArgs a, const double* __restrict__ x, double* __restrict__ ref
              int32_t* __restrict__ idx_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), nullptr, lane);
     int idx0;
@@ -389,7 +454,7 @@ k_total_cost(BatchArgs a, const double* __restrict__ u, const double* __restrict
              double* __restrict__ J_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * (N + 1), u + (size_t)b * 2 * N, lane);
     int idx0;
@@ -407,7 +472,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     for (int e = lane; e < 8 * N; e += CILQR_WAVE) l.kd[CILQR_KD * (e >> 3) + CILQR_KD_K(e & 7)] = K[(size_t)b * 8 * N + e];
@@ -442,7 +507,7 @@ k_cost_derivatives(BatchArgs a, const double* __restrict__ u, const double* __re
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
@@ -489,7 +554,7 @@ k_backward_pass(BatchArgs a, const double* __restrict__ u, const double* __restr
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N;
     const int R = N + 1;
-    Lds l; carve(l, g_lds, N, a.W, a.alm);
+    Lds l; carve(l, g_lds, N, a.W, a.alm, 1);
     Cst c; load_cst(c, a, b, l, lane);
     stage_xu(l, N, x + (size_t)b * 4 * R, u + (size_t)b * 2 * N, lane);
     int idx0;
@@ -607,7 +672,8 @@ struct cilqr_handle {
     DevBuf d_scenes;
     // scratch + staging
     int win = 0;      // LDS lane-window capacity in samples (derived from the tables)
-    int win_occ = 0;  // the same when two wavefronts per SIMD are wanted (large batches)
+    int win_occ = 0;  // the same when two wavefronts per SIMD are wanted (large batches), one stage-cost slot
+    int win_occ2 = 0; // ... with two stage-cost slots (paired passes)
     DevBuf scratch;
     DevBuf alm_mu, alm_mu_next, alm_rho; // ALM solve type: per-trajectory multipliers carried across calls
     int alm_B = 0, alm_C = 0, alm_N = 0; // rows, columns and horizon the multiplier arrays were laid out for
@@ -628,6 +694,7 @@ struct cilqr_handle {
     bool profiling = false;
     int debug_flags = 0;
     int helper_mode = -1;      // -1 auto (by batch size), 0 never, 1 always
+    int rollout_mode = -1;     // -1 adaptive, 0 all step sizes in one pass, 1 first trial alone first (BatchArgs::tier)
     // Largest batch that gets helper wavefronts.  Up to 1024 trajectories a lone wavefront per trajectory leaves
     // SIMD slots empty.  Beyond that the blocks take a second round, which pays while the batch's stragglers
     // dominate: measured +20 % at 1536 straight-lane trajectories, +3 % / -13 % at 2048 (straight / bend), and
@@ -658,7 +725,7 @@ static void update_window(cilqr_handle* h) {
     // comfortable (anything outside the window is still read correctly, from global memory)
     const int N = h->params[0].N;
     const int alm = h->params[0].solve_type == 1 ? 1 : 0;
-    const size_t fixed = lds_bytes(N, 0, alm);
+    size_t fixed = lds_bytes(N, 0, alm, 2);
     auto pick = [&](int floor_w) {
         for (int k = 8; k >= 1; --k) {
             const long budget = (long)(163840 / k) - (long)fixed;
@@ -670,7 +737,11 @@ static void update_window(cilqr_handle* h) {
     };
     h->win = pick(floor_ok);
     // batches that fill the chip several times over: occupancy (two wavefronts per SIMD hide each other's
-    // latencies) is worth more than the far end of the window, which only the last rows at full speed reach
+    // latencies) is worth more than the far end of the window, which only the last rows at full speed reach;
+    // their kernels cost one trial at a time (one stage-cost slot)
+    const int occ_floor = std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8);
+    h->win_occ2 = pick(occ_floor);
+    fixed = lds_bytes(N, 0, alm, 1);
     h->win_occ = pick(std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8));
 }
 
@@ -777,6 +848,12 @@ extern "C" int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, doubl
 extern "C" int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     h->debug_flags = flags;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_rollout_mode(cilqr_handle* h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0 or 1");
+    h->rollout_mode = mode;
     return CILQR_OK;
 }
 
@@ -1018,6 +1095,17 @@ static bool wants_helper(const cilqr_handle* h, int B) {
            (h->helper_mode < 0 && B <= (two ? h->helper_max_batch_two_rows : h->helper_max_batch));
 }
 
+// does the solve-kernel variant for this batch cost one trial per pass without a helper (one stage-cost slot)?
+// Mirrors the dispatch in cilqr_solve_batch_device, which checks the two against each other.
+static bool single_slot(const cilqr_handle* h, int B) {
+    const bool alm = h->params[0].solve_type == 1, two = h->params[0].N + 1 > CILQR_WAVE;
+    if (wants_helper(h, B)) return false;
+    if (alm) return B > h->occ2_min_batch;
+    if (h->debug_flags != 0 || h->profiling) return false;
+    if (B > h->single_trial_min_batch) return true;
+    return B > h->occ2_min_batch && two;
+}
+
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     BatchArgs a;
     a.params = static_cast<const cilqr_params*>(h->d_params.p);
@@ -1032,10 +1120,11 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.n_params = (int)h->params.size();
     a.n_scenes = (int)h->scenes.size();
     a.flags = h->debug_flags;
+    a.tier = h->rollout_mode;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
     const bool occ2 = B > h->occ2_min_batch && (a.alm || a.flags == 0) && !h->profiling && !wants_helper(h, B);
-    a.W = occ2 ? h->win_occ : h->win;
+    a.W = occ2 ? (single_slot(h, B) ? h->win_occ : h->win_occ2) : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
     a.alm_rho = static_cast<double*>(h->alm_rho.p);
@@ -1116,7 +1205,6 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
     BatchArgs a = make_args(h, B, ids);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t shm = lds_bytes(a.N, a.W, a.alm);
     if (h->profiling) {
         if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
         a.prof = static_cast<long long*>(h->prof.p);
@@ -1127,19 +1215,33 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool two = (a.N + 1 > CILQR_WAVE);
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
         const bool help = wants_helper(h, B);
+        // `one` = the variant costs one trial per pass without a helper: one stage-cost slot in LDS (k_solve's SLOTS)
         auto kern = k_solve<false, 1, false, false, false>;
-        if (a.alm) kern = help ? (two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>)
-                          : (B > h->occ2_min_batch)
-                              ? (two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>)
-                              : (two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>);
-        else if (a.flags != 0) kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
-        else if (a.prof) kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
-                                     : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
-        else if (help) kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
-        else if (B > h->single_trial_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
-        else if (B > h->occ2_min_batch) kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2>; // two rows per lane: paired trials spill too much
-        else kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
+        bool one = false;
+        if (a.alm) {
+            if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
+            else if (B > h->occ2_min_batch) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; }
+            else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
+        } else if (a.flags != 0) {
+            kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
+        } else if (a.prof) {
+            kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
+                        : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
+        } else if (help) {
+            kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
+        } else if (B > h->single_trial_min_batch) {
+            kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
+            one = true;
+        } else if (B > h->occ2_min_batch) {
+            // two rows per lane: paired trials spill too much
+            if (two) { kern = k_solve<false, 2, false, false, false, 2, 1>; one = true; }
+            else kern = k_solve<false, 1, false, false, false, 2>;
+        } else {
+            kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
+        }
         const bool helped = help && (a.alm || a.flags == 0);
+        if (one != single_slot(h, B)) return fail(CILQR_ERR_DEVICE, "internal: kernel variant / LDS layout mismatch");
+        const size_t shm = lds_bytes(a.N, a.W, a.alm, one ? 1 : 2);
         hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }
@@ -1323,7 +1425,7 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     if (rc) return rc;
     pc.a = make_args(h, B, pc.ids);
     pc.N = pc.a.N;
-    pc.shm = lds_bytes(pc.N, pc.a.W, pc.a.alm);
+    pc.shm = lds_bytes(pc.N, pc.a.W, pc.a.alm, 1);
     return CILQR_OK;
 }
 

@@ -135,11 +135,12 @@ struct Lds {
     double* luu; // [N][2]
     CstK* ck;    // the cost model's constants (see Cst)
     double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
-    double* cs;  // [CILQR_NT][3][(N+1)] stage-cost scratch: state, ctrl, barrier.  ALIASES kd: the gains
-                 // are dead once the rollout has produced the trial trajectories, and costs are only summed then
+    double* cs;  // [slots][3][(N+1)] stage-cost scratch: state, ctrl, barrier (slots = trials costed concurrently).
+                 // Its own array: the gains in kd must survive the costing of the first trial, because the other 19
+                 // trial trajectories are only rolled out once that one has been rejected (see k_solve)
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
-    int* tidx;   // [CILQR_NT][(N+2)] the same for the trial trajectories being costed
+    int* tidx;   // [slots][(N+2)] the same for the trial trajectories being costed
     int* ctli;   // [8]  control words shared by the main and the helper wavefront of a block
     double* ctld; // [CILQR_CTLD]
     int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
@@ -159,14 +160,16 @@ struct Lds {
 #define CILQR_CTLD 8 /* doubles shared by the main and the helper wavefront (k_solve) */
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
-__host__ __device__ inline int lds_doubles(int N, int alm) {
-    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES;
+// slots = trial trajectories costed concurrently by a block: 2 with a helper wavefront or paired passes, else 1
+__host__ __device__ inline int lds_doubles(int N, int alm, int slots) {
+    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES +
+           slots * 3 * (N + 1);
 }
-__host__ __device__ inline size_t lds_bytes(int N, int W, int alm) {
-    return sizeof(double) * ((size_t)lds_doubles(N, alm) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + CILQR_NT) * (N + 2) + 8);
+__host__ __device__ inline size_t lds_bytes(int N, int W, int alm, int slots) {
+    return sizeof(double) * ((size_t)lds_doubles(N, alm, slots) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + slots) * (N + 2) + 8);
 }
 
-__device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
+__device__ inline void carve(Lds& l, double* base, int N, int W, int alm, int slots) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
@@ -177,13 +180,13 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm) {
     l.lxx = p; p += l.lxs * (N + 1);
     l.luu = p; p += 2 * N;
     l.xch = p; p += CILQR_XCH;
-    l.cs = l.kd; // 10 N doubles >= CILQR_NT * 3 * (N + 1) for every N >= 2
+    l.cs = p; p += slots * 3 * (N + 1);
     l.ctld = p; p += CILQR_CTLD;
     l.ck = reinterpret_cast<CstK*>(p); p += CILQR_CSTK_DOUBLES;
     l.win = p; p += 2 * W;
     l.ridx = reinterpret_cast<int*>(p);
     l.tidx = l.ridx + (N + 2);
-    l.ctli = l.tidx + CILQR_NT * (N + 2);
+    l.ctli = l.tidx + slots * (N + 2);
     l.w0 = 0;
     l.W = 0; // nothing staged yet: every lookup goes to global memory
 }
@@ -213,10 +216,18 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
 // scratch slab of the trial trajectories: [6][(N+1)][20 alphas] doubles, alpha fastest, so that the
 // 20 rollout lanes of one store instruction write 160 contiguous bytes.
 // rows 0-3 = x' components, 4-5 = u' components.  TR(t, c, k) with t = slab + alpha.
+// Behind the slab, [6][(N+1)] doubles for the alpha = 1 trial alone (the "first-trial buffer"): most iterations
+// accept that trial, so they roll out, cost and accept only it — 2.4 KB written and read back contiguously,
+// L2-resident — and the slab is written only in iterations expected (or found) to search deeper.  Both are
+// addressed as TRS(t, c, k, as): as = 20 inside the slab (t = slab + alpha), as = 1 in the first-trial buffer.
 #define CILQR_TRIAL_ROWS 6
-#define TR(t, c, k) (t)[((size_t)(c) * R + (size_t)(k)) * CILQR_MAX_ALPHA_TRIALS]
-__host__ __device__ inline size_t scratch_doubles(int N) {
+#define TRS(t, c, k, as) (t)[((size_t)(c) * R + (size_t)(k)) * (size_t)(as)]
+#define TR(t, c, k) TRS(t, c, k, CILQR_MAX_ALPHA_TRIALS)
+__host__ __device__ inline size_t slab_doubles(int N) {
     return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
+}
+__host__ __device__ inline size_t scratch_doubles(int N) {
+    return slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * (size_t)(N + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -666,7 +677,9 @@ __device__ inline double total_cost_lds(const Cst& c, const Lds& l, const AlmSt&
 template <bool DBG, int NCH, bool ALM, int NTR>
 __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt& al, const double* scr, int a0,
                                          int nt, int lane, int idx0, int flags_in, int* n_fallback, double J[NTR],
-                                         long long* sub = nullptr, int slot0 = 0) {
+                                         long long* sub = nullptr, int slot0 = 0, int as = CILQR_MAX_ALPHA_TRIALS) {
+    // scr/as: where the trials live — the slab (as = 20, trial a0 + tt at scr + a0 + tt) or, for the first
+    // trial of a shallow iteration, the first-trial buffer (as = 1, a0 = 0)
     const int flags = DBG ? flags_in : 0;
     const int N = c.N;
     const int R = N + 1;
@@ -688,10 +701,10 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
             xk[tt][ch][0] = xk[tt][ch][1] = xk[tt][ch][2] = xk[tt][ch][3] = 0.0;
             uk[tt][ch][0] = uk[tt][ch][1] = um[tt][ch][0] = um[tt][ch][1] = 0.0;
             if (tt < nt && k <= N) {
-                xk[tt][ch][0] = TR(t, 0, k); xk[tt][ch][1] = TR(t, 1, k);
-                xk[tt][ch][2] = TR(t, 2, k); xk[tt][ch][3] = TR(t, 3, k);
-                if (k < N) { uk[tt][ch][0] = TR(t, 4, k); uk[tt][ch][1] = TR(t, 5, k); }
-                if (k >= 1) { um[tt][ch][0] = TR(t, 4, k - 1); um[tt][ch][1] = TR(t, 5, k - 1); }
+                xk[tt][ch][0] = TRS(t, 0, k, as); xk[tt][ch][1] = TRS(t, 1, k, as);
+                xk[tt][ch][2] = TRS(t, 2, k, as); xk[tt][ch][3] = TRS(t, 3, k, as);
+                if (k < N) { uk[tt][ch][0] = TRS(t, 4, k, as); uk[tt][ch][1] = TRS(t, 5, k, as); }
+                if (k >= 1) { um[tt][ch][0] = TRS(t, 4, k - 1, as); um[tt][ch][1] = TRS(t, 5, k - 1, as); }
             }
         }
     }
@@ -760,7 +773,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
         int s = idx0;
         if (lane == 0) tix[0] = s;
         for (int i = 1; i <= N; ++i) {
-            s = ref_scan_from(c, l, TR(t, 0, i), TR(t, 1, i), s);
+            s = ref_scan_from(c, l, TRS(t, 0, i, as), TRS(t, 1, i, as), s);
             if (lane == 0) tix[i] = s;
         }
     }
@@ -912,25 +925,27 @@ __device__ inline void ref_indices_lds(const Cst& c, Lds& l, int lane, int& idx0
 // forward_pass (cs:442-461) for all trial step sizes at once: lane a < n_alpha uses alpha = 2^-a.
 // The trial trajectories go to the scratch slab; their reference points are found later, only for
 // the trials whose cost is actually needed.
+// `scr`, `as`: destination — the slab (as = 20: lane a writes trial a) or the first-trial buffer (as = 1,
+// n_alpha = 1: only alpha = 1 is rolled out).  A trial trajectory has the same bits whichever pass produced it.
 template <int RP>
-__device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
+__device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha, int as) {
     const int N = c.N;
     const int R = N + 1;
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
         double* t = scr + lane;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
-        TR(t, 0, 0) = xc[0]; TR(t, 1, 0) = xc[1]; TR(t, 2, 0) = xc[2]; TR(t, 3, 0) = xc[3];
+        TRS(t, 0, 0, as) = xc[0]; TRS(t, 1, 0, as) = xc[1]; TRS(t, 2, 0, as) = xc[2]; TRS(t, 3, 0, as) = xc[3];
         const double* Ki = l.kd;
         const double* xi = l.x;
         const double* ui = l.u;
-        const size_t CS = (size_t)R * CILQR_MAX_ALPHA_TRIALS; // component stride
+        const size_t CS = (size_t)R * (size_t)as; // component stride
         // stores go through a wave-uniform row pointer plus this lane's byte offset (scalar base + 32-bit
         // vector offset addressing: no per-store 64-bit address arithmetic in vector registers)
-        char* tx = reinterpret_cast<char*>(scr + CILQR_MAX_ALPHA_TRIALS);   // row 1 of component 0
-        char* tu = reinterpret_cast<char*>(scr + 4 * CS);                   // row 0 of component 4
+        char* tx = reinterpret_cast<char*>(scr + as);       // row 1 of component 0
+        char* tu = reinterpret_cast<char*>(scr + 4 * CS);   // row 0 of component 4
         const unsigned lane_off = 8u * (unsigned)lane;
-        const size_t CSB = CS * sizeof(double), ROWB = CILQR_MAX_ALPHA_TRIALS * sizeof(double);
+        const size_t CSB = CS * sizeof(double), ROWB = (size_t)as * sizeof(double);
 #define CILQR_SLAB_ST(base, comp, val) (*reinterpret_cast<double*>((base) + (comp) * CSB + lane_off) = (val))
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
@@ -1020,26 +1035,28 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
     wave_sync();
 }
 
-__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha) {
+__device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha,
+                                      int as = CILQR_MAX_ALPHA_TRIALS) {
     // one loop per vehicle model: only that model's polynomial constants are live inside it
-    if (c.rp == 0) rollout_trials_rp<0>(c, l, scr, lane, n_alpha);
-    else rollout_trials_rp<1>(c, l, scr, lane, n_alpha);
+    if (c.rp == 0) rollout_trials_rp<0>(c, l, scr, lane, n_alpha, as);
+    else rollout_trials_rp<1>(c, l, scr, lane, n_alpha, as);
 }
 
 // copy trial `a` (costed in slot `slot` of the last pass, whose index row is still in l.tidx) into the current trajectory
-__device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int slot, int lane) {
+__device__ inline void accept_trial(const Cst& c, const Lds& l, const double* scr, int a, int slot, int lane,
+                                    int as = CILQR_MAX_ALPHA_TRIALS) {
     const int N = c.N;
     const int R = N + 1;
     const double* t = scr + a;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
-        l.x[4 * k] = TR(t, 0, k);
-        l.x[4 * k + 1] = TR(t, 1, k);
-        l.x[4 * k + 2] = TR(t, 2, k);
-        l.x[4 * k + 3] = TR(t, 3, k);
+        l.x[4 * k] = TRS(t, 0, k, as);
+        l.x[4 * k + 1] = TRS(t, 1, k, as);
+        l.x[4 * k + 2] = TRS(t, 2, k, as);
+        l.x[4 * k + 3] = TRS(t, 3, k, as);
         l.ridx[k] = l.tidx[slot * (N + 2) + k];
         if (k < N) {
-            l.u[2 * k] = TR(t, 4, k);
-            l.u[2 * k + 1] = TR(t, 5, k);
+            l.u[2 * k] = TRS(t, 4, k, as);
+            l.u[2 * k + 1] = TRS(t, 5, k, as);
         }
     }
     wave_sync();

@@ -160,6 +160,10 @@ class BatchedCILQR:
         """-1 automatic, 0 one wavefront per trajectory, 1 main + helper wavefront"""
         check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
 
+    def set_rollout_mode(self, mode):
+        """-1 adaptive, 0 all 20 step sizes in one rollout pass, 1 the first trial alone first"""
+        check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
+
     def set_debug_flags(self, flags):
         check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
