@@ -112,7 +112,9 @@ enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 // trials' latencies inside one wavefront (pays while SIMDs hold one or two wavefronts: +5 % at B = 1536-2048);
 // 1 keeps fewer values live (27 instead of 68 spilled registers) and is the faster choice once every SIMD
 // holds two wavefronts anyway (+1.5 % at B >= 3072)
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT>
+// NC = horizon known at compile time (0: taken from the parameter table): every LDS offset but the lane window's
+// and every row count become constants — fewer live scalar registers, addresses folded into instruction offsets
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -121,7 +123,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
     if (b >= a.B) return;
-    const int N = a.N; // one horizon per handle
+    const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
         if (wave == 0) {
             const double qnan = dm_from_bits(0x7ff8000000000000ULL);
@@ -141,6 +143,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS);
     Cst c;
     load_cst(c, a, b, l, lane);
+    if (NC) c.N = NC;
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
     double* first = scr + slab_doubles(N); // the first-trial buffer
     AlmSt al = load_alm(a, b, N);
@@ -251,76 +254,55 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         } else {
             flag = 0;
             const bool deep = (a.tier == 0) || (a.tier < 0 && deep_next);
-            if (deep) rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
-            else rollout_trials(c, l, first, lane, 1, 1);
-            PROF_ADD(PH_ROLLOUT);
-            if (PROF && a.prof) ph_acc[deep ? PH_ROLL_ALL : PH_ROLL_FIRST] += 1;
-            if (HELP) {
-                if (lane == 0) {
-                    l.ctli[CTL_MODE] = deep ? 1 : 2;
-                    l.ctld[CTLD_RHO] = al.rho; l.ctld[CTLD_JCUR] = J_cur; l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1];
-                }
-                __syncthreads(); // B1
-            }
+            bool have_all = false; // the slab holds all 20 trial trajectories of this iteration
             bool done = false;
             int t0 = 0;
-            if (!deep) {
-                // the first trial on its own, from the first-trial buffer
-                double J1[1];
-                total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, first, 0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                    (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0, 1);
-                PROF_ADD(PH_TRIAL_COST);
-                if (HELP) {
-                    if (lane == 0) l.ctld[CTLD_JM] = J1[0];
-                    __syncthreads(); // B2s
-                }
-                new_J = J1[0];
-                trials = 1;
-                const int verdict = trial_verdict(J_cur, new_J, 0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
-                if (verdict == 1) {
-                    status = CILQR_CONVERGED;
-                    alpha_idx = 0;
-                    done = true;
-                } else if (verdict == 2) {
-                    flag = 1;
-                    alpha_idx = 0;
-                    accept_trial(c, l, first, 0, 0, lane, 1);
-                    PROF_ADD(PH_ACCEPT);
-                    J_cur = new_J;
-                    done = true;
-                } else {
-                    // rejected: now the other step sizes (lane 0 repeats the first trial: the same bits)
-                    rollout_trials(c, l, scr, lane, CILQR_MAX_ALPHA_TRIALS);
-                    PROF_ADD(PH_ROLLOUT);
-                    if (PROF && a.prof) ph_acc[PH_ROLL_SECOND] += 1;
-                    if (HELP) __syncthreads(); // B3
-                    t0 = 1;
-                }
-            }
-            // the line search of cs:354-372; the costs are produced pass by pass — alpha = 1 alone
-            // (usually accepted), then NTP trials per pass (two with a helper wavefront) — and consumed strictly in order
             int par = 0; // helper mode: which pair of cost slots this pass uses
-            for (; t0 < CILQR_MAX_ALPHA_TRIALS && !done;) {
+            // The line search of cs:354-372.  The costs are produced pass by pass — alpha = 1 alone (usually
+            // accepted), then NTP trials per pass (two with a helper wavefront) — and consumed strictly in order.
+            // One call site each for the rollout, the costing and the acceptance keeps the loop body small.
+            while (t0 < CILQR_MAX_ALPHA_TRIALS && !done) {
+                if (t0 == 0 || !have_all) {
+                    // t0 == 0: the iteration's first rollout pass; t0 == 1 without the slab: the first trial
+                    // was rejected, now the other step sizes (lane 0 repeats the first trial: the same bits)
+                    const bool all = deep || t0 == 1;
+                    if (t0 == 1) restore_gains_head(l, first, N, lane);
+                    rollout_trials(c, l, all ? scr : first, lane, all ? CILQR_MAX_ALPHA_TRIALS : 1, all ? CILQR_MAX_ALPHA_TRIALS : 1);
+                    have_all = all;
+                    PROF_ADD(PH_ROLLOUT);
+                    if (PROF && a.prof) ph_acc[t0 == 1 ? PH_ROLL_SECOND : (all ? PH_ROLL_ALL : PH_ROLL_FIRST)] += 1;
+                    if (HELP) {
+                        if (t0 == 0 && lane == 0) {
+                            l.ctli[CTL_MODE] = all ? 1 : 2;
+                            l.ctld[CTLD_RHO] = al.rho; l.ctld[CTLD_JCUR] = J_cur; l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1];
+                        }
+                        __syncthreads(); // B1 (first pass) / B3 (second pass)
+                    }
+                    // the stage-cost scratch lies over the gains of the first steps: a shallow iteration may
+                    // still need them for its second pass
+                    if (!all) save_gains_head(l, first, N, lane);
+                }
+                const double* src = have_all ? scr : first;
+                const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
                 double Jp[CILQR_NT];
                 int nt = (t0 == 0) ? 1 : NTP;
-                if (HELP) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
+                if (HELP && have_all) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
                 if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
-                if (HELP) {
+                if (HELP || nt == 1) {
                     double J1[1];
-                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0);
+                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, src, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
+                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0, as);
                     Jp[0] = J1[0];
-                    if (lane == 0) l.ctld[CTLD_JM + par] = J1[0];
-                    __syncthreads(); // B2
-                    Jp[1] = l.ctld[CTLD_JH + par];
-                    par ^= 1;
-                } else if (nt == 1) {
-                    double J1[1];
-                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
-                    Jp[0] = J1[0];
+                    if (HELP) {
+                        if (lane == 0) l.ctld[CTLD_JM + par] = J1[0];
+                        __syncthreads(); // B2 (B2s for the lone first trial of a shallow iteration)
+                        if (have_all) {
+                            Jp[1] = l.ctld[CTLD_JH + par];
+                            par ^= 1;
+                        }
+                    }
                 } else if (NTP > 1) {
-                    total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, scr, t0, nt, lane, idx0, a.flags, &n_fallback,
+                    total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, src, t0, nt, lane, idx0, a.flags, &n_fallback,
                                                                Jp, (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                 }
                 PROF_ADD(PH_TRIAL_COST);
@@ -337,7 +319,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                         if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
                         flag = 1;
                         alpha_idx = t;
-                        accept_trial(c, l, scr, t, tt, lane);
+                        accept_trial(c, l, src, t, tt, lane, as);
                         PROF_ADD(PH_ACCEPT);
                         J_cur = new_J;
                         done = true;
@@ -1229,8 +1211,12 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
                         : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
         } else if (help) {
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
+            if (a.N == 50) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 50>;
+            if (a.N == 100) kern = k_solve<false, 2, false, true, false, 1, CILQR_NT, 100>;
         } else if (B > h->single_trial_min_batch) {
             kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
+            if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
+            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100>;
             one = true;
         } else if (B > h->occ2_min_batch) {
             // two rows per lane: paired trials spill too much

@@ -136,8 +136,10 @@ struct Lds {
     CstK* ck;    // the cost model's constants (see Cst)
     double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
     double* cs;  // [slots][3][(N+1)] stage-cost scratch: state, ctrl, barrier (slots = trials costed concurrently).
-                 // Its own array: the gains in kd must survive the costing of the first trial, because the other 19
-                 // trial trajectories are only rolled out once that one has been rejected (see k_solve)
+                 // ALIASES kd: the gains are dead once the rollout has produced the trial trajectories, and costs
+                 // are only summed then.  An iteration that rolls out the first trial alone may still need them for
+                 // a second pass: it parks the 3 (N+1) doubles its lone costing overwrites behind the first-trial
+                 // buffer (save_gains_head / restore_gains_head)
     double* win; // [W][2] copy of lane_xy[w0 .. w0+W): the stretch of lane the horizon can reach
     int* ridx;   // [(N+1)] lane-sample index of every row of the current trajectory
     int* tidx;   // [slots][(N+2)] the same for the trial trajectories being costed
@@ -161,32 +163,39 @@ struct Lds {
 #define CILQR_NT 2 /* trial trajectories costed per pass (after the first): their memory latencies overlap */
 
 // slots = trial trajectories costed concurrently by a block: 2 with a helper wavefront or paired passes, else 1
+__host__ __device__ inline int kd_doubles(int N, int slots) {
+    const int g = CILQR_KD * N, c = slots * 3 * (N + 1); // gains / stage-cost scratch share the array
+    return g > c ? g : c;
+}
 __host__ __device__ inline int lds_doubles(int N, int alm, int slots) {
-    return 4 * (N + 1) + 2 * N + CILQR_KD * N + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES +
-           slots * 3 * (N + 1);
+    return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm, int slots) {
-    return sizeof(double) * ((size_t)lds_doubles(N, alm, slots) + 2 * (size_t)W) + sizeof(int) * (size_t)((1 + slots) * (N + 2) + 8);
+    return sizeof(double) * ((size_t)lds_doubles(N, alm, slots) + 2 * (size_t)W) + sizeof(int) * (size_t)(((1 + slots) * (N + 2) + 8 + 1) & ~1);
 }
 
 __device__ inline void carve(Lds& l, double* base, int N, int W, int alm, int slots) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
-    l.kd = p; p += CILQR_KD * N;
+    l.kd = p; p += kd_doubles(N, slots);
     l.lx = p; p += 4 * (N + 1);
     l.lu = p; p += 2 * N;
     l.lxs = alm ? 16 : 7;
     l.lxx = p; p += l.lxs * (N + 1);
     l.luu = p; p += 2 * N;
     l.xch = p; p += CILQR_XCH;
-    l.cs = p; p += slots * 3 * (N + 1);
+    l.cs = l.kd;
     l.ctld = p; p += CILQR_CTLD;
     l.ck = reinterpret_cast<CstK*>(p); p += CILQR_CSTK_DOUBLES;
-    l.win = p; p += 2 * W;
+    // the index arrays next (an even number of ints), the lane window — the only part whose size is not a function
+    // of the horizon — last: with a compile-time horizon every other offset is a constant
+    const int n_int = ((1 + slots) * (N + 2) + 8 + 1) & ~1;
     l.ridx = reinterpret_cast<int*>(p);
     l.tidx = l.ridx + (N + 2);
     l.ctli = l.tidx + slots * (N + 2);
+    p += n_int / 2;
+    l.win = p; p += 2 * W;
     l.w0 = 0;
     l.W = 0; // nothing staged yet: every lookup goes to global memory
 }
@@ -227,7 +236,7 @@ __host__ __device__ inline size_t slab_doubles(int N) {
     return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
 }
 __host__ __device__ inline size_t scratch_doubles(int N) {
-    return slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * (size_t)(N + 1);
+    return slab_doubles(N) + (size_t)(CILQR_TRIAL_ROWS + 3) * (size_t)(N + 1); // first-trial buffer + parked gains
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1059,6 +1068,18 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
             l.u[2 * k + 1] = TRS(t, 5, k, as);
         }
     }
+    wave_sync();
+}
+
+// The head of l.kd that the lone costing of a first trial overwrites (slot 0 of the stage-cost scratch), parked
+// behind the first-trial buffer and brought back if the search goes on to a second rollout pass.
+__device__ inline void save_gains_head(const Lds& l, double* first, int N, int lane) {
+    double* park = first + CILQR_TRIAL_ROWS * (N + 1);
+    for (int e = lane; e < 3 * (N + 1); e += CILQR_WAVE) park[e] = l.kd[e];
+}
+__device__ inline void restore_gains_head(const Lds& l, const double* first, int N, int lane) {
+    const double* park = first + CILQR_TRIAL_ROWS * (N + 1);
+    for (int e = lane; e < 3 * (N + 1); e += CILQR_WAVE) l.kd[e] = park[e];
     wave_sync();
 }
 
