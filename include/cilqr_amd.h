@@ -255,6 +255,12 @@ int cilqr_build_routes(const double* wx, const double* wy, int32_t n, const doub
                        double max_simulation_time, double delta_t, double* routes, int32_t T_cap,
                        int32_t* T_out, int32_t* line_num, double* start_s);
 
+/* Initial states of the synthetic benchmark batches (BASELINE configs 2-5): row b of a batch is a
+ * function of (seed, first + b) alone — splitmix64 counter generator -> uniform -> Box-Muller — so shards of a
+ * batch regenerate exactly their own rows.  x0_out[B][4] = base + (U(-5,5), +-U(0.05,1.0), N(0,0.5), N(0,0.02));
+ * |dy| >= 0.05 keeps the starts off the singular reference line.  Host C++ twin of workloads.py::perturbed_starts. */
+int cilqr_perturbed_starts(const double base[4], int32_t B, uint64_t seed, int64_t first, double* x0_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,9 @@
 //         const ReferenceLine& ref_waypoints, double ref_velo,
 //         const std::vector<RoutingLine>& obs_preds, const Eigen::Vector2d& road_boaders);
 // The Eigen-typed overload is compiled only when <Eigen/Core> is available (it is not in the build
-// container); the plain-array overload below it is what the overload forwards to.  The config type
+// container: tests/eigen_standin/ holds a minimal stand-in with which tests/test_cabi.py compiles and links this
+// overload against a caller shaped like the reference's main()); the plain-array overload below it is what the
+// overload forwards to.  The config type
 // is a template parameter: anything with `template<class T> T get_config(const std::string&) const`
 // (the reference's GlobalConfig, include/global_config.hpp:30-36) works unchanged.
 //
@@ -14,6 +16,7 @@
 // use_last_solution (src/cilqr_solver.cpp:97-102,144).  One instance = one handle = one GPU stream;
 // like the reference class it is not re-entrant.
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <tuple>

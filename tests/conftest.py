@@ -66,3 +66,43 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def reference_layout_yaml(flat):
+    """A scenario in the layout of the reference's config/*.yaml (block maps, inline lists, "- [..]" rows, comments),
+    re-created from one of our flattened scenario files — what include/cilqr_config.hpp's YAML reader must handle."""
+    nested = {"max_simulation_time": flat["max_simulation_time"], "delta_t": flat["delta_t"], "lqr": {}, "iteration": {},
+              "vehicle": {}, "laneline": {"reference": {}}, "visualization": {}}
+    for k, v in flat.items():
+        parts = k.split("/")
+        if len(parts) == 2 and parts[0] in nested:
+            nested[parts[0]][parts[1]] = v
+        elif len(parts) == 3:
+            nested["laneline"]["reference"][parts[2]] = v
+    nested["initial_condition"] = flat["initial_condition"]
+
+    def scalar(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, str):
+            return f'"{v}"'
+        return repr(v)
+
+    def emit(d, ind=0):
+        out = []
+        for k, v in d.items():
+            pad = " " * ind
+            if isinstance(v, dict):
+                out.append(f"{pad}{k}:   # section")
+                out += emit(v, ind + 2)
+            elif isinstance(v, list) and v and isinstance(v[0], list):
+                out.append(f"{pad}{k}:")
+                out.append(f"{pad}  # [x, y, v, yaw]")
+                out += [f"{pad}  - [{', '.join(repr(e) for e in row)}]" for row in v]
+            elif isinstance(v, list):
+                out.append(f"{pad}{k}: [{', '.join(repr(e) for e in v)}]")
+            else:
+                out.append(f"{pad}{k}: {scalar(v)}")
+        return out
+
+    return "\n".join(["# generated for the test"] + emit(nested)) + "\n"

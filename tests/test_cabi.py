@@ -100,6 +100,23 @@ def test_cpp_host_driver_builds_against_the_cabi(pkg):
     assert exe.exists()
 
 
+def test_eigen_typed_solve_overload_compiles_against_a_reference_shaped_caller(pkg, tmp_path, gpu_available):
+    """include/cilqr_solver_shim.hpp's Eigen-typed solve() (the reference's signature, cilqr_solver.hpp:37-41) is
+    dead text without <Eigen/Core>; tests/eigen_standin holds a minimal stand-in (test infrastructure) with which
+    a caller shaped like the reference's main() (mp:178,194-197) compiles, links libcilqr_amd.so and — on a GPU box
+    — plans one tick.  A syntax / ABI check, nothing more."""
+    import subprocess
+    exe = tmp_path / "check_shim"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"),
+           "-I", str(ROOT / "tests" / "eigen_standin"), str(ROOT / "tests" / "eigen_standin" / "check_shim.cpp"),
+           "-L", str(pkg._lib.PKG_DIR), "-lcilqr_amd", "-Wl,-rpath," + str(pkg._lib.PKG_DIR), "-o", str(exe)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ("EIGEN-SHIM-OK" if gpu_available else "EIGEN-SHIM-COMPILED") in r.stdout, r.stdout
+
+
 def test_cpp_config_reader_yaml_matches_json(pkg, tmp_path):
     """include/cilqr_config.hpp reads the reference's YAML layout and the flattened JSON to the same
     values (checked through a tiny C++ program; the YAML is re-created from our scenario data)."""

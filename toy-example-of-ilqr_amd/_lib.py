@@ -117,6 +117,7 @@ SIGNATURES = {
     "cilqr_detmath_eval": (C.c_int, [_P, _I, _P, _P, _I, _P]),
     "cilqr_reference_line_build": (C.c_int, [_P, _P, _I, _D, _D, _P, _P, _P, _P, _I, C.POINTER(_I)]),
     "cilqr_reference_line_position": (C.c_int, [_P, _P, _I, _D, _D, _P]),
+    "cilqr_perturbed_starts": (C.c_int, [_P, _I, C.c_uint64, C.c_int64, _P]),
     "cilqr_build_routes": (C.c_int, [_P, _P, _I, _P, _I, _D, _P, _I, _D, _D, _P, _I, C.POINTER(_I), _P, _P]),
 }
 

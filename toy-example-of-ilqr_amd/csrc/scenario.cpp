@@ -228,3 +228,45 @@ extern "C" int cilqr_build_routes(const double* wx, const double* wy, int32_t n,
     }
     return CILQR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The benchmark workloads' initial states: counter-based generator — splitmix64 of
+// (seed ^ splitmix64(counter)) -> uniform in (0, 1) -> Box-Muller — so that any implementation regenerates row b of
+// a batch from (seed, b) alone.  Twin of toy-example-of-ilqr_amd/workloads.py::perturbed_starts (counter = 8 b + i,
+// i = 0..4): x0_b = base + (U(-5, 5), +-U(0.05, 1.0), N(0, 0.5), N(0, 0.02)).  The uniform components are bit-identical
+// to the Python twin; the normal ones go through log / cos / sqrt of the platform's libm and may differ from
+// numpy's in the last place.
+namespace {
+inline uint64_t splitmix64(uint64_t v) {
+    v += 0x9E3779B97F4A7C15ULL;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBULL;
+    return v ^ (v >> 31);
+}
+inline double uniform01(uint64_t seed, uint64_t counter) {
+    const uint64_t r = splitmix64(seed ^ splitmix64(counter));
+    return (static_cast<double>(r >> 11) + 0.5) / 9007199254740992.0;  // 2^53
+}
+inline double normal01(uint64_t seed, uint64_t counter) {
+    const double u1 = uniform01(seed, 2 * counter), u2 = uniform01(seed, 2 * counter + 1);
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+}
+}  // namespace
+
+extern "C" int cilqr_perturbed_starts(const double base[4], int32_t B, uint64_t seed, int64_t first, double* x0_out) {
+    if (!base || !x0_out || B < 1 || first < 0) return CILQR_ERR_BAD_ARG;
+    for (int32_t i = 0; i < B; ++i) {
+        const uint64_t b = static_cast<uint64_t>(first) + static_cast<uint64_t>(i);
+        const double dx = -5.0 + 10.0 * uniform01(seed, 8 * b + 0);
+        const double mag = 0.05 + 0.95 * uniform01(seed, 8 * b + 1);
+        const double sgn = uniform01(seed, 8 * b + 2) < 0.5 ? 1.0 : -1.0;
+        const double dv = 0.5 * normal01(seed, 8 * b + 3);
+        const double dyaw = 0.02 * normal01(seed, 8 * b + 4);
+        double* o = x0_out + static_cast<size_t>(i) * 4;
+        o[0] = base[0] + dx;
+        o[1] = base[1] + sgn * mag;
+        o[2] = base[2] + dv;
+        o[3] = base[3] + dyaw;
+    }
+    return CILQR_OK;
+}

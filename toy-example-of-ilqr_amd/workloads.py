@@ -35,7 +35,9 @@ def normal(seed, counter):
 def perturbed_starts(base, B, seed, first=0):
     """x0_b = base + (U(-5,5), +-U(0.05,1.0), N(0,0.5), N(0,0.02)); |dy| >= 0.05 keeps the start off
     the singular reference line (SURVEY.md §7 hard part 1).  `first` = global index of row 0, so a
-    shard of a larger batch regenerates exactly its own rows."""
+    shard of a larger batch regenerates exactly its own rows.  Counter of component i of row b: 8 b + i (the
+    normal components consume counters 2 c and 2 c + 1 of their own stream).  Host C++ twin:
+    cilqr_perturbed_starts (csrc/scenario.cpp)."""
     out = np.empty((B, 4))
     for i in range(B):
         b = first + i
