@@ -591,9 +591,9 @@ __global__ void k_detmath(int f, const double* __restrict__ x, const double* __r
         case 5: r = dm_hypot(a, b); break;
         case 6: r = a / b; break;
         case 7: r = dm_sqrt(a < 0 ? -a : a); break;
-        case 8: r = dm_sin<1>(a); break;  // the flavours with coefficients pinned to vector registers
-        case 9: r = dm_cos<1>(a); break;
-        case 10: r = dm_tan<1>(a); break;
+        case 8: { DmPinned pk; dm_pin_load(pk); r = dm_sin<1>(a, &pk); break; }  // coefficients pinned to vector registers
+        case 9: { DmPinned pk; dm_pin_load(pk); r = dm_cos<1>(a, &pk); break; }
+        case 10: { DmPinned pk; dm_pin_load(pk); r = dm_tan<1>(a, &pk); break; }
         default: break;
     }
     o[i] = r;

@@ -243,20 +243,21 @@ __host__ __device__ inline size_t scratch_doubles(int N) {
 // ut:262-283 kinematic_propagate
 // TRIG = flavour of the elementary functions (detmath.h: DM_PIN, DM_NOSHORT, DM_SMALL)
 template <int RP, int TRIG = 0>
-__device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4]) {
+__device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4],
+                                 const DmPinned* pk = nullptr) {
     if (RP == 0) {
         double sn, cs;
-        dm_sincos<TRIG>(x[3], &sn, &cs);
-        double tn = dm_tan<TRIG>(u[1]);
+        dm_sincos<TRIG>(x[3], &sn, &cs, pk);
+        double tn = dm_tan<TRIG>(u[1], pk);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
         xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
     } else {
-        double beta = dm_atan<TRIG>(dm_tan<TRIG>(u[1]) / 2);
+        double beta = dm_atan<TRIG>(dm_tan<TRIG>(u[1], pk) / 2);
         double sn, cs;
-        dm_sincos<TRIG>(beta + x[3], &sn, &cs);
-        double sb = dm_sin<TRIG>(beta);
+        dm_sincos<TRIG>(beta + x[3], &sn, &cs, pk);
+        double sb = dm_sin<TRIG>(beta, pk);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
@@ -268,25 +269,26 @@ __device__ inline void propagate(const Cst& c, const double x[4], const double u
 // interval selections are known to be the identity (detmath.h, DM_SMALL).  The caller has checked
 // |yaw| < 0.785 and |steer| < 0.7 (so |tan(steer)| / 2 < 0.4375 and |beta| < 0.42); for the CoG model the
 // angle beta + yaw is only known here: returns false, with xn untouched, when it is not small on
-// some lane — the caller then redoes the step the general way.
+// some lane — the caller then redoes the step the general way.  pk: the pinned coefficients (dm_pin_load).
 template <int RP>
-__device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4]) {
+__device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4],
+                                       const DmPinned* pk) {
     constexpr int T = DM_PIN | DM_SMALL;
     if (RP == 0) {
         double sn, cs;
-        dm_sincos<T>(x[3], &sn, &cs);
-        double tn = dm_tan<T>(u[1]);
+        dm_sincos<T>(x[3], &sn, &cs, pk);
+        double tn = dm_tan<T>(u[1], pk);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
         xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
     } else {
-        double beta = dm_atan<T>(dm_tan<T>(u[1]) / 2);
+        double beta = dm_atan<T>(dm_tan<T>(u[1], pk) / 2);
         const double ang = beta + x[3];
         if (!DM_WAVE_ALL(__builtin_fabs(ang) < 0.785)) return false;
         double sn, cs;
-        dm_sincos<T>(ang, &sn, &cs);
-        double sb = dm_sin<T>(beta);
+        dm_sincos<T>(ang, &sn, &cs, pk);
+        double sb = dm_sin<T>(beta, pk);
         xn[0] = x[0] + x[2] * cs * c.dt;
         xn[1] = x[1] + x[2] * sn * c.dt;
         xn[2] = x[2] + u[0] * c.dt;
@@ -936,111 +938,127 @@ __device__ inline void ref_indices_lds(const Cst& c, Lds& l, int lane, int& idx0
 // the trials whose cost is actually needed.
 // `scr`, `as`: destination — the slab (as = 20: lane a writes trial a) or the first-trial buffer (as = 1,
 // n_alpha = 1: only alpha = 1 is rolled out).  A trial trajectory has the same bits whichever pass produced it.
+//
+// One step of the closed-loop rollout: the nominal point and the gains of the step arrive in `g` (fetched from LDS
+// one step ahead, see RollIn), xc is the trial state on entry and the next state on exit.  SMALL = the straight-line
+// small-angle step: returns false — nothing stored, xc untouched — when some active lane does not qualify.
+struct RollIn {
+    double k[CILQR_KD], x[4], u[2];
+};
+__device__ inline void roll_fetch(RollIn& g, const Lds& l, int i) {
+#pragma unroll
+    for (int e = 0; e < CILQR_KD; ++e) g.k[e] = l.kd[CILQR_KD * i + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g.x[e] = l.x[4 * i + e];
+    g.u[0] = l.u[2 * i];
+    g.u[1] = l.u[2 * i + 1];
+}
+typedef char __attribute__((address_space(1))) gchar_w;     // HBM, writable (global_store, not flat_store)
+typedef double __attribute__((address_space(1))) gdouble_w;
+struct RollOut {      // where the lanes store: wave-uniform row pointers (scalar registers) + this lane's byte offset
+    gchar_w* tx;      // row i + 1 of component 0
+    gchar_w* tu;      // row i of component 4
+    size_t csb, rowb; // component / row stride in bytes
+    unsigned lane_off;
+};
+template <int RP, bool SMALL>
+__device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], RollOut& o) {
+    const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
+    const double k0 = ((g.k[0] * dx0 + g.k[1] * dx1) + g.k[2] * dx2) + g.k[3] * dx3;
+    const double k1 = ((g.k[5] * dx0 + g.k[6] * dx1) + g.k[7] * dx2) + g.k[8] * dx3;
+    double un[2];
+    un[0] = (g.u[0] + k0) + alpha * g.k[CILQR_KD_D(0)];
+    un[1] = (g.u[1] + k1) + alpha * g.k[CILQR_KD_D(1)];
+    double xn[4];
+    if (SMALL) {
+        if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) return false;
+        if (!propagate_small<RP>(c, xc, un, xn, &pk)) return false;
+    } else {
+        propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn, &pk);
+    }
+#define CILQR_SLAB_ST(base, comp, val) (*reinterpret_cast<gdouble_w*>((base) + (comp) * o.csb + o.lane_off) = (val))
+    CILQR_SLAB_ST(o.tu, 0, un[0]);
+    CILQR_SLAB_ST(o.tu, 1, un[1]);
+    CILQR_SLAB_ST(o.tx, 0, xn[0]);
+    CILQR_SLAB_ST(o.tx, 1, xn[1]);
+    CILQR_SLAB_ST(o.tx, 2, xn[2]);
+    CILQR_SLAB_ST(o.tx, 3, xn[3]);
+#undef CILQR_SLAB_ST
+    xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+    o.tx += o.rowb;
+    o.tu += o.rowb;
+    return true;
+}
+
+// a wave-uniform value the compiler cannot see to be uniform (it descends from vector comparisons), moved into
+// scalar registers so that addresses built from it stay scalar
+__device__ inline int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline gdouble_w* uniform_ptr(double* p) {
+    const unsigned long long u = (unsigned long long)(size_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u & 0xffffffffULL));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return (gdouble_w*)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
 template <int RP>
-__device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha, int as) {
+__device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr_in, int lane, int n_alpha, int as_in) {
     const int N = c.N;
     const int R = N + 1;
+    const int as = uniform_int(as_in);
+    gdouble_w* scr = uniform_ptr(scr_in);
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
-        double* t = scr + lane;
+        gdouble_w* t = scr + lane;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         TRS(t, 0, 0, as) = xc[0]; TRS(t, 1, 0, as) = xc[1]; TRS(t, 2, 0, as) = xc[2]; TRS(t, 3, 0, as) = xc[3];
-        const double* Ki = l.kd;
-        const double* xi = l.x;
-        const double* ui = l.u;
         const size_t CS = (size_t)R * (size_t)as; // component stride
         // stores go through a wave-uniform row pointer plus this lane's byte offset (scalar base + 32-bit
         // vector offset addressing: no per-store 64-bit address arithmetic in vector registers)
-        char* tx = reinterpret_cast<char*>(scr + as);       // row 1 of component 0
-        char* tu = reinterpret_cast<char*>(scr + 4 * CS);   // row 0 of component 4
-        const unsigned lane_off = 8u * (unsigned)lane;
-        const size_t CSB = CS * sizeof(double), ROWB = (size_t)as * sizeof(double);
-#define CILQR_SLAB_ST(base, comp, val) (*reinterpret_cast<double*>((base) + (comp) * CSB + lane_off) = (val))
+        RollOut o;
+        o.tx = reinterpret_cast<gchar_w*>(scr + as);       // row 1 of component 0
+        o.tu = reinterpret_cast<gchar_w*>(scr + 4 * CS);   // row 0 of component 4
+        o.lane_off = 8u * (unsigned)lane;
+        o.csb = CS * sizeof(double);
+        o.rowb = (size_t)as * sizeof(double);
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
         // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
         // general loop, which finishes the horizon.
-        // In both, the gains and the nominal point of step i + 1 are fetched from LDS while step i computes.
+        // In both, the gains and the nominal point of step i + 1 are fetched from LDS while step i computes;
+        // the loops are unrolled by two over two register sets, so nothing is copied between steps.  The
+        // polynomial coefficients of sin / cos / tan sit in vector registers for the whole pass (dm_pin_load).
+        DmPinned pk;
+        dm_pin_load(pk);
         int i = 0;
         {
-            double kq[CILQR_KD], xq[4], uq[2];
-#pragma unroll
-            for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xq[e] = xi[e];
-            uq[0] = ui[0]; uq[1] = ui[1];
-            for (; i < N; ++i) {
-                double kk[CILQR_KD], xr[4], ur[2];
-#pragma unroll
-                for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xr[e] = xq[e];
-                ur[0] = uq[0]; ur[1] = uq[1];
-                const int nx = (i + 1 < N) ? i + 1 : i;
-#pragma unroll
-                for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * nx + e];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xq[e] = xi[4 * nx + e];
-                uq[0] = ui[2 * nx]; uq[1] = ui[2 * nx + 1];
-                double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
-                double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
-                double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
-                double un[2];
-                un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
-                un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
-                if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) break;
-                double xn[4];
-                if (!propagate_small<RP>(c, xc, un, xn)) break;
-                CILQR_SLAB_ST(tu, 0, un[0]);
-                CILQR_SLAB_ST(tu, 1, un[1]);
-                CILQR_SLAB_ST(tx, 0, xn[0]);
-                CILQR_SLAB_ST(tx, 1, xn[1]);
-                CILQR_SLAB_ST(tx, 2, xn[2]);
-                CILQR_SLAB_ST(tx, 3, xn[3]);
-                xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-                tx += ROWB; tu += ROWB;
+            RollIn ga, gb;
+            roll_fetch(ga, l, 0);
+            for (;;) {
+                if (i >= N) break;
+                if (i + 1 < N) roll_fetch(gb, l, i + 1);
+                if (!roll_step<RP, true>(c, pk, ga, alpha, xc, o)) break;
+                ++i;
+                if (i >= N) break;
+                if (i + 1 < N) roll_fetch(ga, l, i + 1);
+                if (!roll_step<RP, true>(c, pk, gb, alpha, xc, o)) break;
+                ++i;
             }
         }
         if (i < N) {
-            double kq[CILQR_KD], xq[4], uq[2];
-#pragma unroll
-            for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * i + e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xq[e] = xi[4 * i + e];
-            uq[0] = ui[2 * i]; uq[1] = ui[2 * i + 1];
-            for (; i < N; ++i) {
-                double kk[CILQR_KD], xr[4], ur[2];
-#pragma unroll
-                for (int e = 0; e < CILQR_KD; ++e) kk[e] = kq[e];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xr[e] = xq[e];
-                ur[0] = uq[0]; ur[1] = uq[1];
-                const int nx = (i + 1 < N) ? i + 1 : i;
-#pragma unroll
-                for (int e = 0; e < CILQR_KD; ++e) kq[e] = Ki[CILQR_KD * nx + e];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xq[e] = xi[4 * nx + e];
-                uq[0] = ui[2 * nx]; uq[1] = ui[2 * nx + 1];
-                double dx0 = xc[0] - xr[0], dx1 = xc[1] - xr[1], dx2 = xc[2] - xr[2], dx3 = xc[3] - xr[3];
-                double k0 = ((kk[0] * dx0 + kk[1] * dx1) + kk[2] * dx2) + kk[3] * dx3;
-                double k1 = ((kk[5] * dx0 + kk[6] * dx1) + kk[7] * dx2) + kk[8] * dx3;
-                double un[2];
-                un[0] = (ur[0] + k0) + alpha * kk[CILQR_KD_D(0)];
-                un[1] = (ur[1] + k1) + alpha * kk[CILQR_KD_D(1)];
-                double xn[4];
-                propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn);
-                CILQR_SLAB_ST(tu, 0, un[0]);
-                CILQR_SLAB_ST(tu, 1, un[1]);
-                CILQR_SLAB_ST(tx, 0, xn[0]);
-                CILQR_SLAB_ST(tx, 1, xn[1]);
-                CILQR_SLAB_ST(tx, 2, xn[2]);
-                CILQR_SLAB_ST(tx, 3, xn[3]);
-                xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-                tx += ROWB; tu += ROWB;
+            RollIn ga, gb;
+            roll_fetch(ga, l, i);
+            for (;;) {
+                if (i + 1 < N) roll_fetch(gb, l, i + 1);
+                roll_step<RP, false>(c, pk, ga, alpha, xc, o);
+                ++i;
+                if (i >= N) break;
+                if (i + 1 < N) roll_fetch(ga, l, i + 1);
+                roll_step<RP, false>(c, pk, gb, alpha, xc, o);
+                ++i;
+                if (i >= N) break;
             }
         }
     }
-#undef CILQR_SLAB_ST
     wave_sync();
 }
 

@@ -46,20 +46,55 @@
 #if defined(__HIPCC__)
 #define DM_TFN template <int VK = 0> DM_FN
 #define DM_T(fn) fn<VK>
+/* The coefficients of the DM_PIN flavour: made opaque ONCE (dm_pin_load, before the loop that uses them) and then
+ * read in place — an opaque value per use would cost a register copy per use. */
+struct DmPinned {
+    double S1, S2, S3, S4, S5, S6, C1, C2, C3, C4, C5, C6;   /* dm_ksincos */
+    double INV_PIO2, P1, P2, P3, P4, MAGIC;                  /* dm_trig_reduce */
+};
+static __device__ inline void dm_pin_load(DmPinned& k) {
+    k.S1 = -1.66666666666666324348e-01; k.S2 = 8.33333333332248946124e-03; k.S3 = -1.98412698298579493134e-04;
+    k.S4 = 2.75573137070700676789e-06; k.S5 = -2.50507602534068634195e-08; k.S6 = 1.58969099521155010221e-10;
+    k.C1 = 4.16666666666666019037e-02; k.C2 = -1.38888888888741095749e-03; k.C3 = 2.48015872894767294178e-05;
+    k.C4 = -2.75573143513906633035e-07; k.C5 = 2.08757232129817482790e-09; k.C6 = -1.13596475577881948265e-11;
+    k.INV_PIO2 = 6.36619772367581382433e-01; k.P1 = 1.57079632673412561417e+00; k.P2 = 6.07710050630396597660e-11;
+    k.P3 = 2.02226624871116645580e-21; k.P4 = 8.47842766036889956997e-32; k.MAGIC = 6755399441055744.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int VK>
-static __device__ inline double dm_const(double k) {
-    if (VK & DM_PIN) __asm__("" : "+v"(k));
-    return k;
+    /* the same literals as in the functions below (tests compare the pinned flavour with the plain one bit for
+     * bit); from here on the compiler sees 18 values in vector registers, not constants */
+    __asm__("" : "+v"(k.S1), "+v"(k.S2), "+v"(k.S3), "+v"(k.S4), "+v"(k.S5), "+v"(k.S6));
+    __asm__("" : "+v"(k.C1), "+v"(k.C2), "+v"(k.C3), "+v"(k.C4), "+v"(k.C5), "+v"(k.C6));
+    __asm__("" : "+v"(k.INV_PIO2), "+v"(k.P1), "+v"(k.P2), "+v"(k.P3), "+v"(k.P4), "+v"(k.MAGIC));
+#endif
 }
-#define DM_K(x) dm_const<VK>(x)
+#define DM_PKARG , const DmPinned* pk = nullptr
+#define DM_PK , pk
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_K(name, x) ((VK & DM_PIN) ? pk->name : (x))
+/* fma(a, b, k) with a pinned coefficient k as the addend: the compiler would pick the two-address form
+ * (v_fmac_f64, accumulating into the addend's register) and first copy the coefficient — one extra vector
+ * instruction per Horner step.  The three-operand instruction reads the coefficient in place.  Same operation. */
+template <int VK>
+static __device__ inline double dm_fmak(double a, double b, double k) {
+    if (VK & DM_PIN) {
+        double r;
+        __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
+        return r;
+    }
+    return __builtin_fma(a, b, k);
+}
+#define DM_FMAK(a, b, k) dm_fmak<VK>((a), (b), (k))
 #else
-#define DM_K(x) (x)
+#define DM_K(name, x) (x)
+#define DM_FMAK(a, b, k) DM_FMA((a), (b), (k))
 #endif
 #else
 #define DM_TFN DM_FN
 #define DM_T(fn) fn
-#define DM_K(x) (x)
+#define DM_PKARG
+#define DM_PK
+#define DM_K(name, x) (x)
+#define DM_FMAK(a, b, k) DM_FMA((a), (b), (k))
 #endif
 
 /* Wave-uniform shortcuts (device only).  A shortcut is taken when EVERY active lane qualifies, and it
@@ -153,13 +188,13 @@ DM_FN double dm_exp(double x) {
 }
 
 /* ---- trigonometric range reduction: x = n*(pi/2) + r, |r| <= pi/4 (+eps) ---- */
-DM_TFN double dm_trig_reduce(double x, int* quadrant) {
-    const double INV_PIO2 = DM_K(6.36619772367581382433e-01);
-    const double P1 = DM_K(1.57079632673412561417e+00);  /* first 33 bits of pi/2 */
-    const double P2 = DM_K(6.07710050630396597660e-11);  /* next 33 bits */
-    const double P3 = DM_K(2.02226624871116645580e-21);  /* next 33 bits */
-    const double P4 = DM_K(8.47842766036889956997e-32);  /* remainder */
-    const double MAGIC = DM_K(6755399441055744.0);
+DM_TFN double dm_trig_reduce(double x, int* quadrant DM_PKARG) {
+    const double INV_PIO2 = DM_K(INV_PIO2, 6.36619772367581382433e-01);
+    const double P1 = DM_K(P1, 1.57079632673412561417e+00);  /* first 33 bits of pi/2 */
+    const double P2 = DM_K(P2, 6.07710050630396597660e-11);  /* next 33 bits */
+    const double P3 = DM_K(P3, 2.02226624871116645580e-21);  /* next 33 bits */
+    const double P4 = DM_K(P4, 8.47842766036889956997e-32);  /* remainder */
+    const double MAGIC = DM_K(MAGIC, 6755399441055744.0);
     /* accurate for |x| <~ 2^30; beyond that the result is meaningless but still the same on host
      * and device (saturating quadrant conversion), and +-inf / NaN give NaN through r */
     double nd = (x * INV_PIO2 + MAGIC) - MAGIC;
@@ -172,32 +207,32 @@ DM_TFN double dm_trig_reduce(double x, int* quadrant) {
 }
 
 /* sin and cos kernels on |r| <= pi/4 share z = r*r */
-DM_TFN void dm_ksincos(double r, double* s_out, double* c_out) {
-    const double S1 = DM_K(-1.66666666666666324348e-01);
-    const double S2 = DM_K(8.33333333332248946124e-03);
-    const double S3 = DM_K(-1.98412698298579493134e-04);
-    const double S4 = DM_K(2.75573137070700676789e-06);
-    const double S5 = DM_K(-2.50507602534068634195e-08);
-    const double S6 = DM_K(1.58969099521155010221e-10);
-    const double C1 = DM_K(4.16666666666666019037e-02);
-    const double C2 = DM_K(-1.38888888888741095749e-03);
-    const double C3 = DM_K(2.48015872894767294178e-05);
-    const double C4 = DM_K(-2.75573143513906633035e-07);
-    const double C5 = DM_K(2.08757232129817482790e-09);
-    const double C6 = DM_K(-1.13596475577881948265e-11);
+DM_TFN void dm_ksincos(double r, double* s_out, double* c_out DM_PKARG) {
+    const double S1 = DM_K(S1, -1.66666666666666324348e-01);
+    const double S2 = DM_K(S2, 8.33333333332248946124e-03);
+    const double S3 = DM_K(S3, -1.98412698298579493134e-04);
+    const double S4 = DM_K(S4, 2.75573137070700676789e-06);
+    const double S5 = DM_K(S5, -2.50507602534068634195e-08);
+    const double S6 = DM_K(S6, 1.58969099521155010221e-10);
+    const double C1 = DM_K(C1, 4.16666666666666019037e-02);
+    const double C2 = DM_K(C2, -1.38888888888741095749e-03);
+    const double C3 = DM_K(C3, 2.48015872894767294178e-05);
+    const double C4 = DM_K(C4, -2.75573143513906633035e-07);
+    const double C5 = DM_K(C5, 2.08757232129817482790e-09);
+    const double C6 = DM_K(C6, -1.13596475577881948265e-11);
     double z = r * r;
-    double p = DM_FMA(z, S6, S5);
-    p = DM_FMA(z, p, S4);
-    p = DM_FMA(z, p, S3);
-    p = DM_FMA(z, p, S2);
-    p = DM_FMA(z, p, S1);
+    double p = DM_FMAK(z, S6, S5);
+    p = DM_FMAK(z, p, S4);
+    p = DM_FMAK(z, p, S3);
+    p = DM_FMAK(z, p, S2);
+    p = DM_FMAK(z, p, S1);
     double v = z * r;
     *s_out = DM_FMA(v, p, r);
-    double q = DM_FMA(z, C6, C5);
-    q = DM_FMA(z, q, C4);
-    q = DM_FMA(z, q, C3);
-    q = DM_FMA(z, q, C2);
-    q = DM_FMA(z, q, C1);
+    double q = DM_FMAK(z, C6, C5);
+    q = DM_FMAK(z, q, C4);
+    q = DM_FMAK(z, q, C3);
+    q = DM_FMAK(z, q, C2);
+    q = DM_FMAK(z, q, C1);
     double hz = 0.5 * z;
     double w = 1.0 - hz;
     double t = z * q;
@@ -209,55 +244,55 @@ DM_FN double dm_negate_if(double d, int cond) {
     return dm_from_bits(dm_to_bits(d) ^ ((unsigned long long)(cond != 0) << 63));
 }
 
-DM_TFN void dm_sincos(double x, double* s_out, double* c_out) {
+DM_TFN void dm_sincos(double x, double* s_out, double* c_out DM_PKARG) {
 #if defined(__HIP_DEVICE_COMPILE__)
     /* |x| < 0.785 < pi/4 on every lane: x * (2/pi) < 0.49975, so nd = (v + MAGIC) - MAGIC = 0, r = fma(-0, P, x)
      * = x (also for x = +-0), quadrant 0, and the quadrant selection / sign flips below are the identity */
     if ((VK & DM_SMALL) || (!(VK & DM_NOSHORT) && DM_WAVE_ALL(__builtin_fabs(x) < 0.785))) {
-        DM_T(dm_ksincos)(x, s_out, c_out);
+        DM_T(dm_ksincos)(x, s_out, c_out DM_PK);
         return;
     }
 #endif
     int q;
-    double r = DM_T(dm_trig_reduce)(x, &q);
+    double r = DM_T(dm_trig_reduce)(x, &q DM_PK);
     double s, c;
-    DM_T(dm_ksincos)(r, &s, &c);
+    DM_T(dm_ksincos)(r, &s, &c DM_PK);
     double ss = (q & 1) ? c : s;
     double cc = (q & 1) ? s : c;
     *s_out = dm_negate_if(ss, q & 2);
     *c_out = dm_negate_if(cc, (q + 1) & 2);
 }
 
-DM_TFN double dm_sin(double x) {
+DM_TFN double dm_sin(double x DM_PKARG) {
     double s, c;
-    DM_T(dm_sincos)(x, &s, &c);
+    DM_T(dm_sincos)(x, &s, &c DM_PK);
     return s;
 }
 
-DM_TFN double dm_cos(double x) {
+DM_TFN double dm_cos(double x DM_PKARG) {
     double s, c;
-    DM_T(dm_sincos)(x, &s, &c);
+    DM_T(dm_sincos)(x, &s, &c DM_PK);
     return c;
 }
 
-DM_TFN double dm_tan(double x) {
+DM_TFN double dm_tan(double x DM_PKARG) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if ((VK & DM_SMALL) || (!(VK & DM_NOSHORT) && DM_WAVE_ALL(__builtin_fabs(x) < 0.785))) { /* as in dm_sincos: r = x, quadrant 0, tan = sin / cos */
         double s0, c0;
-        DM_T(dm_ksincos)(x, &s0, &c0);
+        DM_T(dm_ksincos)(x, &s0, &c0 DM_PK);
         return s0 / c0;
     }
 #endif
     int q;
-    double r = DM_T(dm_trig_reduce)(x, &q);
+    double r = DM_T(dm_trig_reduce)(x, &q DM_PK);
     double s, c;
-    DM_T(dm_ksincos)(r, &s, &c);
+    DM_T(dm_ksincos)(r, &s, &c DM_PK);
     double num = (q & 1) ? c : s;
     double den = (q & 1) ? s : c;
     return dm_negate_if(num, q & 1) / den;
 }
 
-DM_TFN double dm_atan(double x) {
+DM_TFN double dm_atan(double x DM_PKARG) {
     const double aT0 = 3.33333333333329318027e-01;
     const double aT1 = -1.99999999998764832476e-01;
     const double aT2 = 1.42857142725034663711e-01;
