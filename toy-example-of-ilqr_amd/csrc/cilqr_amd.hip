@@ -65,7 +65,7 @@ enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST
     do {                                                              \
         if (PROF && a.prof) {                                         \
             long long t_now_ = (long long)__builtin_readcyclecounter(); \
-            ph_acc[ph] += t_now_ - t_ph_;                             \
+            if (lane == 0) ph_acc[ph] += t_now_ - t_ph_;              \
             t_ph_ = t_now_;                                           \
         }                                                             \
     } while (0)
@@ -200,7 +200,13 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         wave_sync();
     }
 
-    long long ph_acc[CILQR_PROF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the cycle accounting lives in LDS (written by lane 0 only): as a register array it would cost the profiling
+    // build 34 vector registers and push spill reloads into the backward loop
+    long long* const ph_acc = l.prof;
+    if (PROF && a.prof) {
+        for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) ph_acc[e] = 0;
+        wave_sync();
+    }
     const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
     const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
@@ -270,7 +276,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     rollout_trials(c, l, all ? scr : first, lane, all ? CILQR_MAX_ALPHA_TRIALS : 1, all ? CILQR_MAX_ALPHA_TRIALS : 1);
                     have_all = all;
                     PROF_ADD(PH_ROLLOUT);
-                    if (PROF && a.prof) ph_acc[t0 == 1 ? PH_ROLL_SECOND : (all ? PH_ROLL_ALL : PH_ROLL_FIRST)] += 1;
+                    if (PROF && a.prof && lane == 0) ph_acc[t0 == 1 ? PH_ROLL_SECOND : (all ? PH_ROLL_ALL : PH_ROLL_FIRST)] += 1;
                     if (HELP) {
                         if (t0 == 0 && lane == 0) {
                             l.ctli[CTL_MODE] = all ? 1 : 2;

@@ -145,6 +145,7 @@ struct Lds {
     int* tidx;   // [slots][(N+2)] the same for the trial trajectories being costed
     int* ctli;   // [8]  control words shared by the main and the helper wavefront of a block
     double* ctld; // [CILQR_CTLD]
+    long long* prof; // [CILQR_PROF_SLOTS] in-kernel cycle accounting (profiling builds)
     int w0;      // first lane sample held in win (the row-0 index: scans only move forward from it)
     int W;
 };
@@ -168,7 +169,7 @@ __host__ __device__ inline int kd_doubles(int N, int slots) {
     return g > c ? g : c;
 }
 __host__ __device__ inline int lds_doubles(int N, int alm, int slots) {
-    return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES;
+    return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES + CILQR_PROF_SLOTS;
 }
 __host__ __device__ inline size_t lds_bytes(int N, int W, int alm, int slots) {
     return sizeof(double) * ((size_t)lds_doubles(N, alm, slots) + 2 * (size_t)W) + sizeof(int) * (size_t)(((1 + slots) * (N + 2) + 8 + 1) & ~1);
@@ -188,6 +189,7 @@ __device__ inline void carve(Lds& l, double* base, int N, int W, int alm, int sl
     l.cs = l.kd;
     l.ctld = p; p += CILQR_CTLD;
     l.ck = reinterpret_cast<CstK*>(p); p += CILQR_CSTK_DOUBLES;
+    l.prof = reinterpret_cast<long long*>(p); p += CILQR_PROF_SLOTS;
     // the index arrays next (an even number of ints), the lane window — the only part whose size is not a function
     // of the horizon — last: with a compile-time horizon every other offset is a constant
     const int n_int = ((1 + slots) * (N + 2) + 8 + 1) & ~1;
@@ -770,7 +772,8 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
                 }
             }
             proven[tt] = (__ballot(!ok) == 0ULL);
-            if (sub && __ballot(sampled) != 0ULL) sub[3] += 1;
+            const bool any_sampled = (__ballot(sampled) != 0ULL);
+            if (sub && lane == 0 && any_sampled) sub[3] += 1;
         }
     }
     // level 2: the serial chain of cs:289-314
@@ -789,7 +792,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
         }
     }
     wave_sync();
-    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[0] += t1 - t0; t0 = t1; }
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) sub[0] += t1 - t0; t0 = t1; }
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) {
         if (tt >= nt) continue;
@@ -808,10 +811,10 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
         }
     }
     wave_sync();
-    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[1] += t1 - t0; t0 = t1; }
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) sub[1] += t1 - t0; t0 = t1; }
     sum_stage_costs_multi<NTR>(l, N, lane, J, slot0);
     wave_sync();
-    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); sub[2] += t1 - t0; }
+    if (sub) { long long t1 = (long long)__builtin_readcyclecounter(); if (lane == 0) sub[2] += t1 - t0; }
 }
 
 // single-trial form (piecewise kernel)

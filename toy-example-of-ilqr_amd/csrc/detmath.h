@@ -71,22 +71,31 @@ static __device__ inline void dm_pin_load(DmPinned& k) {
 #define DM_PK , pk
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DM_K(name, x) ((VK & DM_PIN) ? pk->name : (x))
-/* fma(a, b, k) with a pinned coefficient k as the addend: the compiler would pick the two-address form
- * (v_fmac_f64, accumulating into the addend's register) and first copy the coefficient — one extra vector
- * instruction per Horner step.  The three-operand instruction reads the coefficient in place.  Same operation. */
+/* fma(a, b, k) with a polynomial coefficient k as the addend.  Left to the compiler this becomes the two-address
+ * v_fmac_f64, which accumulates into the addend's register: a pinned coefficient is first copied (one extra vector
+ * instruction per Horner step), a literal one is first built in vector registers (two extra).  The three-operand
+ * v_fma_f64 reads the coefficient in place — from its vector register (pinned flavour) or from a scalar register
+ * pair, which the scalar unit fills without costing a vector issue slot.  Same operation, same bits. */
+static __device__ inline double dm_fma_vk(double a, double b, double k) {
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
+    return r;
+}
+static __device__ inline double dm_fma_sk(double a, double b, double k) {
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
 template <int VK>
 static __device__ inline double dm_fmak(double a, double b, double k) {
-    if (VK & DM_PIN) {
-        double r;
-        __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(k));
-        return r;
-    }
-    return __builtin_fma(a, b, k);
+    return (VK & DM_PIN) ? dm_fma_vk(a, b, k) : dm_fma_sk(a, b, k);
 }
 #define DM_FMAK(a, b, k) dm_fmak<VK>((a), (b), (k))
+#define DM_FMAC(a, b, k) dm_fma_sk((a), (b), (k)) /* literal coefficient */
 #else
 #define DM_K(name, x) (x)
 #define DM_FMAK(a, b, k) DM_FMA((a), (b), (k))
+#define DM_FMAC(a, b, k) DM_FMA((a), (b), (k))
 #endif
 #else
 #define DM_TFN DM_FN
@@ -95,6 +104,7 @@ static __device__ inline double dm_fmak(double a, double b, double k) {
 #define DM_PK
 #define DM_K(name, x) (x)
 #define DM_FMAK(a, b, k) DM_FMA((a), (b), (k))
+#define DM_FMAC(a, b, k) DM_FMA((a), (b), (k))
 #endif
 
 /* Wave-uniform shortcuts (device only).  A shortcut is taken when EVERY active lane qualifies, and it
@@ -171,16 +181,16 @@ DM_FN double dm_exp(double x) {
     r = DM_FMA(-kd, LN2LO, r);
     /* exp(r), |r| <= 0.3466: Taylor to r^13 (remainder < 5e-18 relative) */
     double p = 1.6059043836821613e-10;            /* 1/13! */
-    p = DM_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
-    p = DM_FMA(p, r, 2.505210838544172e-08);      /* 1/11! */
-    p = DM_FMA(p, r, 2.755731922398589e-07);      /* 1/10! */
-    p = DM_FMA(p, r, 2.7557319223985893e-06);     /* 1/9!  */
-    p = DM_FMA(p, r, 2.48015873015873e-05);       /* 1/8!  */
-    p = DM_FMA(p, r, 1.984126984126984e-04);      /* 1/7!  */
-    p = DM_FMA(p, r, 1.388888888888889e-03);      /* 1/6!  */
-    p = DM_FMA(p, r, 8.333333333333333e-03);      /* 1/5!  */
-    p = DM_FMA(p, r, 4.1666666666666664e-02);     /* 1/4!  */
-    p = DM_FMA(p, r, 1.6666666666666666e-01);     /* 1/3!  */
+    p = DM_FMAC(p, r, 2.08767569878681e-09);       /* 1/12! */
+    p = DM_FMAC(p, r, 2.505210838544172e-08);      /* 1/11! */
+    p = DM_FMAC(p, r, 2.755731922398589e-07);      /* 1/10! */
+    p = DM_FMAC(p, r, 2.7557319223985893e-06);     /* 1/9!  */
+    p = DM_FMAC(p, r, 2.48015873015873e-05);       /* 1/8!  */
+    p = DM_FMAC(p, r, 1.984126984126984e-04);      /* 1/7!  */
+    p = DM_FMAC(p, r, 1.388888888888889e-03);      /* 1/6!  */
+    p = DM_FMAC(p, r, 8.333333333333333e-03);      /* 1/5!  */
+    p = DM_FMAC(p, r, 4.1666666666666664e-02);     /* 1/4!  */
+    p = DM_FMAC(p, r, 1.6666666666666666e-01);     /* 1/3!  */
     p = DM_FMA(p, r, 0.5);
     p = DM_FMA(p, r, 1.0);
     p = DM_FMA(p, r, 1.0);
@@ -340,16 +350,16 @@ DM_TFN double dm_atan(double x DM_PKARG) {
     }
     double z = t * t;
     double w = z * z;
-    double s1 = DM_FMA(w, aT10, aT8);
-    s1 = DM_FMA(w, s1, aT6);
-    s1 = DM_FMA(w, s1, aT4);
-    s1 = DM_FMA(w, s1, aT2);
-    s1 = DM_FMA(w, s1, aT0);
+    double s1 = DM_FMAC(w, aT10, aT8);
+    s1 = DM_FMAC(w, s1, aT6);
+    s1 = DM_FMAC(w, s1, aT4);
+    s1 = DM_FMAC(w, s1, aT2);
+    s1 = DM_FMAC(w, s1, aT0);
     s1 = z * s1;
-    double s2 = DM_FMA(w, aT9, aT7);
-    s2 = DM_FMA(w, s2, aT5);
-    s2 = DM_FMA(w, s2, aT3);
-    s2 = DM_FMA(w, s2, aT1);
+    double s2 = DM_FMAC(w, aT9, aT7);
+    s2 = DM_FMAC(w, s2, aT5);
+    s2 = DM_FMAC(w, s2, aT3);
+    s2 = DM_FMAC(w, s2, aT1);
     s2 = w * s2;
     double corr = t * (s1 + s2);
     double res = (id < 0) ? (t - corr) : (hi - ((corr - lo) - t));
