@@ -8,7 +8,8 @@ import os
 import pathlib
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libcilqr_amd.so"
+# CILQR_AMD_LIB: another build of the same library (A/B measurements of kernel changes on one GPU box)
+LIB_PATH = pathlib.Path(os.environ["CILQR_AMD_LIB"]) if os.environ.get("CILQR_AMD_LIB") else PKG_DIR / "libcilqr_amd.so"
 
 OK = 0
 ERR_BAD_ARG = -1

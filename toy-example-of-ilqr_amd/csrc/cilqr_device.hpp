@@ -956,12 +956,16 @@ __device__ inline void roll_fetch(RollIn& g, const Lds& l, int i) {
     g.u[0] = l.u[2 * i];
     g.u[1] = l.u[2 * i + 1];
 }
-typedef char __attribute__((address_space(1))) gchar_w;     // HBM, writable (global_store, not flat_store)
-typedef double __attribute__((address_space(1))) gdouble_w;
-struct RollOut {      // where the lanes store: wave-uniform row pointers (scalar registers) + this lane's byte offset
-    gchar_w* tx;      // row i + 1 of component 0
-    gchar_w* tu;      // row i of component 4
-    size_t csb, rowb; // component / row stride in bytes
+typedef double __attribute__((address_space(1))) gdouble_w;  // HBM, writable (global_store, not flat_store)
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+// Where the rollout lanes store: a buffer descriptor of the destination (four scalar registers), wave-uniform byte
+// offsets of the current rows (scalar registers, advanced by the scalar unit) and this lane's byte offset — one
+// buffer_store per value, no address arithmetic in vector registers.
+struct RollOut {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int ox;           // byte offset of row i + 1 of component 0
+    int ou;           // byte offset of row i of component 4
+    int csb, rowb;    // component / row stride in bytes
     unsigned lane_off;
 };
 template <int RP, bool SMALL>
@@ -979,17 +983,18 @@ __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn&
     } else {
         propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn, &pk);
     }
-#define CILQR_SLAB_ST(base, comp, val) (*reinterpret_cast<gdouble_w*>((base) + (comp) * o.csb + o.lane_off) = (val))
-    CILQR_SLAB_ST(o.tu, 0, un[0]);
-    CILQR_SLAB_ST(o.tu, 1, un[1]);
-    CILQR_SLAB_ST(o.tx, 0, xn[0]);
-    CILQR_SLAB_ST(o.tx, 1, xn[1]);
-    CILQR_SLAB_ST(o.tx, 2, xn[2]);
-    CILQR_SLAB_ST(o.tx, 3, xn[3]);
+#define CILQR_SLAB_ST(base, comp, val) \
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (val)), o.rsrc, o.lane_off, (base) + (comp) * o.csb, 0)
+    CILQR_SLAB_ST(o.ou, 0, un[0]);
+    CILQR_SLAB_ST(o.ou, 1, un[1]);
+    CILQR_SLAB_ST(o.ox, 0, xn[0]);
+    CILQR_SLAB_ST(o.ox, 1, xn[1]);
+    CILQR_SLAB_ST(o.ox, 2, xn[2]);
+    CILQR_SLAB_ST(o.ox, 3, xn[3]);
 #undef CILQR_SLAB_ST
     xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-    o.tx += o.rowb;
-    o.tu += o.rowb;
+    o.ox += o.rowb;
+    o.ou += o.rowb;
     return true;
 }
 
@@ -1009,20 +1014,20 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
     const int R = N + 1;
     const int as = uniform_int(as_in);
     gdouble_w* scr = uniform_ptr(scr_in);
+    double* scr_in_uniform = (double*)(size_t)scr; // the same address as a generic pointer, for the descriptor
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
         gdouble_w* t = scr + lane;
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         TRS(t, 0, 0, as) = xc[0]; TRS(t, 1, 0, as) = xc[1]; TRS(t, 2, 0, as) = xc[2]; TRS(t, 3, 0, as) = xc[3];
-        const size_t CS = (size_t)R * (size_t)as; // component stride
-        // stores go through a wave-uniform row pointer plus this lane's byte offset (scalar base + 32-bit
-        // vector offset addressing: no per-store 64-bit address arithmetic in vector registers)
+        const int CS = R * as; // component stride (doubles)
         RollOut o;
-        o.tx = reinterpret_cast<gchar_w*>(scr + as);       // row 1 of component 0
-        o.tu = reinterpret_cast<gchar_w*>(scr + 4 * CS);   // row 0 of component 4
+        o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)scr_in_uniform, 0, (int)(CILQR_TRIAL_ROWS * CS * sizeof(double)), 0x00020000);
+        o.ox = as * (int)sizeof(double);        // row 1 of component 0
+        o.ou = 4 * CS * (int)sizeof(double);    // row 0 of component 4
         o.lane_off = 8u * (unsigned)lane;
-        o.csb = CS * sizeof(double);
-        o.rowb = (size_t)as * sizeof(double);
+        o.csb = CS * (int)sizeof(double);
+        o.rowb = as * (int)sizeof(double);
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
         // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
@@ -1557,13 +1562,15 @@ __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
 }
 
 // ---- cross-lane moves of a double (two 32-bit halves) -------------------------------------------
+// (every lane of the wave is active where this is used and every lane has a valid source lane, so no lane keeps
+// its old value: the move without an `old` operand writes a fresh register and needs no copy of v first)
 template <int CTRL>
 __device__ inline double dpp_move(double v) {
     const unsigned long long u = dm_to_bits(v);
-    int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+    const int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+    const int lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return dm_from_bits(((unsigned long long)(unsigned)hi2 << 32) | (unsigned long long)(unsigned)lo2);
 }
 // the same move, taken only by the lanes of the banks in BANKS (bank = (lane % 16) / 4); the others keep v
 template <int CTRL, int BANKS>
