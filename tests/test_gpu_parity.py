@@ -566,8 +566,9 @@ def test_full_size_configs_bitexact(pkg, orc_det):
     alm4 = pkg.workloads.config4(B=1100)  # two rows per lane, ALM, lone wavefronts two per SIMD (helper switched off below)
     alm4 = pkg.workloads.Workload("config4_alm_B1100_nohelper", [pkg.copy_params(q, solve_type=1) for q in alm4.params],
                                   alm4.scenes, alm4.x0, alm4.scenario_id, alm4.param_id, alm4.tick)
-    mid = pkg.workloads.config3(B=2048)  # between the helper range and the one-trial-per-pass range: paired passes
-    mid.name = "config3_bend_B2048_paired_passes"
+    mid = pkg.workloads.config3(B=2048)  # just above the helper range: lone wavefronts, two per SIMD, horizon at run time
+    mid = pkg.workloads.Workload("config3_bend_B2048_N40", [pkg.copy_params(q, N=40) for q in mid.params], mid.scenes, mid.x0,
+                                 mid.scenario_id, mid.param_id, mid.tick)
     cases = cases + (alm4, mid)
     for wl in cases:
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)

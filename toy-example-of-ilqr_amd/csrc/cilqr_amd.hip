@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -689,8 +690,9 @@ struct cilqr_handle {
     // +45 % at 2048 with two rows per lane (N = 100), whose lone-wavefront kernel is the slower one
     int helper_max_batch = 1536;
     int helper_max_batch_two_rows = 2048;
-    int occ2_min_batch = 1024; // above this the 2-waves-per-SIMD build of the solve kernel is used
-    int single_trial_min_batch = 2560; // above this trials are costed one per pass (see k_solve's NTP)
+    int occ2_min_batch = 1024; // above this (and above the helper range) the 2-waves-per-SIMD build of the solve kernel
+                               // is used; it costs line-search trials one per pass (paired passes were measured again
+                               // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
     int prof_B = 0;
     DevBuf st[16];
 };
@@ -752,6 +754,25 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
     HIP_TRY(hipSetDevice(device));
     cilqr_handle* h = new cilqr_handle();
     h->device = device;
+    // tuning experiments only (A/B runs on one box): CILQR_TUNE="helper_max_batch=1536,single_trial_min_batch=2560,..."
+    if (const char* t = std::getenv("CILQR_TUNE")) {
+        std::string sv(t);
+        size_t pos = 0;
+        while (pos < sv.size()) {
+            size_t e = sv.find(',', pos);
+            if (e == std::string::npos) e = sv.size();
+            const std::string kv = sv.substr(pos, e - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) {
+                const std::string k = kv.substr(0, eq);
+                const int v = std::atoi(kv.c_str() + eq + 1);
+                if (k == "helper_max_batch") h->helper_max_batch = v;
+                else if (k == "helper_max_batch_two_rows") h->helper_max_batch_two_rows = v;
+                else if (k == "occ2_min_batch") h->occ2_min_batch = v;
+            }
+            pos = e + 1;
+        }
+    }
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
@@ -1086,12 +1107,11 @@ static bool wants_helper(const cilqr_handle* h, int B) {
 // does the solve-kernel variant for this batch cost one trial per pass without a helper (one stage-cost slot)?
 // Mirrors the dispatch in cilqr_solve_batch_device, which checks the two against each other.
 static bool single_slot(const cilqr_handle* h, int B) {
-    const bool alm = h->params[0].solve_type == 1, two = h->params[0].N + 1 > CILQR_WAVE;
+    const bool alm = h->params[0].solve_type == 1;
     if (wants_helper(h, B)) return false;
     if (alm) return B > h->occ2_min_batch;
     if (h->debug_flags != 0 || h->profiling) return false;
-    if (B > h->single_trial_min_batch) return true;
-    return B > h->occ2_min_batch && two;
+    return B > h->occ2_min_batch;
 }
 
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
@@ -1219,15 +1239,11 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
             if (a.N == 50) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 50>;
             if (a.N == 100) kern = k_solve<false, 2, false, true, false, 1, CILQR_NT, 100>;
-        } else if (B > h->single_trial_min_batch) {
+        } else if (B > h->occ2_min_batch) {
             kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
             if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
             if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100>;
             one = true;
-        } else if (B > h->occ2_min_batch) {
-            // two rows per lane: paired trials spill too much
-            if (two) { kern = k_solve<false, 2, false, false, false, 2, 1>; one = true; }
-            else kern = k_solve<false, 1, false, false, false, 2>;
         } else {
             kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         }
