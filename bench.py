@@ -12,9 +12,12 @@ Workload (BASELINE.json `configs`):
     horizon 50, the largest single-GPU configuration (north_star: ">= 10k trajectories x 50-step horizon on
     1 x MI355X").  Config 2 (1024 straight-lane trajectories, one launch = a latency measurement: its wall
     time is the slowest trajectory's) is timed in the same run and reported under `extra.config2_latency`.
-  * N > 1 (default): config 4 — 65 536 mixed scenarios, horizon 100, sharded 8 x 8192: every rank solves
-    its own 8192-trajectory block (weak scaling when N < 8: 8192 per GPU), no data-path collective; RCCL
-    only reduces the statistics afterwards.  Config 2's weak scaling (1024 per GPU) is under `extra`.
+  * N > 1 (default): the SAME workload per GPU as at N = 1 — every rank solves its own 4096 x 16 sweep (base
+    starts first = rank * 4096 of one global batch), so that value(N) / value(1) is a weak-scaling efficiency
+    whoever computes it; no data-path collective, RCCL only reduces the statistics afterwards.  BASELINE
+    configs[3] — 65 536 mixed scenarios, horizon 100, sharded 8 x 8192 (8192 per rank) — is timed in the same
+    run and reported under `extra.config4_sharded`, config 2's weak scaling (1024 per GPU) under
+    `extra.config2_weak_scaling`.
   * --config 1: the reference's own case (scenario_two_straight, single ego, horizon 50) as a 10 Hz closed
     loop through the drop-in CILQRSolver.solve(), B = 1: per-tick latency next to the oracle on one core.
   * --config 2|3|4|5 selects any of them explicitly.
@@ -44,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
-                    help="BASELINE.json configuration (0 = default: 5 on one GPU, 4 on several)")
+                    help="BASELINE.json configuration (0 = default: 5 per GPU, with 2 (and 4 on several GPUs) as extras)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the configuration's own)")
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -377,7 +380,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    cfg_id = args.config or (5 if world == 1 else 4)
+    cfg_id = args.config or 5
     wl, B = make_workload(pkg, cfg_id, args.batch, args.horizon, rank)
     N = wl.N
     run = GpuRun(pkg, torch, wl, B, local_rank)
@@ -391,24 +394,31 @@ def main():
     pipelined = run.pipelined(args.steps, args.streams) if (world == 1 and args.streams > 1) else None
     run.close()
 
-    # the other workload of the default command: config 2 (1024 trajectories per GPU), a latency measurement
-    second = None
+    # the other workloads of the default command: config 2 (1024 trajectories per GPU), a latency measurement, and —
+    # on several GPUs — BASELINE configs[3] (8192 trajectories of horizon 100 per rank)
+    def side_run(cfg, steps_side, note):
+        wl_s, B_s = make_workload(pkg, cfg, 0, 0, rank)
+        run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
+        el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier)
+        st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, dev if dist is not None else None)
+        run_s.close()
+        if rank != 0:
+            return None
+        rl = roofline_block(pkg, wl_s, res_s, kms_s, world)
+        return {"workload": wl_s.name, "baseline_config": cfg, "batch_per_gpu": B_s, "global_batch": int(st_s[8]),
+                "horizon": wl_s.N, "steps": steps_side, "value": st_s[0] * steps_side / tmax_s, "unit": "iLQR iterations/s",
+                "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": kms_s,
+                "iterations_per_launch_rank0": float(res_s["iters"].sum()),
+                "slowest_trajectory_iterations": int(res_s["iters"].max()),
+                "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "note": note}
+
+    second = fourth = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
-        wl2, B2 = make_workload(pkg, 2, 0, 0, rank)
-        run2 = GpuRun(pkg, torch, wl2, B2, local_rank)
-        steps2 = max(args.steps, 20)
-        el2, kms2, res2 = run2.timed(steps2, min(args.warmup, 3), barrier)
-        st2, tmax2 = st_mod.reduce_stats(st_mod.local_stats(res2, wl2.N, wl2.M_of), el2, dist, dev if dist is not None else None)
-        run2.close()
-        if rank == 0:
-            rl2 = roofline_block(pkg, wl2, res2, kms2, world)
-            second = {"workload": wl2.name, "baseline_config": 2, "batch_per_gpu": B2, "steps": steps2,
-                      "value": st2[0] * steps2 / tmax2, "unit": "iLQR iterations/s", "ms_per_step": tmax2 / steps2 * 1e3,
-                      "kernel_ms": kms2, "iterations_per_launch_rank0": float(res2["iters"].sum()),
-                      "slowest_trajectory_iterations": int(res2["iters"].max()),
-                      "hbm_frac": rl2["frac"], "traffic": rl2["traffic"], "valu_issue": rl2["valu_issue"],
-                      "note": "one launch of 1024 trajectories occupies a quarter of the chip's wave slots; its wall "
-                              "time is the slowest trajectory's (DESIGN.md)"}
+        second = side_run(2, max(args.steps, 20), "one launch of 1024 trajectories occupies a quarter of the chip's wave "
+                          "slots; its wall time is the slowest trajectory's (DESIGN.md)")
+        if world > 1 or os.environ.get("CILQR_FORCE_DIST") == "1":
+            fourth = side_run(4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
+                              "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs)")
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
@@ -428,7 +438,8 @@ def main():
                       "timed_region_s": tmax,
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
-                      ("config2_latency" if world == 1 else "config2_weak_scaling"): second},
+                      ("config2_latency" if world == 1 else "config2_weak_scaling"): second,
+                      "config4_sharded": fourth},
         }
         if cfg_id == 5:
             # convergence-vs-throughput view of the sweep: per barrier setting, over its 4096 solves

@@ -49,7 +49,8 @@ for c in 2 3 5; do
 done
 
 # 6. the RCCL branch of bench.py on one rank (init_process_group("nccl") + the two all-reduces + barrier)
-CILQR_FORCE_DIST=1 $BENCH --config 4 --steps 2 --warmup 1 $ONLY > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
+# (the default multi-GPU command: config 5 per rank as the headline, configs[3] and config 2 as extras)
+CILQR_FORCE_DIST=1 $BENCH --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_force_dist.json" 2> "$OUT/bench_force_dist.err"
 
 # 7. BASELINE configs[0]: single ego, closed loop through the drop-in solve()
 $BENCH --config 1 > "$OUT/bench_config1.json" 2> "$OUT/bench_config1.err"

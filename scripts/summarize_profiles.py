@@ -131,7 +131,7 @@ for c in (2, 3, 5):
 b = last_json(os.path.join(src, "bench_force_dist.json"))
 if b:
     err = open(os.path.join(src, "bench_force_dist.err"), errors="replace").read().splitlines()[-15:]
-    json.dump({"command": "CILQR_FORCE_DIST=1 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
+    json.dump({"command": "CILQR_FORCE_DIST=1 python bench.py --steps 4 --warmup 1 --no-cpu-baseline",
                "what": "bench.py's multi-GPU branch on one rank: init_process_group('nccl') = RCCL, dist.barrier(), the SUM "
                        "and MAX all-reduces of the statistics, destroy_process_group",
                "bench_line": b, "stderr_tail": err}, open(os.path.join(dst, f"{tag}_force_dist.json"), "w"), indent=1)

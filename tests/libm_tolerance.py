@@ -168,6 +168,9 @@ def analyse(wl, hip_out, threads=8, rows=None):
     bad = ~(gap <= TOL)
     well = spread <= TOL
     recs = [dg.one(int(b), gap[b], spread[b]) for b in np.nonzero(bad)[0]]
+    hr, rr = hip_out["res"], ref["res"]
+    same_path = ((hr["iters"] == rr["iters"]) & (hr["ls_trials"] == rr["ls_trials"]) & (hr["end_reason"] == rr["end_reason"])
+                 & (hr["cost_evals"] == rr["cost_evals"]) & (hr["final_status"] == rr["final_status"]))
     ratio = gap[bad] / np.maximum(spread[bad], 1e-300)
     return {
         "workload": wl.name, "trajectories": int(wl.B), "tolerance": TOL,
@@ -182,6 +185,9 @@ def analyse(wl, hip_out, threads=8, rows=None):
         "max_gap": float(gap[np.isfinite(gap)].max()), "max_spread": float(spread[np.isfinite(spread)].max()),
         "gap_percentiles_50_90_99": [float(v) for v in np.percentile(gap, [50, 90, 99])],
         "spread_percentiles_50_90_99": [float(v) for v in np.percentile(spread, [50, 90, 99])],
+        "same_decision_counters (iterations, trials, cost evaluations, end reason, final status)": int(same_path.sum()),
+        "different_decision_counters": int((~same_path).sum()),
+        "different_decision_counters_inside_1e-5": int((~same_path & ~bad).sum()),
         "outside_with_identical_decision_traces": int(sum(r["identical_decision_traces"] for r in recs)),
         "outside_first_split_by_cost_drift": int(sum(r["split_kind"] == "cost" for r in recs)),
         "outside_first_split_by_flipped_decision": int(sum(r["split_kind"] in ("decision", "length") for r in recs)),

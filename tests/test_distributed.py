@@ -73,6 +73,11 @@ def test_shards_partition_the_batch(pkg):
     b = pkg.workloads.config4(B=40, N=100)
     np.testing.assert_array_equal(a.x0, b.x0[20:30])
     np.testing.assert_array_equal(a.scenario_id, b.scenario_id[20:30])
+    # bench.py's default multi-GPU workload: rank r takes base starts r * B_base ... of the global sweep
+    g5 = pkg.workloads.config5(B_base=16, N=30)
+    r1 = pkg.workloads.config5(B_base=8, N=30, first=8)
+    np.testing.assert_array_equal(r1.x0, g5.x0[128:256])
+    np.testing.assert_array_equal(r1.param_id, g5.param_id[128:256])
     c5 = pkg.workloads.config5(B_base=3, N=30)
     assert c5.B == 48 and len(c5.params) == 16 and c5.param_id[:17].tolist() == list(range(16)) + [0]
     assert pkg.workloads.bytes_per_iteration(50, 3) == 8536 and pkg.workloads.bytes_per_iteration(100, 8) == 29056
