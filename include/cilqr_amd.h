@@ -161,6 +161,14 @@ int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
                              double* d_x_out, cilqr_result* d_res_out, cilqr_trace_rec* d_trace_out,
                              int32_t trace_cap, void* stream);
 
+/* The step after the path for a whole batch, on the device (src/motion_planning.cpp:181,197): ego_state =
+ * new_x.row(1) and the obstacle window one tick on: d_x0[b] = d_x[b][1], d_tick[b] += 1 (d_tick may be NULL).
+ * Together with cilqr_solve_batch_device — whose d_last_u may be the d_u_out buffer of the previous tick, also
+ * when it is this tick's d_u_out: a block reads its rows before it writes them — a closed planning loop over
+ * thousands of egos runs without a host round trip per tick. */
+int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const double* d_x, double* d_x0, int32_t* d_tick,
+                               void* stream);
+
 /* Wall time of the most recent solve kernel measured with HIP events on its own stream (ms). */
 int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
 /* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */

@@ -885,6 +885,70 @@ print("DEVICE-IDS-OK")
 """
 
 
+_DEVICE_LOOP_SCRIPT = r"""
+import sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+dev = torch.device("cuda", 0)
+cfg = pkg.GlobalConfig.get_instance("three_straight")
+sc = pkg.build_scenario(cfg, "three_straight")
+p = pkg.params_from_config(cfg, N=30)
+assert p.use_last_solution == 1
+B, ticks = 48, 25
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 424242)
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+N = p.N
+d_x0 = torch.from_numpy(x0).to(dev)
+d_tick = torch.zeros(B, dtype=torch.int32, device=dev)
+d_u = torch.zeros((B, N, 2), dtype=torch.float64, device=dev)
+d_x = torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev)
+d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+hist = []
+for t in range(ticks):  # no host round trip inside: solve -> advance -> solve ...
+    eng.solve_batch_device(B, d_x0.data_ptr(), 0, 0, d_tick.data_ptr(), d_u.data_ptr() if t else 0, d_u.data_ptr(), d_x.data_ptr(),
+                           d_res.data_ptr(), 0, 0, st)
+    hist.append((d_u.clone(), d_x.clone(), d_res.clone()))   # device-side copies, stream-ordered
+    eng.advance_batch_device(B, d_x.data_ptr(), d_x0.data_ptr(), d_tick.data_ptr(), st)
+torch.cuda.synchronize(dev)
+assert d_tick.cpu().numpy().tolist() == [ticks] * B
+orc = Oracle("det")
+solvers = [orc.solver(p) for _ in range(B)]
+for s_ in solvers:
+    s_.reset()
+xs = x0.copy()
+iters = 0
+for t in range(ticks):
+    scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t)
+    U, X = hist[t][0].cpu().numpy(), hist[t][1].cpu().numpy()
+    res = np.frombuffer(hist[t][2].cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+    for b in range(B):
+        r = solvers[b].solve(xs[b], scene)
+        assert np.array_equal(U[b], r["u"]) and np.array_equal(X[b], r["x"]), (t, b)
+        assert res["iters"][b] == r["res"]["iters"] and res["J_final"][b] == r["res"]["J_final"], (t, b)
+        xs[b] = r["x"][1]
+    iters += int(res["iters"].sum())
+assert iters > ticks * B
+print("DEVICE-LOOP-OK", iters)
+"""
+
+
+def test_closed_loop_resident_on_the_device():
+    """48 egos x 25 ticks of the reference's planning loop (mp:180-197) without a host round trip per tick:
+    cilqr_solve_batch_device (warm-started from its own previous u buffer) + cilqr_advance_batch_device; every tick
+    of every ego equals its own stateful oracle solver."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DEVICE_LOOP_SCRIPT, root], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DEVICE-LOOP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_device_pointer_entry_checks_its_ids_on_the_device():
     """cilqr_solve_batch_device cannot validate scenario_id / param_id / tick on the host: trajectories with an id
     outside the tables, a negative tick or an obstacle route that ends before tick + N + 1 (upstream:

@@ -584,6 +584,16 @@ __global__ void k_prepare_tables(const double* __restrict__ yaw_in, double* __re
     }
 }
 
+// the step after the path, for a batch (mp:181,197): ego_state = new_x.row(1); the obstacle window moves one tick on
+__global__ void k_advance(int B, int N, const double* __restrict__ x, double* __restrict__ x0, int32_t* __restrict__ tick) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const double* r = x + ((size_t)i * (N + 1) + 1) * 4;
+    double* o = x0 + (size_t)i * 4;
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+    if (tick) tick[i] += 1;
+}
+
 __global__ void k_detmath(int f, const double* __restrict__ x, const double* __restrict__ y,
                           double* __restrict__ o, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1258,6 +1268,18 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed_pending = true;
     }
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const double* d_x, double* d_x0, int32_t* d_tick,
+                                          void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (B < 1 || !d_x || !d_x0) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_advance, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), B, h->params[0].N, d_x,
+                       d_x0, d_tick);
+    HIP_TRY(hipGetLastError());
     return CILQR_OK;
 }
 

@@ -143,6 +143,11 @@ class BatchedCILQR:
                                                  d_trace or None, int(trace_cap), stream or None),
               "cilqr_solve_batch_device")
 
+    def advance_batch_device(self, B, d_x, d_x0, d_tick=0, stream=0):
+        """ego_state = x.row(1) and tick += 1 for every trajectory, on the device (raw pointers as ints)"""
+        check(self._lib.cilqr_advance_batch_device(self._h, int(B), d_x, d_x0, d_tick or None, stream or None),
+              "cilqr_advance_batch_device")
+
     def set_timing(self, on=True):
         check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
 
