@@ -116,6 +116,8 @@ class Oracle:
             "orc_reset": (None, [V]),
             "orc_solve": (C.c_int, [V, V, C.POINTER(OrcScene), V, V, V, V, I]),
             "orc_set_margin_buffer": (None, [V, V, I]),
+            "orc_set_alm_state": (None, [V, V, D, I]),
+            "orc_get_alm_next": (None, [V, V]),
             "orc_solve_batch": (C.c_int, [C.POINTER(OrcParams), I, C.POINTER(OrcScene), I, I, V, V, V, V, I, V, V, V]),
             "orc_kinematic_propagate": (None, [V, V, D, D, I, V]),
             "orc_model_derivatives": (None, [V, V, D, D, I, I, V, V]),
@@ -294,6 +296,15 @@ class OracleSolver:
         out = {"u": u, "x": x, "res": res[0], "trace": trace[:res[0]["trace_len"]]}
         if margins:
             out["margins"] = mg[:res[0]["trace_len"]]
+        return out
+
+    def set_alm_state(self, mu, rho):
+        mu = _f64(mu)
+        self.o.lib.orc_set_alm_state(self.h, _p(mu), float(rho), int(mu.shape[1]))
+
+    def get_alm_next(self, cols):
+        out = np.empty((self.N, cols))
+        self.o.lib.orc_get_alm_next(self.h, _p(out))
         return out
 
     def total_cost(self, u, x, scene, tick=None):
