@@ -1678,9 +1678,17 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double Quu0 = lane_bcast<36>(Q), Quu1 = lane_bcast<37>(Q);
         const double Quu2 = lane_bcast<44>(Q), Quu3 = lane_bcast<45>(Q);
         const double Qu0 = lane_bcast<36>(Zv), Qu1 = lane_bcast<44>(Zv);
-        const double S = (cc == 4) ? Zv : Q;               // rows 4-5: (Q_ux | Q_u)
+        // (the lane predicates are recomputed from a vector register each step: one compare instead of the two
+        //  v_readlane a spilled scalar mask costs)
+        int ccv = cc;
+        __asm__("" : "+v"(ccv));
+        const double S = (ccv == 4) ? Zv : Q;               // rows 4-5: (Q_ux | Q_u)
         const double c0 = lane_gather(S, src_c0), c1 = lane_gather(S, src_c1);
         const double r0 = lane_gather(S, src_r0), r1 = lane_gather(S, src_r1);
+        // Matrix2d::inverse() (cs:421) is started before the verdict on Q_uu is in: its division is the longest
+        // dependent chain of the step and the verdict's arithmetic fills its bubbles; a failed verdict discards it
+        const double det = Quu0 * Quu3 - Quu2 * Quu1;
+        const double invdet = 1.0 / det;
         // Eigen::LLT's verdict: Quu0 > 0 and the second pivot Quu3 - (Quu2 / sqrt(Quu0))^2 > 0.  The pivot as
         // computed is Quu3 - (Quu2^2 / Quu0)(1 + e), |e| < 2^-50 (one sqrt, one quotient, one square, and the
         // final subtraction keeps the sign).  So when Quu0 and Quu3 are positive and of ordinary size
@@ -1707,8 +1715,6 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             if (fail_step) *fail_step = i; // steps i .. 0 of l.kd still hold Jacobians, not gains
             return false;
         }
-        const double det = Quu0 * Quu3 - Quu2 * Quu1;
-        const double invdet = 1.0 / det;
         const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
         const double d0 = n00 * Qu0 + n01 * Qu1;
         const double d1 = n10 * Qu0 + n11 * Qu1;
@@ -1719,9 +1725,11 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         const double ta = p0 * kc0 + p1 * kc1;
         const double tb = kr0 * c0 + kr1 * c1;
         const double tc = r0 * kc0 + r1 * kc1;
-        const double own = (cc < 4) ? Q : Zv;
+        const double own = (ccv < 4) ? Q : Zv;
         wn = ((own + ta) + tb) + tc;
-        if (lane < 5) { // row r' = 0 holds (K | d) column c
+        int lanev = lane;
+        __asm__("" : "+v"(lanev));
+        if (lanev < 5) { // row r' = 0 holds (K | d) column c
             // over the Jacobians of this step: every lane loaded its coefficients at the top of the step
             double* kd = l.kd + CILQR_KD * i + lane;
             kd[0] = kc0;
