@@ -362,18 +362,27 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the CILQR solve path has no CPU fallback")
+    # Rehearsal switches (no multi-GPU node has been available): CILQR_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and
+    # CILQR_BENCH_BACKEND=gloo reduces the statistics through host memory, so that the N > 1 code path of this file
+    # can run with two processes on a one-GPU box.  Never set by the driver; the numbers of such a run mean nothing.
+    if os.environ.get("CILQR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CILQR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("CILQR_FORCE_DIST") == "1":  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import cilqr_amd as pkg
     from importlib import import_module
     st_mod = import_module("toy-example-of-ilqr_amd.stats")
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if (dist is not None and backend == "nccl") else None  # where the statistics are reduced
 
     def barrier():
         if dist is not None:
@@ -385,7 +394,7 @@ def main():
     N = wl.N
     run = GpuRun(pkg, torch, wl, B, local_rank)
     elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier)
-    stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, dev if dist is not None else None)
+    stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, red_dev)
     value = stats[0] * args.steps / tmax
     gpu_u = gpu_x = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -400,7 +409,7 @@ def main():
         wl_s, B_s = make_workload(pkg, cfg, 0, 0, rank)
         run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
         el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier)
-        st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, dev if dist is not None else None)
+        st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, red_dev)
         run_s.close()
         if rank != 0:
             return None
