@@ -700,6 +700,9 @@ struct cilqr_handle {
     // +45 % at 2048 with two rows per lane (N = 100), whose lone-wavefront kernel is the slower one
     int helper_max_batch = 1536;
     int helper_max_batch_two_rows = 2048;
+    int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
+                              // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
+                              // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
     int occ2_min_batch = 1024; // above this (and above the helper range) the 2-waves-per-SIMD build of the solve kernel
                                // is used; it costs line-search trials one per pass (paired passes were measured again
                                // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
@@ -739,10 +742,10 @@ static void update_window(cilqr_handle* h) {
     // batches that fill the chip several times over: occupancy (two wavefronts per SIMD hide each other's
     // latencies) is worth more than the far end of the window, which only the last rows at full speed reach;
     // their kernels cost one trial at a time (one stage-cost slot)
-    const int occ_floor = std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8);
+    const int occ_floor = std::min(floor_ok, std::max(64, ((int)(base * (h->occ_floor_pct / 100.0) + 16) + 7) / 8 * 8));
     h->win_occ2 = pick(occ_floor);
     fixed = lds_bytes(N, 0, alm, 1);
-    h->win_occ = pick(std::min(floor_ok, ((int)(base * 0.75 + 16) + 7) / 8 * 8));
+    h->win_occ = pick(occ_floor);
 }
 
 static int check_ready(cilqr_handle* h) {
@@ -779,6 +782,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 if (k == "helper_max_batch") h->helper_max_batch = v;
                 else if (k == "helper_max_batch_two_rows") h->helper_max_batch_two_rows = v;
                 else if (k == "occ2_min_batch") h->occ2_min_batch = v;
+                else if (k == "occ_floor_pct") h->occ_floor_pct = v;
             }
             pos = e + 1;
         }
