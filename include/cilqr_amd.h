@@ -182,8 +182,8 @@ int cilqr_set_alm_state(cilqr_handle* h, int32_t B, const double* mu, const doub
 int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next, double* rho, int32_t* cols);
 
 /* Helper wavefronts: -1 (default) = automatic — a second wavefront per trajectory costs every other
- * line-search trial when the batch is small enough for that to pay (<= 1536 trajectories, <= 2048 for horizons
- * above 63): up to 1024 one wavefront each would leave SIMD slots empty, a little beyond that the quicker
+ * line-search trial when the batch is small enough for that to pay (<= 1536 trajectories; for horizons above 63
+ * <= 1536 + 80 (N - 60)): up to 1024 one wavefront each would leave SIMD slots empty, a little beyond that the quicker
  * stragglers still outweigh the second round of blocks; 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
 

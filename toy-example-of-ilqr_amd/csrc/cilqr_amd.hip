@@ -699,7 +699,8 @@ struct cilqr_handle {
     // dominate: measured +20 % at 1536 straight-lane trajectories, +3 % / -13 % at 2048 (straight / bend), and
     // +45 % at 2048 with two rows per lane (N = 100), whose lone-wavefront kernel is the slower one
     int helper_max_batch = 1536;
-    int helper_max_batch_two_rows = 2048;
+    int helper_max_batch_two_rows = -1; // horizons above 63 (two rows per lane): -1 = 1536 + 80 (N - 60), measured in
+                                        // round 2: the crossover lies near 1800 at N = 64 and near 5000 at N = 100
     int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
                               // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
                               // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
@@ -1115,7 +1116,9 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
 static bool wants_helper(const cilqr_handle* h, int B) {
     const bool two = !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE;
     return (h->helper_mode == 1) ||
-           (h->helper_mode < 0 && B <= (two ? h->helper_max_batch_two_rows : h->helper_max_batch));
+           (h->helper_mode < 0 &&
+            B <= (two ? (h->helper_max_batch_two_rows >= 0 ? h->helper_max_batch_two_rows : 1536 + 80 * (h->params[0].N - 60))
+                      : h->helper_max_batch));
 }
 
 // does the solve-kernel variant for this batch cost one trial per pass without a helper (one stage-cost slot)?
