@@ -569,7 +569,15 @@ def test_full_size_configs_bitexact(pkg, orc_det):
     mid = pkg.workloads.config3(B=2048)  # just above the helper range: lone wavefronts, two per SIMD, horizon at run time
     mid = pkg.workloads.Workload("config3_bend_B2048_N40", [pkg.copy_params(q, N=40) for q in mid.params], mid.scenes, mid.x0,
                                  mid.scenario_id, mid.param_id, mid.tick)
-    cases = cases + (alm4, mid)
+    # horizons above 63 in batches beyond the helper range: the builds that stream the cost expansion from global memory
+    # (horizon at run time; the compile-time N = 100 build runs in test_config4_every_rank_shard_and_stats), both models
+    long_b = pkg.workloads.config3(B=3400)
+    long_b = pkg.workloads.Workload("config3_bend_B3400_N80", [pkg.copy_params(q, N=80) for q in long_b.params], long_b.scenes,
+                                    long_b.x0, long_b.scenario_id, long_b.param_id, long_b.tick)
+    long_s = pkg.workloads.config2(B=2600)
+    long_s = pkg.workloads.Workload("config2_straight_B2600_N71", [pkg.copy_params(q, N=71) for q in long_s.params], long_s.scenes,
+                                    long_s.x0, long_s.scenario_id, long_s.param_id, long_s.tick)
+    cases = cases + (alm4, mid, long_b, long_s)
     for wl in cases:
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)
         if wl.name.endswith("_nohelper"):

@@ -115,7 +115,9 @@ enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 // holds two wavefronts anyway (+1.5 % at B >= 3072)
 // NC = horizon known at compile time (0: taken from the parameter table): every LDS offset but the lane window's
 // and every row count become constants — fewer live scalar registers, addresses folded into instruction offsets
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0>
+// LG = the cost expansion (l_x, l_u, l_xx, l_uu) lives in global memory instead of LDS (CILQR_GL_ROW): large batches
+// of long horizons, where the LDS block of a trajectory would cap the CU at 5 wavefronts
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -141,11 +143,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     }
     Lds l;
     constexpr int SLOTS = (HELP || NTP == 2) ? 2 : 1; // trials costed concurrently (the host sizes the LDS block alike)
-    carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS);
+    carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS, LG ? 1 : 0);
     Cst c;
     load_cst(c, a, b, l, lane);
     if (NC) c.N = NC;
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    if (LG) l.gl = scr + scratch_gl_offset(N);
     double* first = scr + slab_doubles(N); // the first-trial buffer
     AlmSt al = load_alm(a, b, N);
     if (HELP && wave == 1) {
@@ -240,14 +243,14 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
         // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
         if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
-            cost_and_model_derivatives<ALM>(c, l, al, lane);
+            cost_and_model_derivatives<ALM, LG>(c, l, al, lane);
         } else {
             model_jacobians(c, l, lane); // the gains of the failed pass sit where A, B were
         }
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
-        bool ok = backward_sweep<(DBG && !ALM)>(c, l, lamb, lane, dV, a.flags);
+        bool ok = backward_sweep<(DBG && !ALM), LG>(c, l, lamb, lane, dV, a.flags);
         wave_sync();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
@@ -704,6 +707,9 @@ struct cilqr_handle {
     int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
                               // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
                               // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
+    int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
+                               // two-wavefronts-per-SIMD range (barrier mode), 0 = never, 1 = wherever a build exists
+    int win_lg = 0;            // lane window of those builds
     int occ2_min_batch = 1024; // above this (and above the helper range) the 2-waves-per-SIMD build of the solve kernel
                                // is used; it costs line-search trials one per pass (paired passes were measured again
                                // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
@@ -747,6 +753,8 @@ static void update_window(cilqr_handle* h) {
     h->win_occ2 = pick(occ_floor);
     fixed = lds_bytes(N, 0, alm, 1);
     h->win_occ = pick(occ_floor);
+    fixed = lds_bytes(N, 0, alm, 1, 1);
+    h->win_lg = pick(occ_floor);
 }
 
 static int check_ready(cilqr_handle* h) {
@@ -784,6 +792,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "helper_max_batch_two_rows") h->helper_max_batch_two_rows = v;
                 else if (k == "occ2_min_batch") h->occ2_min_batch = v;
                 else if (k == "occ_floor_pct") h->occ_floor_pct = v;
+                else if (k == "global_expansion") h->global_expansion = v;
             }
             pos = e + 1;
         }
@@ -1131,6 +1140,16 @@ static bool single_slot(const cilqr_handle* h, int B) {
     return B > h->occ2_min_batch;
 }
 
+// does this batch run a build that keeps the cost expansion in global memory (k_solve's LG)?
+static bool global_expansion(const cilqr_handle* h, int B) {
+    if (!single_slot(h, B) || h->params[0].solve_type == 1 || h->global_expansion == 0) return false;
+    const int N = h->params[0].N;
+    if (N + 1 <= CILQR_WAVE) return false; // (builds exist for two rows per lane only; shorter horizons fit anyway)
+    // worth it where the LDS block with the expansion inside keeps a CU from holding the 8 wavefronts its registers
+    // allow (N >= 76): measured +30-40 % at N = 100, +6 % at N = 80, -5 % at N = 64 where nothing is gained
+    return h->global_expansion == 1 || lds_bytes(N, 64, 0, 1, 0) * 8 > 163840;
+}
+
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     BatchArgs a;
     a.params = static_cast<const cilqr_params*>(h->d_params.p);
@@ -1149,7 +1168,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
     const bool occ2 = B > h->occ2_min_batch && (a.alm || a.flags == 0) && !h->profiling && !wants_helper(h, B);
-    a.W = occ2 ? (single_slot(h, B) ? h->win_occ : h->win_occ2) : h->win;
+    a.W = occ2 ? (single_slot(h, B) ? (global_expansion(h, B) ? h->win_lg : h->win_occ) : h->win_occ2) : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
     a.alm_rho = static_cast<double*>(h->alm_rho.p);
@@ -1242,7 +1261,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool help = wants_helper(h, B);
         // `one` = the variant costs one trial per pass without a helper: one stage-cost slot in LDS (k_solve's SLOTS)
         auto kern = k_solve<false, 1, false, false, false>;
-        bool one = false;
+        bool one = false, lg = false;
         if (a.alm) {
             if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
             else if (B > h->occ2_min_batch) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; }
@@ -1260,13 +1279,18 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
             if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
             if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100>;
+            if (global_expansion(h, B)) {
+                kern = k_solve<false, 2, false, false, false, 2, 1, 0, true>;
+                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true>;
+                lg = true;
+            }
             one = true;
         } else {
             kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         }
         const bool helped = help && (a.alm || a.flags == 0);
         if (one != single_slot(h, B)) return fail(CILQR_ERR_DEVICE, "internal: kernel variant / LDS layout mismatch");
-        const size_t shm = lds_bytes(a.N, a.W, a.alm, one ? 1 : 2);
+        const size_t shm = lds_bytes(a.N, a.W, a.alm, one ? 1 : 2, lg ? 1 : 0);
         hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }

@@ -48,6 +48,7 @@ __device__ inline void wave_sync() {
 // pointers into HBM are typed as address space 1 so that every access is a global_load (a generic
 // pointer would compile to flat_load, which also ties up the LDS counter)
 typedef const double __attribute__((address_space(1))) gdouble;
+typedef double __attribute__((address_space(1))) gdouble_w;  // HBM, writable (global_store, not flat_store)
 #define CILQR_OBS_STRIDE 5  /* device obstacle record: x, y, yaw, sin(yaw), cos(yaw) */
 #define CILQR_AUX_STRIDE 4  /* device lane record: yaw, sin(yaw), cos(yaw), unused */
 
@@ -133,6 +134,8 @@ struct Lds {
     double* lxx; // [(N+1)][lxs]: 7 packed entries (barrier mode: symmetric) or 16 dense (ALM mode)
     int lxs;
     double* luu; // [N][2]
+    double* gl;  // derivative rows in global memory instead of lx / lu / lxx / luu (see CILQR_GL_ROW), or nullptr
+    double* ring; // [CILQR_GL_RING] rows of l.gl staged for the backward sweep, eight at a time (lg builds)
     CstK* ck;    // the cost model's constants (see Cst)
     double* xch; // [CILQR_XCH] constant block of the lane-parallel backward sweep (see backward_sweep_lanes)
     double* cs;  // [slots][3][(N+1)] stage-cost scratch: state, ctrl, barrier (slots = trials costed concurrently).
@@ -168,23 +171,48 @@ __host__ __device__ inline int kd_doubles(int N, int slots) {
     const int g = CILQR_KD * N, c = slots * 3 * (N + 1); // gains / stage-cost scratch share the array
     return g > c ? g : c;
 }
-__host__ __device__ inline int lds_doubles(int N, int alm, int slots) {
-    return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES + CILQR_PROF_SLOTS;
+// The cost expansion in global memory ("lg" builds: long horizons in large batches, barrier mode).  The expansion is
+// 15 (N + 1) doubles — 12 KB of the 25.5 KB a horizon of 100 needs in LDS, which caps a CU at 5 trajectories.  It is
+// written once per iteration by the lane = row phase and read by the backward sweep strictly in order, one row per
+// step: exactly what a prefetched stream out of L2 serves.  One 128-byte row per step:
+//   0-3 l_x | 4-5 l_u | 6-11 l_xx packed (00 01 03 11 13 33) | 12-13 l_uu diagonal | 14 l_xx (22) | 15 zero
+// (slot 15 is what the lanes of the structurally zero entries of l read, in range and uniform with the others)
+#define CILQR_GL_ROW 16
+#define CILQR_GL_LX 0
+#define CILQR_GL_LU 4
+#define CILQR_GL_LXX 6
+#define CILQR_GL_LUU 12
+#define CILQR_GL_LXX22 14
+#define CILQR_GL_ZERO 15
+// The sweep reads them through a ring of 8 rows in LDS that is refilled four rows (= 64 doubles, one per lane) at a
+// time: the global load of a chunk is issued four steps before its rows are needed and costs two instructions.
+#define CILQR_GL_CHUNK 4
+#define CILQR_GL_RING (2 * CILQR_GL_CHUNK * CILQR_GL_ROW)
+__host__ __device__ inline int lds_doubles(int N, int alm, int slots, int lg = 0) {
+    const int expansion = lg ? CILQR_GL_RING : 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N;
+    return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + expansion + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES + CILQR_PROF_SLOTS;
 }
-__host__ __device__ inline size_t lds_bytes(int N, int W, int alm, int slots) {
-    return sizeof(double) * ((size_t)lds_doubles(N, alm, slots) + 2 * (size_t)W) + sizeof(int) * (size_t)(((1 + slots) * (N + 2) + 8 + 1) & ~1);
+__host__ __device__ inline size_t lds_bytes(int N, int W, int alm, int slots, int lg = 0) {
+    return sizeof(double) * ((size_t)lds_doubles(N, alm, slots, lg) + 2 * (size_t)W) + sizeof(int) * (size_t)(((1 + slots) * (N + 2) + 8 + 1) & ~1);
 }
 
-__device__ inline void carve(Lds& l, double* base, int N, int W, int alm, int slots) {
+__device__ inline void carve(Lds& l, double* base, int N, int W, int alm, int slots, int lg = 0) {
     double* p = base;
     l.x = p; p += 4 * (N + 1);
     l.u = p; p += 2 * N;
     l.kd = p; p += kd_doubles(N, slots);
-    l.lx = p; p += 4 * (N + 1);
-    l.lu = p; p += 2 * N;
     l.lxs = alm ? 16 : 7;
-    l.lxx = p; p += l.lxs * (N + 1);
-    l.luu = p; p += 2 * N;
+    l.gl = nullptr;
+    l.ring = nullptr;
+    if (lg) {
+        l.lx = l.lu = l.lxx = l.luu = nullptr; // the expansion lives in l.gl (set by the kernel)
+        l.ring = p; p += CILQR_GL_RING;
+    } else {
+        l.lx = p; p += 4 * (N + 1);
+        l.lu = p; p += 2 * N;
+        l.lxx = p; p += l.lxs * (N + 1);
+        l.luu = p; p += 2 * N;
+    }
     l.xch = p; p += CILQR_XCH;
     l.cs = l.kd;
     l.ctld = p; p += CILQR_CTLD;
@@ -237,8 +265,12 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
 __host__ __device__ inline size_t slab_doubles(int N) {
     return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
 }
+__host__ __device__ inline size_t scratch_gl_offset(int N) { // rows of the cost expansion ("lg" builds), 128-byte aligned
+    const size_t head = slab_doubles(N) + (size_t)(CILQR_TRIAL_ROWS + 3) * (size_t)(N + 1); // + first-trial buffer + parked gains
+    return (head + 15) / 16 * 16;
+}
 __host__ __device__ inline size_t scratch_doubles(int N) {
-    return slab_doubles(N) + (size_t)(CILQR_TRIAL_ROWS + 3) * (size_t)(N + 1); // first-trial buffer + parked gains
+    return scratch_gl_offset(N) + (size_t)CILQR_GL_ROW * (size_t)(N + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -956,7 +988,6 @@ __device__ inline void roll_fetch(RollIn& g, const Lds& l, int i) {
     g.u[0] = l.u[2 * i];
     g.u[1] = l.u[2 * i + 1];
 }
-typedef double __attribute__((address_space(1))) gdouble_w;  // HBM, writable (global_store, not flat_store)
 typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
 // Where the rollout lanes store: a buffer descriptor of the destination (four scalar registers), wave-uniform byte
 // offsets of the current rows (scalar registers, advanced by the scalar unit) and this lane's byte offset — one
@@ -1178,9 +1209,12 @@ __device__ inline void model_jacobians(const Cst& c, const Lds& l, int lane) {
 // ALM = false: exponential barriers, l_xx packed (symmetric).  ALM = true: augmented Lagrangian
 // terms (cs:581-643, 665-680), l_xx dense (b_dot c_dot^T is not bitwise symmetric), and the
 // multiplier proposal alm_mu_next is written.
-template <bool ALM>
+// LG = true (barrier mode only): the expansion goes to the 128-byte rows of l.gl in global memory (CILQR_GL_ROW)
+template <bool ALM, bool LG = false>
 __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
+    static_assert(!(ALM && LG), "the global-memory expansion is built for barrier mode");
     const int N = c.N;
+    gdouble_w* const grows = LG ? (gdouble_w*)l.gl : nullptr;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
         int ridx = l.ridx[k];
@@ -1271,10 +1305,18 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             double luub0 = (q22 * b_au) + (q22 * b_al);
             double luub1 = (q22 * b_su) + (q22 * b_sl);
             // l_u = 2 (u R) + barrier, l_uu = 2 R + barrier (cs:491-492, 686-687)
-            l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + lub0;
-            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + lub1;
-            l.luu[2 * (k - 1)] = 2 * c.k->w_acc + luub0;
-            l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + luub1;
+            if (LG) {
+                gdouble_w* rm = grows + (size_t)CILQR_GL_ROW * (k - 1);
+                rm[CILQR_GL_LU] = 2 * (um0 * c.k->w_acc) + lub0;
+                rm[CILQR_GL_LU + 1] = 2 * (um1 * c.k->w_stl) + lub1;
+                rm[CILQR_GL_LUU] = 2 * c.k->w_acc + luub0;
+                rm[CILQR_GL_LUU + 1] = 2 * c.k->w_stl + luub1;
+            } else {
+                l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + lub0;
+                l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + lub1;
+                l.luu[2 * (k - 1)] = 2 * c.k->w_acc + luub0;
+                l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + luub1;
+            }
             // velocity bounds and road borders (cs:507-533, 560-580)
             double b_vu = c.k->sq1 * dm_exp(c.k->sq2 * (xk[2] - c.k->velo_max));
             CILQR_SCHED_FENCE();
@@ -1321,6 +1363,23 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
                 h13 = h13 + (sf * (t.gf[1] * t.gf[2]) + srr * (t.gr[1] * t.gr[2]));
                 h33 = h33 + (sf * (t.gf[2] * t.gf[2]) + srr * (t.gr[2] * t.gr[2]));
             }
+        }
+        if (LG) {
+            gdouble_w* r = grows + (size_t)CILQR_GL_ROW * k;
+            r[CILQR_GL_LX] = lx0 + b0;
+            r[CILQR_GL_LX + 1] = lx1 + b1;
+            r[CILQR_GL_LX + 2] = lx2 + b2;
+            r[CILQR_GL_LX + 3] = lx3 + b3;
+            r[CILQR_GL_LXX] = 2 * c.k->w_pos + h00;
+            r[CILQR_GL_LXX + 1] = 0.0 + h01;
+            r[CILQR_GL_LXX + 2] = 0.0 + h03;
+            r[CILQR_GL_LXX + 3] = 2 * c.k->w_pos + h11;
+            r[CILQR_GL_LXX + 4] = 0.0 + h13;
+            r[CILQR_GL_LXX + 5] = 2 * c.k->w_yaw + h33;
+            r[CILQR_GL_LXX22] = 2 * c.k->w_vel + h22;
+            r[CILQR_GL_ZERO] = 0.0;
+            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
+            continue;
         }
         l.lx[4 * k] = lx0 + b0;
         l.lx[4 * k + 1] = lx1 + b1;
@@ -1531,6 +1590,26 @@ __device__ inline void lane_map_M(const Lds& l, int k, int j, int& off, int& str
     if (j == 5 && k == 3) { off = B3 + 2; stride = CILQR_KD; }
 }
 
+// the same for an expansion held in the rows of l.gl: slots (doubles) inside the 128-byte row of a step
+__device__ inline void lane_map_gl(int lane, int& slot_q, int& slot_v) {
+    const int rp = (lane >> 3) % 6, cc = lane & 7;
+    slot_q = CILQR_GL_ZERO;
+    if (rp < 4 && cc < 4) {
+        const int a = (rp < cc) ? rp : cc, b = (rp < cc) ? cc : rp;
+        if (a == 0 && b == 0) slot_q = CILQR_GL_LXX + 0;
+        if (a == 0 && b == 1) slot_q = CILQR_GL_LXX + 1;
+        if (a == 0 && b == 3) slot_q = CILQR_GL_LXX + 2;
+        if (a == 1 && b == 1) slot_q = CILQR_GL_LXX + 3;
+        if (a == 1 && b == 3) slot_q = CILQR_GL_LXX + 4;
+        if (a == 3 && b == 3) slot_q = CILQR_GL_LXX + 5;
+        if (a == 2 && b == 2) slot_q = CILQR_GL_LXX22;
+    } else if (rp >= 4 && cc == rp) {
+        slot_q = CILQR_GL_LUU + (rp - 4);
+    }
+    slot_v = (rp < 4) ? CILQR_GL_LX + rp : CILQR_GL_LU + (rp - 4);
+}
+
+template <bool LG = false>
 __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
     const bool dense_lxx = (l.lxs == 16);
     const int rp = (lane >> 3) % 6, cc = lane & 7;      // lanes >= 48 alias rows 0/1 (results unused)
@@ -1540,9 +1619,11 @@ __device__ inline void make_lane_map(const Lds& l, int lane, LaneMap& m) {
         lane_map_M(l, k, rp, m.m1[k], m.s1[k]);
         lane_map_M(l, k, ccm, m.m2[k], m.s2[k]);
     }
+    m.lq = CC; m.slq = 0;
+    m.lv = CC; m.slv = 0;
+    if (LG) return; // the expansion is not in LDS (lane_map_gl)
     // L[r'][c'']: l_xx (7 packed entries 00 01 03 11 13 33 22), l_uu diagonal, zero elsewhere
     const int LXX = (int)(l.lxx - l.x), LUU = (int)(l.luu - l.x);
-    m.lq = CC; m.slq = 0;
     if (rp < 4 && cc < 4) {
         int a = (rp < cc) ? rp : cc, b = (rp < cc) ? cc : rp, e = -1;
         if (a == 0 && b == 0) e = 0;
@@ -1611,13 +1692,31 @@ __device__ inline double lane_bcast(double v) {
 // The operands that pass 2 and the rank-2 update need live in other lanes' registers; they are moved
 // with DPP (inside the 8-lane row of the grid), ds_bpermute (across rows) and v_readlane (the 2x2
 // Q_uu and Q_u, needed by every lane) — no LDS round trips inside a step.
+// LG: the cost expansion streams in from the rows of l.gl (global memory; this wave wrote them a phase ago) through
+// the LDS ring l.ring: rows 4 c .. 4 c + 3 ("chunk" c, 64 doubles, one per lane) are fetched while the four steps of
+// chunk c + 1 compute and dropped into the ring half c & 1 when the sweep gets there.  Row r sits at ring offset
+// (r & 7) rows, so the per-lane read addresses are the row-independent slot plus a wave-uniform offset.
+__device__ inline double gl_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int row_off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, row_off, 0));
+}
+template <bool LG = false>
 __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
                                             int* fail_step = nullptr) {
     const int N = c.N;
     const int rp = (lane >> 3) % 6, cc = lane & 7;
     const double* const base = l.x;
     LaneMap mp;
-    make_lane_map(l, lane, mp);
+    make_lane_map<LG>(l, lane, mp);
+    constexpr int ROWB = CILQR_GL_ROW * (int)sizeof(double);
+    __amdgpu_buffer_rsrc_t grs;
+    unsigned goq = 0, gov = 0;
+    if (LG) {
+        int sq, sv;
+        lane_map_gl(lane, sq, sv);
+        goq = 8u * (unsigned)sq;
+        gov = 8u * (unsigned)sv;
+        grs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(l.gl), 0, (N + 1) * ROWB, 0x00020000);
+    }
     if (lane == 0) {
         l.xch[CILQR_XCH_CONST + 0] = 0.0;
         l.xch[CILQR_XCH_CONST + 1] = 1.0;
@@ -1626,7 +1725,9 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     }
     wave_sync();
     // W = [l_xx[N] | l_x[N]], element (r, c) in the register `wn` of lane 8 r + c (r < 4, c <= 4)
-    double wn = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
+    double wn;
+    if (LG) wn = gl_load(grs, (cc < 4) ? goq : gov, N * ROWB);
+    else wn = (cc < 4) ? base[mp.lq + mp.slq * N] : base[mp.lv + mp.slv * N];
     dV[0] = 0.0;
     dV[1] = 0.0;
     const int wc = (cc <= 4) ? cc : 4;
@@ -1646,7 +1747,25 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     unsigned alq = lds_addr(base + mp.lq + mp.slq * (N - 1));
     unsigned alv = lds_addr(base + mp.lv + mp.slv * (N - 1));
     const unsigned dlq = 8u * (unsigned)mp.slq, dlv = 8u * (unsigned)mp.slv;
+    constexpr int CHB = CILQR_GL_CHUNK * ROWB; // bytes per chunk
+    double chunk = 0.0;                        // this lane's double of the chunk in flight
+    unsigned rq = 0, rv = 0;                   // this lane's two read addresses inside ring row 0
+    if (LG) {
+        const int c0 = (N - 1) / CILQR_GL_CHUNK;
+        // (rows past N - 1 of the first chunk are not used; reads past row N return zero: the descriptor ends there)
+        const double first = gl_load(grs, 8u * (unsigned)lane, c0 * CHB);
+        ((double*)l.ring)[(c0 & 1) * (CILQR_GL_CHUNK * CILQR_GL_ROW) + lane] = first;
+        if (c0 > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (c0 - 1) * CHB);
+        rq = lds_addr(l.ring) + goq;
+        rv = lds_addr(l.ring) + gov;
+    }
     for (int i = N - 1; i >= 0; --i) {
+        if (LG && (i & (CILQR_GL_CHUNK - 1)) == CILQR_GL_CHUNK - 1 && i != N - 1) {
+            // the sweep enters chunk c: its rows arrived while chunk c + 1 was computed; fetch chunk c - 1
+            const int cch = i / CILQR_GL_CHUNK;
+            ((double*)l.ring)[(cch & 1) * (CILQR_GL_CHUNK * CILQR_GL_ROW) + lane] = chunk;
+            if (cch > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (cch - 1) * CHB);
+        }
         // per-lane coefficients of this step (issued together with the cross-lane moves of pass 1, whose
         // latency they share; fetching them a step ahead was measured and is slower)
         double m1[4], m2[4];
@@ -1657,10 +1776,17 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             am1[k] -= dm1[k];
             am2[k] -= dm2[k];
         }
-        const double Lq = lds_load(alq);
-        const double lv = lds_load(alv);
-        alq -= dlq;
-        alv -= dlv;
+        double Lq, lv;
+        if (LG) {
+            const unsigned ro = (unsigned)(i & (2 * CILQR_GL_CHUNK - 1)) * (unsigned)ROWB; // wave-uniform
+            Lq = lds_load(rq + ro);
+            lv = lds_load(rv + ro);
+        } else {
+            Lq = lds_load(alq);
+            lv = lds_load(alv);
+            alq -= dlq;
+            alv -= dlv;
+        }
         // pass 1: column wc of W from the lanes 8 k + wc
         const double w0 = lane_gather(wn, wc), w1 = lane_gather(wn, 8 + wc);
         const double w2 = lane_gather(wn, 16 + wc), w3 = lane_gather(wn, 24 + wc);
@@ -1746,11 +1872,12 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     return true;
 }
 
-template <bool DBG>
+template <bool DBG, bool LG = false>
 __device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags,
                                       int* fail_step = nullptr) {
+    static_assert(!(DBG && LG), "the wave-uniform twin reads the expansion from LDS");
     if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV, fail_step);
-    return backward_sweep_lanes(c, l, lamb, lane, dV, fail_step);
+    return backward_sweep_lanes<LG>(c, l, lamb, lane, dV, fail_step);
 }
 
 
