@@ -182,10 +182,21 @@ int cilqr_set_alm_state(cilqr_handle* h, int32_t B, const double* mu, const doub
 int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next, double* rho, int32_t* cols);
 
 /* Helper wavefronts: -1 (default) = automatic — a second wavefront per trajectory costs every other
- * line-search trial when the batch is small enough for that to pay (<= 1536 trajectories; for horizons above 63
- * <= 1536 + 80 (N - 60)): up to 1024 one wavefront each would leave SIMD slots empty, a little beyond that the quicker
- * stragglers still outweigh the second round of blocks; 0 = never; 1 = always.  Results are identical in every mode. */
+ * line-search trial when the batch is small enough for that to pay (<= 1536 trajectories; <= 512 for horizons of 96
+ * and more in barrier mode, where work sharing between blocks does better): up to 1024 one wavefront each would leave
+ * SIMD slots empty, a little beyond that the quicker stragglers still outweigh the second round of blocks;
+ * 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
+
+/* Work sharing between blocks (horizons above 63, barrier mode, batches beyond the helper range): 1 (default) = blocks
+ * whose trajectory is done stay — once every block of the launch has started — and cost line-search trials of the
+ * trajectories still being solved; 0 = off.  A cost is a function of the trial trajectory alone, so the results
+ * are identical either way; what changes is how long a launch waits for its slowest trajectories. */
+int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode);
+/* Counters of the last launch that shared work (waits for the device): out = { line searches announced, trial costs
+ * delivered by other blocks, blocks that stayed to help, 1 if a claimed trial was not delivered in time — the owner
+ * then costs it itself and cilqr_solve_batch reports CILQR_ERR_DEVICE }. */
+int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]);
 
 /* Line-search rollouts (forward_pass for the step sizes of cs:354): -1 (default) = adaptive — an iteration rolls
  * out alpha = 1 alone and the other 19 step sizes only once that trial is rejected, unless the previous

@@ -702,6 +702,39 @@ def test_helper_wavefront_and_rollout_modes_are_transparent(pkg, orc_det, engine
         assert (base["trace"]["trials"] == 20).any() and (base["trace"]["trials"] == 1).any()
 
 
+def test_work_sharing_between_blocks_is_transparent(pkg, orc_det):
+    """Horizon 100 beyond the helper range: blocks that are done cost line-search trials of the ones still running.
+    With and without it: the same outputs, counters and decision traces, bit for bit, and equal to the oracle's on a
+    sample; the launch's own counters show that searches were announced and served, and no hand-over timed out."""
+    from oracle import Scene
+    wl = pkg.workloads.config4(B=640, N=100)
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    out = {}
+    for mode in (1, 0):
+        eng.set_work_sharing(mode)
+        out[mode] = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, trace_cap=104)
+        if mode == 1:
+            st = eng.work_sharing_stats()
+    eng.close()
+    assert st["error"] == 0, st
+    assert st["announced"] > 0 and st["helped"] > 0 and 0 < st["helpers"] <= 640, st
+    a, b = out[1], out[0]
+    eq_bits(a["u"], b["u"], "u")
+    eq_bits(a["x"], b["x"], "x")
+    assert (a["res"] == b["res"]).all()
+    for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+        eq_bits(a["trace"][f], b["trace"][f], "trace." + f)
+    sel = np.arange(0, wl.B, 8)
+    scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs if s.obs.shape[0] else None, s.road_borders, s.ref_velo)
+              for s in wl.scenes]
+    ref = orc_det.solve_batch(wl.params, scenes, wl.x0[sel], wl.scenario_id[sel], wl.param_id[sel], None, n_threads=16)
+    eq_bits(a["x"][sel], ref["x"], "sample x")
+    eq_bits(a["u"][sel], ref["u"], "sample u")
+    for f in ("iters", "ls_trials", "end_reason", "final_status"):
+        assert np.array_equal(a["res"][f][sel], ref["res"][f]), f
+    eq_bits(a["res"]["J_final"][sel], ref["res"]["J_final"], "sample J_final")
+
+
 def test_rollout_policy_statistics(pkg, engines):
     """the adaptive policy's bookkeeping (in-kernel counters): every line search starts with exactly one rollout
     pass, second passes happen only after a rejected first trial, and on the benchmark-like batch the slab is

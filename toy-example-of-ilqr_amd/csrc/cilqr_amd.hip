@@ -48,6 +48,13 @@ struct BatchArgs {
     double* alm_rho;
     int alm_C;
     int alm;                    // 1 when the handle's parameter sets use the ALM solve type
+    // work sharing between blocks (k_solve's SHARE; null = off): counters + slots, one request and one row of
+    // reference-index hints per trajectory
+    unsigned* sh_ctl;
+    ShareReq* sh_req;
+    int* sh_hints;              // [B][N + 2]
+    int sh_max_helpers;         // blocks that stay to help (the others leave when they are done)
+    int sh_min_t0;              // a search is announced once this many of its trials have been rejected
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -90,6 +97,67 @@ __device__ inline bool ids_valid(const BatchArgs& a, int b) {
     return !(s.M > 0 && (long long)tk + a.N + 1 > (long long)s.T);
 }
 
+// A block whose own trajectory is done costs open line-search trials of the blocks still running (see ShareReq)
+// until every trajectory of the launch has finished.  `me` only spreads the helpers over the open searches.
+// (not inlined: it runs once, after the solve, with nothing live — inlined, its copy of the trial costing costs the
+//  solve loop 27 more spilled vector registers)
+template <int NCH, int NC>
+__device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, int lane, int me) {
+    unsigned* const ctl = a.sh_ctl;
+    if (sh_add_u(ctl + SH_HELPERS, 1u, lane) >= (unsigned)a.sh_max_helpers) return; // enough of them already
+    int cur_b = -1, idx0h = 0, nfb = 0, idle = 0;
+    unsigned cur_seq = 0;
+    Cst c2;
+    AlmSt al2;
+    al2.mu = nullptr; al2.mu_next = nullptr; al2.rho = 1.0; al2.C = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) { // (bounded: a launch lasts milliseconds, this is seconds)
+        if (sh_ld_u(ctl + SH_FINISHED, lane) >= (unsigned)a.B) break;
+        const unsigned sv = sh_ld(ctl + SH_SLOT0 + lane); // the 64 slots, one per lane
+        unsigned long long open = __ballot(sv != 0u);
+        const int rot = (me * 7 + spin) & 63;
+        if (rot) open = (open >> rot) | (open << (64 - rot));
+        bool worked = false;
+        while (open && !worked) {
+            const int j = __builtin_ctzll(open);
+            open &= open - 1;
+            const int bb = (int)__shfl((int)sv, (j + rot) & 63, CILQR_WAVE) - 1;
+            if (bb < 0 || bb >= a.B) continue;
+            ShareReq* rq = a.sh_req + bb;
+            const unsigned v = sh_ld_u(&rq->claim, lane);
+            const unsigned lo = v & 0xffu, hi = (v >> 8) & 0xffu;
+            if (hi <= lo || hi > (unsigned)CILQR_MAX_ALPHA_TRIALS) continue;
+            if (sh_cas_u(&rq->claim, v, v - 0x100u, lane) != v) continue; // somebody else moved it: look again later
+            const int t = (int)hi - 1;
+            const unsigned seq = v >> 16;
+            if (bb != cur_b || seq != cur_seq) {
+                sh_acquire(); // the owner's slab, hints and row-0 index of this search
+                load_cst(c2, a, bb, l, lane);
+                if (NC) c2.N = NC;
+                wave_sync();
+                idx0h = rq->idx0;
+                stage_window(c2, l, idx0h, a.W, lane);
+                const int* hints = a.sh_hints + (size_t)bb * (N + 2);
+                for (int k = lane; k <= N; k += CILQR_WAVE) l.ridx[k] = hints[k];
+                wave_sync();
+                cur_b = bb;
+                cur_seq = seq;
+            }
+            double J1[1];
+            total_cost_trials<false, NCH, false, 1>(c2, l, al2, a.scratch + (size_t)bb * scratch_doubles(N), t, 1, lane, idx0h, 0,
+                                                    &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
+            if (lane == 0) sh_st64(&rq->J[t], dm_to_bits(J1[0]));
+            (void)sh_add_u(ctl + SH_HELPED, 1u, lane);
+            worked = true;
+        }
+        // nothing to do: look again after 1 us, backing off to 16 us
+        if (worked) idle = 0;
+        else {
+            idle = (idle < 4) ? idle + 1 : 4;
+            for (int r = 0; r < (1 << idle); ++r) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
 // CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
 // DBG = true compiles the testing-aid paths in (cilqr_set_debug_flags); the production
 // instantiation carries neither their code nor their registers.
@@ -117,7 +185,10 @@ enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 // and every row count become constants — fewer live scalar registers, addresses folded into instruction offsets
 // LG = the cost expansion (l_x, l_u, l_xx, l_uu) lives in global memory instead of LDS (CILQR_GL_ROW): large batches
 // of long horizons, where the LDS block of a trajectory would cap the CU at 5 wavefronts
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false>
+// SHARE = blocks that have finished help the ones still running with their line searches (ShareReq; lone wavefronts,
+// barrier mode, one trial per pass); switched on per launch by a.sh_ctl
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
+          bool SHARE = false>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -126,8 +197,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
     if (b >= a.B) return;
+    static_assert(!SHARE || (!HELP && !ALM && !PROF && !DBG && NTP == 1), "work sharing: lone wavefronts, barrier mode");
+    const bool share = SHARE && a.sh_ctl != nullptr;
+    if (share) (void)sh_add_u(a.sh_ctl + SH_STARTED, 1u, lane);
     const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
+        if (share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
         if (wave == 0) {
             const double qnan = dm_from_bits(0x7ff8000000000000ULL);
             for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = qnan;
@@ -237,7 +312,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     // iteration's search went beyond its first trial — failed searches come in runs.  One extra rollout pass on
     // ~2 % of the iterations buys slab writes on 13-30 % of them instead of all.
     bool deep_next = false;
+    ShareReq* const rq = share ? a.sh_req + b : nullptr;
+    unsigned sh_seq = 1; // the searches of this trajectory that were announced, counted (a closed request holds the next number)
     for (int itr = 0; itr < c.max_iter; ++itr) {
+        // are there idle blocks?  (asked here, needed after the backward sweep: the answer's latency is hidden)
+        unsigned sh_probe = 0;
+        if (share && lane == 0) sh_probe = sh_ld(a.sh_ctl + SH_HELPERS);
         // ---- iter_step ----
         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
         if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
@@ -267,6 +347,8 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             bool have_all = false; // the slab holds all 20 trial trajectories of this iteration
             bool done = false;
             int t0 = 0;
+            unsigned sh_st = 0;    // work sharing: state of this search's announcement (SH_ST_*), 0 = not announced
+            bool sh_local = false; // cost the trial here although a helper delivered it
             int par = 0; // helper mode: which pair of cost slots this pass uses
             // The line search of cs:354-372.  The costs are produced pass by pass — alpha = 1 alone (usually
             // accepted), then NTP trials per pass (two with a helper wavefront) — and consumed strictly in order.
@@ -298,7 +380,18 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 int nt = (t0 == 0) ? 1 : NTP;
                 if (HELP && have_all) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
                 if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
-                if (HELP || nt == 1) {
+                bool foreign = false; // the cost of trial t0 comes from another block
+                if (SHARE && share && have_all && t0 >= a.sh_min_t0 && !sh_local &&
+                    (sh_st != 0u || (CILQR_MAX_ALPHA_TRIALS - t0 >= CILQR_SH_MIN_OPEN &&
+                                     __builtin_amdgcn_readfirstlane((int)sh_probe) != 0))) {
+                    sh_st = sh_owner_step(a.sh_ctl, rq, a.sh_hints + (size_t)b * (N + 2), l.ridx, &l.ctld[CTLD_JM], b, N, t0,
+                                          idx0, sh_seq, sh_st, lane);
+                    foreign = (sh_st & SH_ST_FOREIGN) != 0u;
+                    if (foreign) Jp[0] = l.ctld[CTLD_JM];
+                }
+                if (SHARE && foreign) {
+                    // nothing to compute
+                } else if (HELP || nt == 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, src, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
                                                         (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0, as);
@@ -316,6 +409,12 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                                                                Jp, (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
                 }
                 PROF_ADD(PH_TRIAL_COST);
+                if (SHARE && foreign && trial_verdict(J_cur, Jp[0], t0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr) == 2) {
+                    // the accepted trial's lane indices are needed too: cost it here (the same bits) and accept then
+                    sh_local = true;
+                    continue;
+                }
+                sh_local = false;
                 for (int tt = 0; tt < nt && !done; ++tt) {
                     const int t = t0 + tt;
                     new_J = Jp[tt];
@@ -336,6 +435,10 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                     }
                 }
                 t0 += nt;
+            }
+            if (SHARE && sh_st != 0u) { // (before anything touches the slab again)
+                sh_owner_close(a.sh_ctl, rq, b, sh_seq, sh_st, lane);
+                sh_seq++;
             }
             deep_next = (trials > 1);
             if (!done) {
@@ -400,6 +503,11 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         r.final_status = status; r.ls_trials = ls_trials; r.cost_evals = cost_evals;
         r.trace_len = (trace_out && tl > trace_cap) ? trace_cap : tl;
         res_out[b] = r;
+    }
+    if (SHARE && share) {
+        (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
+        // stay only when every block of the grid is running or done: then no block waits for this one's place
+        if (sh_ld_u(a.sh_ctl + SH_STARTED, lane) >= (unsigned)a.B) share_help<NCH, NC>(a, l, N, lane, b);
     }
 }
 
@@ -702,11 +810,16 @@ struct cilqr_handle {
     // dominate: measured +20 % at 1536 straight-lane trajectories, +3 % / -13 % at 2048 (straight / bend), and
     // +45 % at 2048 with two rows per lane (N = 100), whose lone-wavefront kernel is the slower one
     int helper_max_batch = 1536;
-    int helper_max_batch_two_rows = -1; // horizons above 63 (two rows per lane): -1 = 1536 + 80 (N - 60), measured in
-                                        // round 2: the crossover lies near 1800 at N = 64 and near 5000 at N = 100
+    int helper_max_batch_two_rows = -1; // horizons above 63 (two rows per lane): -1 = by horizon and solve type, see
+                                        // wants_helper()
     int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
                               // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
                               // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
+    int share_max_helpers = 64, share_min_t0 = 1; // (measured: 64 helpers serve the few open searches of a launch's tail; 2048 polling blocks cost 9-16 %)
+    bool last_launch_shared = false;
+    int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
+    DevBuf sh_ctl, sh_req, sh_hints;
+    int sh_B = 0, sh_N = 0;
     int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
                                // two-wavefronts-per-SIMD range (barrier mode), 0 = never, 1 = wherever a build exists
     int win_lg = 0;            // lane window of those builds
@@ -793,6 +906,9 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "occ2_min_batch") h->occ2_min_batch = v;
                 else if (k == "occ_floor_pct") h->occ_floor_pct = v;
                 else if (k == "global_expansion") h->global_expansion = v;
+                else if (k == "share") h->share = v;
+                else if (k == "share_max_helpers") h->share_max_helpers = v;
+                else if (k == "share_min_t0") h->share_min_t0 = v;
             }
             pos = e + 1;
         }
@@ -822,6 +938,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     h->d_params.release();
     h->d_scenes.release();
     h->scratch.release();
+    h->sh_ctl.release(); h->sh_req.release(); h->sh_hints.release();
     h->alm_mu.release();
     h->alm_mu_next.release();
     h->alm_rho.release();
@@ -887,6 +1004,25 @@ extern "C" int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags) {
 extern "C" int cilqr_set_rollout_mode(cilqr_handle* h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0 or 1");
     h->rollout_mode = mode;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    if (mode != 0 && mode != 1) return fail(CILQR_ERR_BAD_ARG, "work sharing mode must be 0 or 1");
+    h->share = mode;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
+    if (!h || !out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!h->sh_ctl.p) return CILQR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned w[SH_SLOT0];
+    HIP_TRY(hipMemcpy(w, h->sh_ctl.p, sizeof(w), hipMemcpyDeviceToHost));
+    out[0] = w[SH_ANNOUNCED]; out[1] = w[SH_HELPED]; out[2] = w[SH_HELPERS]; out[3] = w[SH_ERROR];
     return CILQR_OK;
 }
 
@@ -1122,22 +1258,36 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
     return CILQR_OK;
 }
 
+// Which build of the solve kernel a batch gets.  Small batches: a helper wavefront per block.  Beyond that lone
+// wavefronts in the register build that lets two share a SIMD, one trial per pass.  Two rows per lane (horizons
+// above 63), barrier mode: those blocks help each other's line searches once they are done (k_solve's SHARE), which
+// beats the helper wavefront from 1536 trajectories on (N = 64 ... 80: 17.4 vs 20.0 ms at N = 72, B = 2048; below
+// that the helper wavefront is 10-20 % ahead) and from 512 on for N >= 96 (config 4's mix: 17.1 vs 28.2 ms at 1024,
+// 26.1 vs 50.0 at 2048; the two tie below).  The augmented-Lagrangian builds have no work sharing: their helper range
+// grows with the horizon as measured before it existed.
+static bool two_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE; }
 static bool wants_helper(const cilqr_handle* h, int B) {
-    const bool two = !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE;
-    return (h->helper_mode == 1) ||
-           (h->helper_mode < 0 &&
-            B <= (two ? (h->helper_max_batch_two_rows >= 0 ? h->helper_max_batch_two_rows : 1536 + 80 * (h->params[0].N - 60))
-                      : h->helper_max_batch));
+    if (h->helper_mode >= 0) return h->helper_mode == 1;
+    if (!two_rows(h)) return B <= h->helper_max_batch;
+    if (h->helper_max_batch_two_rows >= 0) return B <= h->helper_max_batch_two_rows;
+    const int N = h->params[0].N;
+    if (h->params[0].solve_type == 1 || !h->share) return B <= 1536 + 80 * (N - 60);
+    return B <= (N >= 96 ? 512 : 1536);
+}
+// lone wavefronts, two per SIMD (the builds with WPS = 2, NTP = 1)?
+static bool lone_two_per_simd(const cilqr_handle* h, int B) {
+    if (wants_helper(h, B)) return false;
+    const bool alm = h->params[0].solve_type == 1;
+    if (two_rows(h) && !alm && h->share) return true; // (the work-sharing builds, whatever the batch)
+    return B > h->occ2_min_batch;
 }
 
 // does the solve-kernel variant for this batch cost one trial per pass without a helper (one stage-cost slot)?
 // Mirrors the dispatch in cilqr_solve_batch_device, which checks the two against each other.
 static bool single_slot(const cilqr_handle* h, int B) {
     const bool alm = h->params[0].solve_type == 1;
-    if (wants_helper(h, B)) return false;
-    if (alm) return B > h->occ2_min_batch;
-    if (h->debug_flags != 0 || h->profiling) return false;
-    return B > h->occ2_min_batch;
+    if (!alm && (h->debug_flags != 0 || h->profiling)) return false;
+    return lone_two_per_simd(h, B);
 }
 
 // does this batch run a build that keeps the cost expansion in global memory (k_solve's LG)?
@@ -1167,12 +1317,17 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.tier = h->rollout_mode;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
-    const bool occ2 = B > h->occ2_min_batch && (a.alm || a.flags == 0) && !h->profiling && !wants_helper(h, B);
+    const bool occ2 = lone_two_per_simd(h, B) && (a.alm || a.flags == 0) && !h->profiling;
     a.W = occ2 ? (single_slot(h, B) ? (global_expansion(h, B) ? h->win_lg : h->win_occ) : h->win_occ2) : h->win;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
     a.alm_rho = static_cast<double*>(h->alm_rho.p);
     a.alm_C = h->alm_C;
+    a.sh_ctl = nullptr;
+    a.sh_req = nullptr;
+    a.sh_hints = nullptr;
+    a.sh_max_helpers = h->share_max_helpers;
+    a.sh_min_t0 = h->share_min_t0;
     return a;
 }
 
@@ -1227,6 +1382,18 @@ static int ensure_scratch(cilqr_handle* h, int B) {
     }
     if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
+    // work sharing between blocks: counters and slots, one request and one row of hints per trajectory
+    if (B > h->sh_B || N != h->sh_N || !h->sh_ctl.p) {
+        HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
+        h->sh_req.release(); h->sh_hints.release();
+        if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS) || h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) ||
+            h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
+            return fail(CILQR_ERR_DEVICE, "hipMalloc work-sharing state");
+        HIP_TRY(hipMemset(h->sh_req.p, 0, sizeof(ShareReq) * (size_t)B)); // every request closed
+        HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
+        h->sh_B = B;
+        h->sh_N = N;
+    }
     return CILQR_OK;
 }
 
@@ -1262,9 +1429,10 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         // `one` = the variant costs one trial per pass without a helper: one stage-cost slot in LDS (k_solve's SLOTS)
         auto kern = k_solve<false, 1, false, false, false>;
         bool one = false, lg = false;
+        h->last_launch_shared = false;
         if (a.alm) {
             if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
-            else if (B > h->occ2_min_batch) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; }
+            else if (lone_two_per_simd(h, B)) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; }
             else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
         } else if (a.flags != 0) {
             kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
@@ -1275,16 +1443,26 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
             if (a.N == 50) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 50>;
             if (a.N == 100) kern = k_solve<false, 2, false, true, false, 1, CILQR_NT, 100>;
-        } else if (B > h->occ2_min_batch) {
-            kern = two ? k_solve<false, 2, false, false, false, 2, 1> : k_solve<false, 1, false, false, false, 2, 1>;
+        } else if (lone_two_per_simd(h, B)) {
+            // (two rows per lane: built with work sharing between blocks, which a.sh_ctl switches on.  Shorter horizons
+            //  are not: a trial costs 5 us there, the hand-over of a search about 10, and the build costs the solve loop
+            //  3 % in spilled registers — measured: config 5 -5 %, config 3 -33 % with it, config 4 +25 %)
+            kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, true> : k_solve<false, 1, false, false, false, 2, 1>;
             if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
-            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100>;
+            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, false, true>;
             if (global_expansion(h, B)) {
-                kern = k_solve<false, 2, false, false, false, 2, 1, 0, true>;
-                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true>;
+                kern = k_solve<false, 2, false, false, false, 2, 1, 0, true, true>;
+                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true, true>;
                 lg = true;
             }
             one = true;
+            if (h->share && two) {
+                a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
+                a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
+                a.sh_hints = static_cast<int*>(h->sh_hints.p);
+                HIP_TRY(hipMemsetAsync(a.sh_ctl, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+                h->last_launch_shared = true;
+            }
         } else {
             kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         }
@@ -1356,7 +1534,11 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     DL(6, x_out, nb_x);
     if (res_out) DL(7, res_out, sizeof(cilqr_result) * B);
     if (d_tr) DL(8, trace_out, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap);
+    unsigned sh_err = 0;
+    if (h->sh_ctl.p && h->last_launch_shared)
+        HIP_TRY(hipMemcpyAsync(&sh_err, static_cast<unsigned*>(h->sh_ctl.p) + SH_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (sh_err) return fail(CILQR_ERR_DEVICE, "work sharing between blocks: a claimed line-search trial was not delivered in time");
     return CILQR_OK;
 }
 

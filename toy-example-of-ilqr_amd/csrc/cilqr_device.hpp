@@ -1141,6 +1141,167 @@ __device__ inline void restore_gains_head(const Lds& l, const double* first, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Work sharing between blocks (k_solve's SHARE).  A launch ends with a few long line searches on a mostly idle
+// chip: the last trajectories each cost their 20 trial trajectories one after the other.  Blocks that have finished
+// their own trajectory — once every block of the grid has started, so that staying resident keeps nobody out —
+// therefore stay and cost open trials of the blocks still running.  A cost is a pure function of the trial
+// trajectory (in the global slab), the trajectory's tables and the row-0 lane index, so whoever computes it
+// computes the same bits; the search's verdicts are still taken in order by the owner.
+//
+// Per trajectory one ShareReq; a search in need of help is announced in one of 64 slots that idle blocks poll.
+// claim = seq << 16 | hi << 8 | lo: the owner costs trials below lo (it extends lo one trial at a time), helpers
+// take trials from the top (hi - 1, hi - 2, ...) while hi > lo; seq numbers the searches of the trajectory, a
+// closed request has hi = lo = 0.  J[t] holds the bits of the cost of trial t or the pending mark.  The owner does
+// not touch the slab again before every claimed trial has been delivered (sh_close), so no helper ever reads a
+// slab that is being rewritten or writes into a later search.
+// Visibility across the chip's eight L2s: the owner's release (L2 write-back) before it opens the claim word, the
+// helper's acquire (L2 invalidate) after it has claimed; claim words, slots, counters and results are agent-scope
+// atomics.  Every wait is bounded: past the bound the owner costs the trial itself and the launch is flagged
+// (SH_ERROR), it never hangs.
+struct ShareReq {
+    unsigned claim;
+    int idx0;       // row-0 lane index of the trajectory (= first sample of its lane window)
+    int pad0, pad1;
+    unsigned long long J[CILQR_MAX_ALPHA_TRIALS];
+    unsigned long long pad2[2];
+};
+static_assert(sizeof(ShareReq) == 192, "ShareReq layout");
+enum { SH_STARTED = 0, SH_FINISHED = 1, SH_HELPERS = 2, SH_ERROR = 3, SH_ANNOUNCED = 4, SH_HELPED = 5, SH_SLOT0 = 8 };
+#define CILQR_SH_NSLOT 64
+#define CILQR_SH_WORDS (SH_SLOT0 + CILQR_SH_NSLOT)
+#define CILQR_SH_PENDING 0x7ff8c11a5ea7ed00ULL /* a NaN no arithmetic produces */
+#define CILQR_SH_SPIN_CAP (1 << 22)
+#define CILQR_SH_MIN_OPEN 4 /* trials still open for a search to be announced */
+
+__device__ inline unsigned sh_ld(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void sh_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned long long sh_ld64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void sh_st64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform forms: lane 0 acts, every lane gets the result
+__device__ inline unsigned sh_ld_u(const unsigned* p, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = sh_ld(p);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ inline unsigned sh_add_u(unsigned* p, unsigned inc, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(p, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// compare-and-swap by lane 0; returns the value found (== expected on success)
+__device__ inline unsigned sh_cas_u(unsigned* p, unsigned expected, unsigned desired, int lane) {
+    unsigned v = 0;
+    if (lane == 0) {
+        unsigned e = expected;
+        __hip_atomic_compare_exchange_strong(p, &e, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = e;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ inline void sh_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ inline void sh_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+// owner: announce the search whose trials t0 .. 19 sit in the slab; the owner keeps t0 and t0 + 1.  false = no slot free
+__device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx, int b, int N, int t0, int idx0,
+                               unsigned seq, int lane) {
+    for (int k = lane; k <= N; k += CILQR_WAVE) hints[k] = ridx[k];
+    if (lane < CILQR_MAX_ALPHA_TRIALS) rq->J[lane] = CILQR_SH_PENDING;
+    if (lane == 0) rq->idx0 = idx0;
+    sh_release(); // the slab, the hints and the marks are out before the claim word opens
+    const unsigned own = (unsigned)((t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS);
+    if (lane == 0) sh_st(&rq->claim, (seq << 16) | ((unsigned)CILQR_MAX_ALPHA_TRIALS << 8) | own);
+    bool placed = false;
+    for (int i = 0; i < 4 && !placed; ++i) {
+        unsigned* slot = ctl + SH_SLOT0 + ((unsigned)(b + 17 * i) % CILQR_SH_NSLOT);
+        placed = (sh_cas_u(slot, 0u, (unsigned)b + 1u, lane) == 0u);
+    }
+    if (placed) (void)sh_add_u(ctl + SH_ANNOUNCED, 1u, lane);
+    return placed; // (not placed: the claim word stays open but nobody is pointed at it; sh_owner_close closes it)
+}
+// owner: take trial t for itself (extend lo) unless a helper has it
+__device__ inline bool sh_take(ShareReq* rq, unsigned seq, int t, int lane) {
+    for (int tries = 0; tries < 64; ++tries) {
+        const unsigned v = sh_ld_u(&rq->claim, lane);
+        const unsigned lo = v & 0xffu, hi = (v >> 8) & 0xffu;
+        if ((unsigned)t >= hi) return false;       // a helper's
+        if ((unsigned)t < lo) return true;         // already the owner's
+        if (sh_cas_u(&rq->claim, v, (v & ~0xffu) | (unsigned)(t + 1), lane) == v) return true;
+    }
+    return false;
+}
+// owner: the cost a helper delivers for trial t; false = not delivered within the bound
+__device__ inline bool sh_await(unsigned* ctl, ShareReq* rq, int t, int lane, double& J) {
+    unsigned long long v = CILQR_SH_PENDING;
+    for (int spin = 0; spin < CILQR_SH_SPIN_CAP; ++spin) {
+        unsigned long long w = 0;
+        if (lane == 0) w = sh_ld64(&rq->J[t]);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w & 0xffffffffULL));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32));
+        v = ((unsigned long long)hi << 32) | lo;
+        if (v != CILQR_SH_PENDING) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (v == CILQR_SH_PENDING) {
+        if (lane == 0) sh_st(ctl + SH_ERROR, 1u);
+        return false;
+    }
+    J = dm_from_bits(v);
+    return true;
+}
+// The owner's side as the solve loop calls it, once per trial of an announced search.  Kept out of line: the loop
+// pays for it in registers otherwise (26 -> 50 spilled vector registers), and it runs on a few searches per launch.
+// State word: bit 0 announced, bit 1 in a slot, bits 8-15 first trial that is not the owner's, bit 31 (result only)
+// the cost of trial t0 was delivered by a helper and is in *Jout (LDS).
+#define SH_ST_ON 1u
+#define SH_ST_PLACED 2u
+#define SH_ST_FOREIGN 0x80000000u
+__device__ __attribute__((noinline)) unsigned sh_owner_step(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx,
+                                                            double* Jout, int b, int N, int t0, int idx0, unsigned seq,
+                                                            unsigned st, int lane) {
+    st &= ~SH_ST_FOREIGN;
+    if (!(st & SH_ST_ON)) {
+        const bool placed = sh_open(ctl, rq, hints, ridx, b, N, t0, idx0, seq, lane);
+        const int own0 = (t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS;
+        st = SH_ST_ON | (placed ? SH_ST_PLACED : 0u) | ((unsigned)own0 << 8);
+    }
+    const int own = (int)((st >> 8) & 0xffu);
+    if (t0 < own) return st;
+    if (sh_take(rq, seq, t0, lane)) return (st & ~0xff00u) | ((unsigned)(t0 + 1) << 8);
+    double J;
+    if (!sh_await(ctl, rq, t0, lane, J)) return st; // not delivered (flagged): the owner costs it
+    if (lane == 0) *Jout = J;
+    wave_sync();
+    return st | SH_ST_FOREIGN;
+}
+// owner: close the search; returns when every trial a helper claimed has been delivered (the slab is free again)
+__device__ __attribute__((noinline)) void sh_owner_close(unsigned* ctl, ShareReq* rq, int b, unsigned seq, unsigned st, int lane) {
+    const bool placed = (st & SH_ST_PLACED) != 0u;
+    unsigned v = sh_ld_u(&rq->claim, lane);
+    for (int tries = 0; tries < 1024; ++tries) {
+        const unsigned f = sh_cas_u(&rq->claim, v, ((seq + 1u) << 16), lane);
+        if (f == v) break;
+        v = f;
+    }
+    const int hi = (int)((v >> 8) & 0xffu);
+    for (int t = hi; t < CILQR_MAX_ALPHA_TRIALS; ++t) {
+        double dummy;
+        (void)sh_await(ctl, rq, t, lane, dummy);
+    }
+    if (placed) {
+        for (int i = 0; i < 4; ++i) {
+            unsigned* slot = ctl + SH_SLOT0 + ((unsigned)(b + 17 * i) % CILQR_SH_NSLOT);
+            if (sh_cas_u(slot, (unsigned)b + 1u, 0u, lane) == (unsigned)b + 1u) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // hpp/cs:701-713 lagrangian_derivative_and_Hessian: the scalar s with b_dot = s * c_dot,
 // b_ddot = b_dot * c_dot^T (s = 0 when the constraint is inactive)
 __device__ inline double alm_slope(double cv, double rho, double mu) {

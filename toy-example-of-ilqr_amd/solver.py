@@ -169,6 +169,18 @@ class BatchedCILQR:
         """-1 adaptive, 0 all 20 step sizes in one rollout pass, 1 the first trial alone first"""
         check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
 
+
+    def set_work_sharing(self, mode):
+        """1 (default): finished blocks cost line-search trials of the trajectories still being solved (horizons
+        above 63, barrier mode, large batches); 0: off.  Same results either way."""
+        check(self._lib.cilqr_set_work_sharing(self._h, int(mode)), "cilqr_set_work_sharing")
+
+    def work_sharing_stats(self):
+        """counters of the last launch that shared work: searches announced, trial costs delivered by other blocks,
+        blocks that stayed to help, error flag"""
+        out = (C.c_uint32 * 4)()
+        check(self._lib.cilqr_work_sharing_stats(self._h, out), "cilqr_work_sharing_stats")
+        return {"announced": int(out[0]), "helped": int(out[1]), "helpers": int(out[2]), "error": int(out[3])}
     def set_debug_flags(self, flags):
         check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
