@@ -128,6 +128,14 @@ for c in (2, 3, 5):
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_phase_config{c}.json"))
 
+# SQ wait / active counters of scripts/stall_counters.sh (per launch, averaged over launches)
+for name in ("c5", "c4", "c3", "c2"):
+    st = {}
+    for d in sorted(glob.glob(os.path.join(src, f"stall_{name}_[0-9]"))):
+        st.update({k: v for k, v in counters(os.path.basename(d)).items() if not k.endswith("_launches") and k != "kernel"})
+    if st:
+        json.dump(st, open(os.path.join(dst, f"{tag}_stall_{name}.json"), "w"), indent=1)
+
 b = last_json(os.path.join(src, "bench_force_dist.json"))
 if b:
     err = open(os.path.join(src, "bench_force_dist.err"), errors="replace").read().splitlines()[-15:]
