@@ -55,6 +55,7 @@ struct BatchArgs {
     int* sh_hints;              // [B][N + 2]
     int sh_max_helpers;         // blocks that stay to help (the others leave when they are done)
     int sh_min_t0;              // a search is announced once this many of its trials have been rejected
+    int sh_backoff;             // an idle helper looks again after 1 us, doubling up to 2^sh_backoff us
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -124,10 +125,10 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
             if (bb < 0 || bb >= a.B) continue;
             ShareReq* rq = a.sh_req + bb;
             const unsigned v = sh_ld_u(&rq->claim, lane);
-            const unsigned lo = v & 0xffu, hi = (v >> 8) & 0xffu;
-            if (hi <= lo || hi > (unsigned)CILQR_MAX_ALPHA_TRIALS) continue;
-            if (sh_cas_u(&rq->claim, v, v - 0x100u, lane) != v) continue; // somebody else moved it: look again later
-            const int t = (int)hi - 1;
+            const unsigned next = v & 0xffu;
+            if (next >= (unsigned)CILQR_MAX_ALPHA_TRIALS) continue; // closed, or every trial handed out
+            if (sh_cas_u(&rq->claim, v, v + 1u, lane) != v) continue; // somebody else moved it: look again later
+            const int t = (int)next;
             const unsigned seq = v >> 16;
             if (bb != cur_b || seq != cur_seq) {
                 sh_acquire(); // the owner's slab, hints and row-0 index of this search
@@ -149,10 +150,10 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
             (void)sh_add_u(ctl + SH_HELPED, 1u, lane);
             worked = true;
         }
-        // nothing to do: look again after 1 us, backing off to 16 us
+        // nothing to do: look again after 1 us, backing off
         if (worked) idle = 0;
         else {
-            idle = (idle < 4) ? idle + 1 : 4;
+            idle = (idle < a.sh_backoff) ? idle + 1 : a.sh_backoff;
             for (int r = 0; r < (1 << idle); ++r) __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -437,7 +438,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 t0 += nt;
             }
             if (SHARE && sh_st != 0u) { // (before anything touches the slab again)
-                sh_owner_close(a.sh_ctl, rq, b, sh_seq, sh_st, lane);
+                sh_owner_close(a.sh_ctl, rq, b, sh_seq, sh_st, (t0 > 0 ? t0 - 1 : 0), lane);
                 sh_seq++;
             }
             deep_next = (trials > 1);
@@ -815,6 +816,7 @@ struct cilqr_handle {
     int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
                               // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
                               // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
+    int share_backoff = 4;
     int share_max_helpers = 64, share_min_t0 = 1; // (measured: 64 helpers serve the few open searches of a launch's tail; 2048 polling blocks cost 9-16 %)
     bool last_launch_shared = false;
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
@@ -909,6 +911,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "share") h->share = v;
                 else if (k == "share_max_helpers") h->share_max_helpers = v;
                 else if (k == "share_min_t0") h->share_min_t0 = v;
+                else if (k == "share_backoff") h->share_backoff = v;
             }
             pos = e + 1;
         }
@@ -1327,7 +1330,8 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.sh_req = nullptr;
     a.sh_hints = nullptr;
     a.sh_max_helpers = h->share_max_helpers;
-    a.sh_min_t0 = h->share_min_t0;
+    a.sh_min_t0 = h->share_min_t0 < 1 ? 1 : h->share_min_t0;
+    a.sh_backoff = h->share_backoff < 0 ? 0 : (h->share_backoff > 8 ? 8 : h->share_backoff);
     return a;
 }
 
@@ -1389,7 +1393,7 @@ static int ensure_scratch(cilqr_handle* h, int B) {
         if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS) || h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) ||
             h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc work-sharing state");
-        HIP_TRY(hipMemset(h->sh_req.p, 0, sizeof(ShareReq) * (size_t)B)); // every request closed
+        HIP_TRY(hipMemset(h->sh_req.p, 0xff, sizeof(ShareReq) * (size_t)B)); // every request closed (next = 255)
         HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
         h->sh_B = B;
         h->sh_N = N;

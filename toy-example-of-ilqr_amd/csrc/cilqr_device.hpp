@@ -1149,11 +1149,11 @@ __device__ inline void restore_gains_head(const Lds& l, const double* first, int
 // computes the same bits; the search's verdicts are still taken in order by the owner.
 //
 // Per trajectory one ShareReq; a search in need of help is announced in one of 64 slots that idle blocks poll.
-// claim = seq << 16 | hi << 8 | lo: the owner costs trials below lo (it extends lo one trial at a time), helpers
-// take trials from the top (hi - 1, hi - 2, ...) while hi > lo; seq numbers the searches of the trajectory, a
-// closed request has hi = lo = 0.  J[t] holds the bits of the cost of trial t or the pending mark.  The owner does
-// not touch the slab again before every claimed trial has been delivered (sh_close), so no helper ever reads a
-// slab that is being rewritten or writes into a later search.
+// claim = seq << 16 | next: trials are handed out in ascending order — the order the verdicts need them in — by
+// compare-and-swap on `next`, to helpers and to the owner alike (the owner keeps the first two of the search without
+// asking); seq numbers the searches of the trajectory, a closed request has next = 255.  J[t] holds the bits of the
+// cost of trial t or the pending mark.  The owner does not touch the slab again before every claimed trial has been
+// delivered (sh_owner_close), so no helper ever reads a slab that is being rewritten or writes into a later search.
 // Visibility across the chip's eight L2s: the owner's release (L2 write-back) before it opens the claim word, the
 // helper's acquire (L2 invalidate) after it has claimed; claim words, slots, counters and results are agent-scope
 // atomics.  Every wait is bounded: past the bound the owner costs the trial itself and the launch is flagged
@@ -1215,7 +1215,7 @@ __device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const in
     if (lane == 0) rq->idx0 = idx0;
     sh_release(); // the slab, the hints and the marks are out before the claim word opens
     const unsigned own = (unsigned)((t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS);
-    if (lane == 0) sh_st(&rq->claim, (seq << 16) | ((unsigned)CILQR_MAX_ALPHA_TRIALS << 8) | own);
+    if (lane == 0) sh_st(&rq->claim, (seq << 16) | own);
     bool placed = false;
     for (int i = 0; i < 4 && !placed; ++i) {
         unsigned* slot = ctl + SH_SLOT0 + ((unsigned)(b + 17 * i) % CILQR_SH_NSLOT);
@@ -1224,13 +1224,12 @@ __device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const in
     if (placed) (void)sh_add_u(ctl + SH_ANNOUNCED, 1u, lane);
     return placed; // (not placed: the claim word stays open but nobody is pointed at it; sh_owner_close closes it)
 }
-// owner: take trial t for itself (extend lo) unless a helper has it
+// owner: take trial t for itself unless a helper has it (trials go out in ascending order: t is free iff next == t)
 __device__ inline bool sh_take(ShareReq* rq, unsigned seq, int t, int lane) {
     for (int tries = 0; tries < 64; ++tries) {
         const unsigned v = sh_ld_u(&rq->claim, lane);
-        const unsigned lo = v & 0xffu, hi = (v >> 8) & 0xffu;
-        if ((unsigned)t >= hi) return false;       // a helper's
-        if ((unsigned)t < lo) return true;         // already the owner's
+        const unsigned next = v & 0xffu;
+        if (next > (unsigned)t) return false; // a helper's
         if (sh_cas_u(&rq->claim, v, (v & ~0xffu) | (unsigned)(t + 1), lane) == v) return true;
     }
     return false;
@@ -1280,16 +1279,20 @@ __device__ __attribute__((noinline)) unsigned sh_owner_step(unsigned* ctl, Share
     return st | SH_ST_FOREIGN;
 }
 // owner: close the search; returns when every trial a helper claimed has been delivered (the slab is free again)
-__device__ __attribute__((noinline)) void sh_owner_close(unsigned* ctl, ShareReq* rq, int b, unsigned seq, unsigned st, int lane) {
+// (t_last = the last trial whose verdict was taken: everything handed out beyond it went to helpers)
+__device__ __attribute__((noinline)) void sh_owner_close(unsigned* ctl, ShareReq* rq, int b, unsigned seq, unsigned st,
+                                                         int t_last, int lane) {
     const bool placed = (st & SH_ST_PLACED) != 0u;
     unsigned v = sh_ld_u(&rq->claim, lane);
     for (int tries = 0; tries < 1024; ++tries) {
-        const unsigned f = sh_cas_u(&rq->claim, v, ((seq + 1u) << 16), lane);
+        const unsigned f = sh_cas_u(&rq->claim, v, ((seq + 1u) << 16) | 0xffu, lane);
         if (f == v) break;
         v = f;
     }
-    const int hi = (int)((v >> 8) & 0xffu);
-    for (int t = hi; t < CILQR_MAX_ALPHA_TRIALS; ++t) {
+    int next = (int)(v & 0xffu);
+    next = (next < CILQR_MAX_ALPHA_TRIALS) ? next : CILQR_MAX_ALPHA_TRIALS;
+    const int own = (int)((st >> 8) & 0xffu); // trials below this were the owner's
+    for (int t = (t_last + 1 > own) ? t_last + 1 : own; t < next; ++t) {
         double dummy;
         (void)sh_await(ctl, rq, t, lane, dummy);
     }
