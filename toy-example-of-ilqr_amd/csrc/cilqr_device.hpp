@@ -1898,7 +1898,13 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     const bool diag = (rp >= 4) && (cc == rp);
     const int r4 = rp & 3;
     const int src_c0 = 32 + wc, src_c1 = 40 + wc;   // (Q_ux | Q_u)[0][c], [1][c]
-    const int src_r0 = 32 + r4, src_r1 = 40 + r4;   // Q_ux[0][r], [1][r]
+    // Q_ux[0][r], [1][r] for the rows of W.  Rows 4 and 5 of the grid have no part in the update of W: they take
+    // r = Q_u instead, which makes their K[:, r] the step d, and carry the expected cost reduction (cs:435-436):
+    // with d halved on row 4 (krf), lane (4, 4) gets ta = (0.5 d)^T Q_uu d and lane (5, 4) gets tb = d^T Q_u out of
+    // the very expressions the other lanes evaluate for W — the reference's operands in the reference's order
+    const int src_r0 = (rp >= 4) ? 36 : 32 + r4, src_r1 = (rp >= 4) ? 44 : 40 + r4;
+    const double krf = (rp == 4) ? 0.5 : 1.0;
+    double dvacc = 0.0; // lane 36: delta_V[0], lane 44: delta_V[1]
     // this lane's ten coefficient addresses (LDS byte addresses) walk backwards with the step
     unsigned am1[4], am2[4], dm1[4], dm2[4];
 #pragma unroll
@@ -1967,7 +1973,6 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
         const double Quu0 = lane_bcast<36>(Q), Quu1 = lane_bcast<37>(Q);
         const double Quu2 = lane_bcast<44>(Q), Quu3 = lane_bcast<45>(Q);
-        const double Qu0 = lane_bcast<36>(Zv), Qu1 = lane_bcast<44>(Zv);
         // (the lane predicates are recomputed from a vector register each step: one compare instead of the two
         //  v_readlane a spilled scalar mask costs)
         int ccv = cc;
@@ -2006,10 +2011,10 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             return false;
         }
         const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
-        const double d0 = n00 * Qu0 + n01 * Qu1;
-        const double d1 = n10 * Qu0 + n11 * Qu1;
         const double kc0 = n00 * c0 + n01 * c1, kc1 = n10 * c0 + n11 * c1; // (K | d)[:, c]
-        const double kr0 = n00 * r0 + n01 * r1, kr1 = n10 * r0 + n11 * r1; // K[:, r]
+        double kr0 = n00 * r0 + n01 * r1, kr1 = n10 * r0 + n11 * r1; // K[:, r]
+        kr0 = kr0 * krf; // (exact: the factor is 1, or 0.5 on row 4 — hd = 0.5 d of cs:435)
+        kr1 = kr1 * krf;
         const double p0 = kr0 * Quu0 + kr1 * Quu2;                         // (K^T Q_uu)[r][:]
         const double p1 = kr0 * Quu1 + kr1 * Quu3;
         const double ta = p0 * kc0 + p1 * kc1;
@@ -2025,13 +2030,13 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             kd[0] = kc0;
             kd[CILQR_KD_ROW] = kc1;
         }
-        // expected cost reduction (cs:435-436)
-        const double hd0 = 0.5 * d0, hd1 = 0.5 * d1;
-        const double g0 = hd0 * Quu0 + hd1 * Quu2;
-        const double g1 = hd0 * Quu1 + hd1 * Quu3;
-        dV[0] += g0 * d0 + g1 * d1;
-        dV[1] += d0 * Qu0 + d1 * Qu1;
+        // expected cost reduction (cs:435-436): delta_V[0] += (0.5 d)^T Q_uu d on lane 36, delta_V[1] += d^T Q_u on lane 44
+        int rpv = rp;
+        __asm__("" : "+v"(rpv));
+        dvacc = dvacc + ((rpv == 4) ? ta : tb);
     }
+    dV[0] = lane_bcast<36>(dvacc);
+    dV[1] = lane_bcast<44>(dvacc);
     wave_sync();
     return true;
 }
