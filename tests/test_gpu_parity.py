@@ -735,6 +735,47 @@ def test_work_sharing_between_blocks_is_transparent(pkg, orc_det):
     eq_bits(a["res"]["J_final"][sel], ref["res"]["J_final"], "sample J_final")
 
 
+@pytest.mark.parametrize("N,B", [(64, 1600), (75, 1600), (76, 1600), (96, 600), (127, 600)])
+def test_long_horizon_builds_across_horizons(pkg, orc_det, N, B):
+    """The lone-wavefront builds of horizons above 63 on either side of their switches: N = 75 / 76 (cost expansion in
+    LDS / in global memory), N = 96 (helper range 1536 -> 512), N = 127 (largest horizon; ring of expansion rows at
+    its longest), batches just beyond the helper range so that blocks help each other from the first finisher on.
+    Against the helper-wavefront build (work sharing off) on every trajectory, against the oracle on a sample; warm
+    start from a shifted previous solution included (last_u)."""
+    from oracle import Scene
+    wl = pkg.workloads.config3(B=B)
+    if wl.scenes[0].obs.shape[1] < N + 1:
+        pytest.skip("obstacle routes shorter than the horizon")
+    params = [pkg.copy_params(q, N=N, max_iter=30) for q in wl.params]
+    eng = pkg.BatchedCILQR(params, wl.scenes)
+    rng = np.random.default_rng(N)
+    last_u = rng.normal(0.0, 0.05, size=(B, N, 2))
+    out = {}
+    for mode in (1, 0):
+        eng.set_work_sharing(mode)
+        out[mode] = (eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick),
+                     eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, last_u=last_u))
+        if mode == 1:
+            st = eng.work_sharing_stats()
+    eng.close()
+    assert st["error"] == 0 and st["helpers"] > 0, st
+    for a, b, what in ((out[1][0], out[0][0], "cold"), (out[1][1], out[0][1], "warm")):
+        eq_bits(a["u"], b["u"], f"N={N} {what} u")
+        eq_bits(a["x"], b["x"], f"N={N} {what} x")
+        assert (a["res"] == b["res"]).all(), (N, what)
+    sel = np.arange(0, B, 16)
+    s0 = wl.scenes[0]
+    scene = Scene(s0.lane_x, s0.lane_y, s0.lane_yaw, s0.obs, s0.road_borders, s0.ref_velo)
+    ref = orc_det.solve_batch(params, scene, wl.x0[sel], None, wl.param_id[sel] if wl.param_id is not None else None, None,
+                              n_threads=16)
+    a = out[1][0]
+    eq_bits(a["x"][sel], ref["x"], f"N={N} sample x")
+    eq_bits(a["u"][sel], ref["u"], f"N={N} sample u")
+    eq_bits(a["res"]["J_final"][sel], ref["res"]["J_final"], f"N={N} sample J_final")
+    for f in ("iters", "ls_trials", "end_reason", "final_status"):
+        assert np.array_equal(a["res"][f][sel], ref["res"][f]), (N, f)
+
+
 def test_rollout_policy_statistics(pkg, engines):
     """the adaptive policy's bookkeeping (in-kernel counters): every line search starts with exactly one rollout
     pass, second passes happen only after a rejected first trial, and on the benchmark-like batch the slab is
