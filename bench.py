@@ -11,7 +11,8 @@ Workload (BASELINE.json `configs`):
   * N = 1 (default): config 5 — 4096 perturbed three_bend starts x 16 barrier settings = 65 536 solves of
     horizon 50, the largest single-GPU configuration (north_star: ">= 10k trajectories x 50-step horizon on
     1 x MI355X").  Config 2 (1024 straight-lane trajectories, one launch = a latency measurement: its wall
-    time is the slowest trajectory's) is timed in the same run and reported under `extra.config2_latency`.
+    time is the slowest trajectory's) is timed in the same run and reported under `extra.config2_latency`,
+    one rank's shard of BASELINE configs[3] (8192 mixed scenarios of horizon 100) under `extra.config4_sharded`.
   * N > 1 (default): the SAME workload per GPU as at N = 1 — every rank solves its own 4096 x 16 sweep (base
     starts first = rank * 4096 of one global batch), so that value(N) / value(1) is a weak-scaling efficiency
     whoever computes it; no data-path collective, RCCL only reduces the statistics afterwards.  BASELINE
@@ -425,9 +426,9 @@ def main():
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
         second = side_run(2, max(args.steps, 20), "one launch of 1024 trajectories occupies a quarter of the chip's wave "
                           "slots; its wall time is the slowest trajectory's (DESIGN.md)")
-        if world > 1 or os.environ.get("CILQR_FORCE_DIST") == "1":
-            fourth = side_run(4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
-                              "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs)")
+        fourth = side_run(4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
+                          "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs; at fewer, the "
+                          "first ranks' shards)")
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
