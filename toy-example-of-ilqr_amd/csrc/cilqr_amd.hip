@@ -1386,8 +1386,9 @@ static int ensure_scratch(cilqr_handle* h, int B) {
     }
     if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
-    // work sharing between blocks: counters and slots, one request and one row of hints per trajectory
-    if (B > h->sh_B || N != h->sh_N || !h->sh_ctl.p) {
+    // work sharing between blocks (builds of horizons above 63, barrier mode): counters and slots, one request and
+    // one row of hints per trajectory
+    if (two_rows(h) && h->params[0].solve_type != 1 && (B > h->sh_B || N != h->sh_N || !h->sh_ctl.p)) {
         HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
         h->sh_req.release(); h->sh_hints.release();
         if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS) || h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) ||
@@ -1460,7 +1461,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
                 lg = true;
             }
             one = true;
-            if (h->share && two) {
+            if (h->share && two && h->sh_ctl.p) {
                 a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
                 a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
                 a.sh_hints = static_cast<int*>(h->sh_hints.p);
