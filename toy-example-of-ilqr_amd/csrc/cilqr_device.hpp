@@ -1727,7 +1727,7 @@ __device__ inline bool backward_sweep_uniform(const Cst& c, const Lds& l, double
 // the reference's dense Eigen evaluation order, zeros included.  Lane (r', c'') = (lane >> 3,
 // lane & 7) owns one element; operands travel through the small LDS exchange area l.xch, the
 // per-step coefficients come straight from the stage arrays through per-lane address maps.
-// ~170 wave instructions per step instead of ~540 for the wave-uniform form.
+// ~145 vector (~220 wave) instructions per step instead of ~540 for the wave-uniform form.
 struct LaneMap {
     int m1[4];  // LDS double-offsets (at step 0) of M[k][r'], k = 0..3
     int s1[4];  // their per-step strides
