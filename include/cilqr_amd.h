@@ -220,6 +220,11 @@ int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
  * lane-parallel one.  Results must be identical either way. */
 int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags);
 int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B);
+/* Development aid: when enabled, the fused solve records per trajectory when the block that solved it started and
+ * ended (constant 100 MHz clock), that block's index and the XCC (chiplet) it ran on — out[B][4] — which shows how
+ * the launch fills the chip over time (scripts/block_timeline.py). */
+int cilqr_set_block_timeline(cilqr_handle* h, int32_t enabled);
+int cilqr_get_block_timeline(cilqr_handle* h, int64_t* out, int32_t B);
 
 /* ---- the pieces of the path, exported so each can be parity-checked on its own -------------- */
 /* get_init_traj / const_velo_prediction (cs:155-161,182-197): x_out[B][N+1][4] */

@@ -19,7 +19,7 @@ eng = pkg.BatchedCILQR(params, wl.scenes)
 eng.set_helper_mode(0)
 eng.set_timing(True)
 out = {}
-for B in (512, 1024, 1536, 1792, 2048, 2304, 2560, 3072, 3584, 4096, 6144, 8192):
+for B in [int(b) for b in sys.argv[2:]] or (512, 1024, 1536, 1792, 2048, 2304, 2560, 3072, 3584, 4096, 6144, 8192):
     x0 = np.repeat(wl.x0[3:4], B, axis=0)
     eng.solve_batch(x0)
     ms = []

@@ -104,6 +104,8 @@ SIGNATURES = {
     "cilqr_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "cilqr_set_timing": (C.c_int, [_P, _I]),
     "cilqr_set_phase_profiling": (C.c_int, [_P, _I]),
+    "cilqr_set_block_timeline": (C.c_int, [_P, _I]),
+    "cilqr_get_block_timeline": (C.c_int, [_P, _P, _I]),
     "cilqr_get_phase_cycles": (C.c_int, [_P, _P, _I]),
     "cilqr_set_debug_flags": (C.c_int, [_P, _I]),
     "cilqr_set_helper_mode": (C.c_int, [_P, _I]),

@@ -56,6 +56,10 @@ struct BatchArgs {
     int sh_max_helpers;         // blocks that stay to help (the others leave when they are done)
     int sh_min_t0;              // a search is announced once this many of its trials have been rejected
     int sh_backoff;             // an idle helper looks again after 1 us, doubling up to 2^sh_backoff us
+    unsigned* next;             // persistent blocks (large batches): the next trajectory to hand out; null = one block
+                                // per trajectory
+    long long* timeline;        // optional [B][4]: start / end of the solve of trajectory b (constant 100 MHz clock), the
+                                // index of the block that solved it, the XCC it ran on (cilqr_set_block_timeline; null = off)
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -106,7 +110,7 @@ template <int NCH, int NC>
 __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, int lane, int me) {
     unsigned* const ctl = a.sh_ctl;
     if (sh_add_u(ctl + SH_HELPERS, 1u, lane) >= (unsigned)a.sh_max_helpers) return; // enough of them already
-    int cur_b = -1, idx0h = 0, nfb = 0, idle = 0;
+    int cur_b = -1, idx0h = 0, nfb = 0, idle = 0, slot_b = 0;
     unsigned cur_seq = 0;
     Cst c2;
     AlmSt al2;
@@ -136,6 +140,7 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
                 if (NC) c2.N = NC;
                 wave_sync();
                 idx0h = rq->idx0;
+                slot_b = rq->slot; // the owner block's scratch area (its slab)
                 stage_window(c2, l, idx0h, a.W, lane);
                 const int* hints = a.sh_hints + (size_t)bb * (N + 2);
                 for (int k = lane; k <= N; k += CILQR_WAVE) l.ridx[k] = hints[k];
@@ -144,8 +149,8 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
                 cur_seq = seq;
             }
             double J1[1];
-            total_cost_trials<false, NCH, false, 1>(c2, l, al2, a.scratch + (size_t)bb * scratch_doubles(N), t, 1, lane, idx0h, 0,
-                                                    &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
+            total_cost_trials<false, NCH, false, 1>(c2, l, al2, a.scratch + (size_t)slot_b * scratch_doubles(N), t, 1, lane, idx0h,
+                                                    0, &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
             if (lane == 0) sh_st64(&rq->J[t], dm_to_bits(J1[0]));
             (void)sh_add_u(ctl + SH_HELPED, 1u, lane);
             worked = true;
@@ -201,19 +206,17 @@ enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 // of long horizons, where the LDS block of a trajectory would cap the CU at 5 wavefronts
 // SHARE = blocks that have finished help the ones still running with their line searches (ShareReq; lone wavefronts,
 // barrier mode, one trial per pass); switched on per launch by a.sh_ctl
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
-          bool SHARE = false>
-__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
-k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
-        double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
-        cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
-    if ((int)blockIdx.x >= a.B) return;
-    const int b = trajectory_of_block(blockIdx.x, a.B);
+// solve_one = the solve of trajectory b by the calling block; `slot` = which scratch area (slab, ...) it uses
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE>
+__device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const int slot, const double* __restrict__ x0,
+                                          const double* __restrict__ last_u, double* __restrict__ u_out,
+                                          double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
+                                          cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
+    const long long tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     static_assert(!SHARE || (!HELP && !ALM && !PROF && !DBG && NTP == 1), "work sharing: lone wavefronts, barrier mode");
     const bool share = SHARE && a.sh_ctl != nullptr;
-    if (share) (void)sh_add_u(a.sh_ctl + SH_STARTED, 1u, lane);
     const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
         if (share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
@@ -236,7 +239,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     Cst c;
     load_cst(c, a, b, l, lane);
     if (NC) c.N = NC;
-    double* scr = a.scratch + (size_t)b * scratch_doubles(N);
+    double* scr = a.scratch + (size_t)slot * scratch_doubles(N);
     if (LG) l.gl = scr + scratch_gl_offset(N);
     double* first = scr + slab_doubles(N); // the first-trial buffer
     AlmSt al = load_alm(a, b, N);
@@ -398,7 +401,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
                 if (SHARE && share && have_all && t0 >= a.sh_min_t0 && !sh_local &&
                     (sh_st != 0u || (CILQR_MAX_ALPHA_TRIALS - t0 >= CILQR_SH_MIN_OPEN &&
                                      __builtin_amdgcn_readfirstlane((int)sh_probe) != 0))) {
-                    sh_st = sh_owner_step(a.sh_ctl, rq, a.sh_hints + (size_t)b * (N + 2), l.ridx, &l.ctld[CTLD_JM], b, N, t0,
+                    sh_st = sh_owner_step(a.sh_ctl, rq, a.sh_hints + (size_t)b * (N + 2), l.ridx, &l.ctld[CTLD_JM], b, slot, N, t0,
                                           idx0, sh_seq, sh_st, lane);
                     foreign = (sh_st & SH_ST_FOREIGN) != 0u;
                     if (foreign) Jp[0] = l.ctld[CTLD_JM];
@@ -518,10 +521,46 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         r.trace_len = (trace_out && tl > trace_cap) ? trace_cap : tl;
         res_out[b] = r;
     }
-    if (SHARE && share) {
-        (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
-        // stay only when every block of the grid is running or done: then no block waits for this one's place
-        if (sh_ld_u(a.sh_ctl + SH_STARTED, lane) >= (unsigned)a.B) share_help<NCH, NC>(a, l, N, lane, b);
+    if (a.timeline && lane == 0) {
+        long long* tl_rec = a.timeline + 4 * (size_t)b;
+        tl_rec[0] = tl_start;
+        tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        tl_rec[2] = blockIdx.x;
+        tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
+    }
+    if (SHARE && share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
+}
+
+// The solve kernel.  Small batches: one block per trajectory (in the XCD-aware order above).  Large batches (a.next
+// set): PERSISTENT blocks — as many as the chip holds at once — that pull trajectories from a counter until none is
+// left.  The hardware's workgroup dispatcher hands blocks out in order, round-robin over the XCDs, and waits whenever
+// the XCD whose turn it is has no room: with solves of 1 to 8 ms a freed slot stood empty for 157 us (median; 7 % of
+// all slot time) before the next block began; pulling, the next solve begins 3 us after the last (measured with
+// cilqr_set_block_timeline, scripts/block_timeline.py: config 5 82.4 -> 75.8 ms).  Pulling also evens out the XCDs,
+// and a launch touches one scratch area per resident block instead of one per trajectory.  A block that finds no
+// trajectory left turns to the line searches of the blocks still running (SHARE builds).
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
+          bool SHARE = false>
+__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
+k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
+        double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
+        cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
+    const int lane = threadIdx.x & (CILQR_WAVE - 1);
+    const bool persistent = !HELP && a.next != nullptr;
+    if (!persistent && (int)blockIdx.x >= a.B) return;
+    for (;;) { // (one call site: a second inlined copy of the solve costs the loop ~70 spilled vector registers; out of
+               //  line, with the arguments on the stack, a solve takes 7 % longer)
+        const unsigned b = persistent ? sh_add_u(a.next, 1u, lane) : (unsigned)trajectory_of_block(blockIdx.x, a.B);
+        if (b >= (unsigned)a.B) break;
+        solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE>(a, (int)b, persistent ? (int)blockIdx.x : (int)b, x0, last_u,
+                                                                      u_out, x_out, res_out, trace_out, trace_cap);
+        if (!persistent) break;
+    }
+    if (SHARE && persistent && a.sh_ctl != nullptr) {
+        const int N = NC ? NC : a.N;
+        Lds l;
+        carve(l, g_lds, N, a.W, ALM ? 1 : 0, (HELP || NTP == 2) ? 2 : 1, LG ? 1 : 0);
+        share_help<NCH, NC>(a, l, N, lane, (int)blockIdx.x);
     }
 }
 
@@ -829,8 +868,13 @@ struct cilqr_handle {
     int occ_floor_pct = 0;    // smallest lane window the occupancy-driven choice accepts, in % of the horizon's reach (never
                               // below 64 samples).  Round 2: occupancy beats the window — horizon 100 went from 4 blocks per
                               // CU with a 912-sample window to 6 with 64 samples: +18 %; horizon 50 fits 8 blocks either way
+    int persistent_blocks = 1; // large batches: as many blocks as fit on the chip pull trajectories (0: one block each)
+    int num_cus = 256;
     int share_backoff = 4;
     int share_max_helpers = 64, share_min_t0 = 1; // (measured: 64 helpers serve the few open searches of a launch's tail; 2048 polling blocks cost 9-16 %)
+    bool timeline = false;     // record a block timeline with the next solves (development aid)
+    DevBuf tl;
+    int tl_B = 0;
     bool last_launch_shared = false;
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
     DevBuf sh_ctl, sh_req, sh_hints;
@@ -925,9 +969,15 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "share_max_helpers") h->share_max_helpers = v;
                 else if (k == "share_min_t0") h->share_min_t0 = v;
                 else if (k == "share_backoff") h->share_backoff = v;
+                else if (k == "persistent_blocks") h->persistent_blocks = v;
             }
             pos = e + 1;
         }
+    }
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     }
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
@@ -955,6 +1005,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     h->d_scenes.release();
     h->scratch.release();
     h->sh_ctl.release(); h->sh_req.release(); h->sh_hints.release();
+    h->tl.release();
     h->alm_mu.release();
     h->alm_mu_next.release();
     h->alm_rho.release();
@@ -978,6 +1029,21 @@ extern "C" int cilqr_set_timing(cilqr_handle* h, int32_t enabled) {
 extern "C" int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     h->profiling = enabled != 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_block_timeline(cilqr_handle* h, int32_t enabled) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    h->timeline = enabled != 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_get_block_timeline(cilqr_handle* h, int64_t* out, int32_t B) {
+    if (!h || !out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    if (!h->tl.p || B < 1 || B > h->tl_B) return fail(CILQR_ERR_BAD_ARG, "no timeline recorded for that batch");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->tl.p, sizeof(long long) * 4 * (size_t)B, hipMemcpyDeviceToHost));
     return CILQR_OK;
 }
 
@@ -1345,6 +1411,8 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.sh_max_helpers = h->share_max_helpers;
     a.sh_min_t0 = h->share_min_t0 < 1 ? 1 : h->share_min_t0;
     a.sh_backoff = h->share_backoff < 0 ? 0 : (h->share_backoff > 8 ? 8 : h->share_backoff);
+    a.timeline = nullptr;
+    a.next = nullptr;
     return a;
 }
 
@@ -1399,16 +1467,19 @@ static int ensure_scratch(cilqr_handle* h, int B) {
     }
     if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
-    // work sharing between blocks (builds of horizons above 63, barrier mode): counters and slots, one request and
-    // one row of hints per trajectory
-    if (two_rows(h) && h->params[0].solve_type != 1 && (B > h->sh_B || N != h->sh_N || !h->sh_ctl.p)) {
+    // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
+    if (!h->sh_ctl.p) {
+        if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS)) return fail(CILQR_ERR_DEVICE, "hipMalloc control words");
+        HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
+    }
+    // work sharing between blocks (builds of horizons above 63, barrier mode): one request and one row of hints per
+    // trajectory
+    if (two_rows(h) && h->params[0].solve_type != 1 && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
         HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
         h->sh_req.release(); h->sh_hints.release();
-        if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS) || h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) ||
-            h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
+        if (h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) || h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc work-sharing state");
         HIP_TRY(hipMemset(h->sh_req.p, 0xff, sizeof(ShareReq) * (size_t)B)); // every request closed (next = 255)
-        HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
         h->sh_B = B;
         h->sh_N = N;
     }
@@ -1439,6 +1510,12 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         a.prof = static_cast<long long*>(h->prof.p);
         h->prof_B = B;
     }
+    if (h->timeline) {
+        if (h->tl.ensure(sizeof(long long) * 4 * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc timeline");
+        HIP_TRY(hipMemsetAsync(h->tl.p, 0, sizeof(long long) * 4 * (size_t)B, s));
+        a.timeline = static_cast<long long*>(h->tl.p);
+        h->tl_B = B;
+    }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     {
         const bool two = (a.N + 1 > CILQR_WAVE);
@@ -1446,11 +1523,11 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool help = wants_helper(h, B);
         // `one` = the variant costs one trial per pass without a helper: one stage-cost slot in LDS (k_solve's SLOTS)
         auto kern = k_solve<false, 1, false, false, false>;
-        bool one = false, lg = false;
+        bool one = false, lg = false, persistent = false;
         h->last_launch_shared = false;
         if (a.alm) {
             if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
-            else if (lone_two_per_simd(h, B)) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; }
+            else if (lone_two_per_simd(h, B)) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; persistent = true; }
             else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
         } else if (a.flags != 0) {
             kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
@@ -1474,11 +1551,11 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
                 lg = true;
             }
             one = true;
-            if (h->share && two && h->sh_ctl.p) {
+            persistent = true;
+            if (h->share && two && h->sh_req.p) {
                 a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
                 a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
                 a.sh_hints = static_cast<int*>(h->sh_hints.p);
-                HIP_TRY(hipMemsetAsync(a.sh_ctl, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
                 h->last_launch_shared = true;
             }
         } else {
@@ -1487,7 +1564,22 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         const bool helped = help && (a.alm || a.flags == 0);
         if (one != single_slot(h, B)) return fail(CILQR_ERR_DEVICE, "internal: kernel variant / LDS layout mismatch");
         const size_t shm = lds_bytes(a.N, a.W, a.alm, one ? 1 : 2, lg ? 1 : 0);
-        hipLaunchKernelGGL(kern, dim3(B), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
+        int grid = B;
+        if (persistent && h->persistent_blocks) {
+            // as many blocks as the chip holds at once; they pull trajectories from the counter
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CILQR_WAVE, shm));
+            const int cap = (per_cu > 0 ? per_cu : 1) * h->num_cus;
+            grid = B < cap ? B : cap;
+            a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
+            HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+        } else {
+            a.sh_ctl = nullptr; // (the work sharing rides on the persistent blocks)
+            a.sh_req = nullptr;
+            a.sh_hints = nullptr;
+            h->last_launch_shared = false;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }
     HIP_TRY(hipGetLastError());

@@ -1142,9 +1142,9 @@ __device__ inline void restore_gains_head(const Lds& l, const double* first, int
 
 // ---------------------------------------------------------------------------------------------
 // Work sharing between blocks (k_solve's SHARE).  A launch ends with a few long line searches on a mostly idle
-// chip: the last trajectories each cost their 20 trial trajectories one after the other.  Blocks that have finished
-// their own trajectory — once every block of the grid has started, so that staying resident keeps nobody out —
-// therefore stay and cost open trials of the blocks still running.  A cost is a pure function of the trial
+// chip: the last trajectories each cost their 20 trial trajectories one after the other.  Blocks that find no
+// trajectory left to pull (the large-batch builds run persistent blocks, k_solve) therefore stay and cost open trials
+// of the blocks still running.  A cost is a pure function of the trial
 // trajectory (in the global slab), the trajectory's tables and the row-0 lane index, so whoever computes it
 // computes the same bits; the search's verdicts are still taken in order by the owner.
 //
@@ -1161,12 +1161,14 @@ __device__ inline void restore_gains_head(const Lds& l, const double* first, int
 struct ShareReq {
     unsigned claim;
     int idx0;       // row-0 lane index of the trajectory (= first sample of its lane window)
-    int pad0, pad1;
+    int slot;       // which scratch area holds its slab (the owner block's)
+    int pad1;
     unsigned long long J[CILQR_MAX_ALPHA_TRIALS];
     unsigned long long pad2[2];
 };
 static_assert(sizeof(ShareReq) == 192, "ShareReq layout");
-enum { SH_STARTED = 0, SH_FINISHED = 1, SH_HELPERS = 2, SH_ERROR = 3, SH_ANNOUNCED = 4, SH_HELPED = 5, SH_SLOT0 = 8 };
+enum { SH_NEXT = 0 /* persistent blocks: the next trajectory */, SH_FINISHED = 1, SH_HELPERS = 2, SH_ERROR = 3, SH_ANNOUNCED = 4,
+       SH_HELPED = 5, SH_SLOT0 = 8 };
 #define CILQR_SH_NSLOT 64
 #define CILQR_SH_WORDS (SH_SLOT0 + CILQR_SH_NSLOT)
 #define CILQR_SH_PENDING 0x7ff8c11a5ea7ed00ULL /* a NaN no arithmetic produces */
@@ -1208,11 +1210,11 @@ __device__ inline void sh_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "
 __device__ inline void sh_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 // owner: announce the search whose trials t0 .. 19 sit in the slab; the owner keeps t0 and t0 + 1.  false = no slot free
-__device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx, int b, int N, int t0, int idx0,
-                               unsigned seq, int lane) {
+__device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx, int b, int slot, int N, int t0,
+                               int idx0, unsigned seq, int lane) {
     for (int k = lane; k <= N; k += CILQR_WAVE) hints[k] = ridx[k];
     if (lane < CILQR_MAX_ALPHA_TRIALS) rq->J[lane] = CILQR_SH_PENDING;
-    if (lane == 0) rq->idx0 = idx0;
+    if (lane == 0) { rq->idx0 = idx0; rq->slot = slot; }
     sh_release(); // the slab, the hints and the marks are out before the claim word opens
     const unsigned own = (unsigned)((t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS);
     if (lane == 0) sh_st(&rq->claim, (seq << 16) | own);
@@ -1261,11 +1263,11 @@ __device__ inline bool sh_await(unsigned* ctl, ShareReq* rq, int t, int lane, do
 #define SH_ST_PLACED 2u
 #define SH_ST_FOREIGN 0x80000000u
 __device__ __attribute__((noinline)) unsigned sh_owner_step(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx,
-                                                            double* Jout, int b, int N, int t0, int idx0, unsigned seq,
-                                                            unsigned st, int lane) {
+                                                            double* Jout, int b, int slot, int N, int t0, int idx0,
+                                                            unsigned seq, unsigned st, int lane) {
     st &= ~SH_ST_FOREIGN;
     if (!(st & SH_ST_ON)) {
-        const bool placed = sh_open(ctl, rq, hints, ridx, b, N, t0, idx0, seq, lane);
+        const bool placed = sh_open(ctl, rq, hints, ridx, b, slot, N, t0, idx0, seq, lane);
         const int own0 = (t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS;
         st = SH_ST_ON | (placed ? SH_ST_PLACED : 0u) | ((unsigned)own0 << 8);
     }

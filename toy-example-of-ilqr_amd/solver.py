@@ -170,6 +170,15 @@ class BatchedCILQR:
         check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
 
 
+    def set_block_timeline(self, on=True):
+        check(self._lib.cilqr_set_block_timeline(self._h, 1 if on else 0), "cilqr_set_block_timeline")
+
+    def block_timeline(self, B):
+        """[B][4] int64: start, end (100 MHz ticks), block index, XCC of the block that solved each trajectory"""
+        out = np.zeros((B, 4), dtype=np.int64)
+        check(self._lib.cilqr_get_block_timeline(self._h, _p(out), int(B)), "cilqr_get_block_timeline")
+        return out
+
     def set_work_sharing(self, mode):
         """1 (default): finished blocks cost line-search trials of the trajectories still being solved (horizons
         above 63, barrier mode, large batches); 0: off.  Same results either way."""
