@@ -267,11 +267,13 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
             valu = {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
                     "frac_of_issue_slots": pmc["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * kernel_ms * 1e-3),
                     "source": "SQ_INSTS_VALU of the same file; 256 CUs x 4 SIMDs, 4 cycles per wave64 "
-                              "instruction, 2.4 GHz nominal (the clock under this FP64 load is lower: DESIGN.md)"}
+                              "instruction, 2.4 GHz (rocm-smi shows 2.36 GHz at ~900 W under this load)"}
             if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_WAVE_CYCLES"):
-                # clock-independent: share of a resident wave's cycles in which it executes a vector instruction;
-                # large batches keep two waves on every SIMD, so the SIMD's VALU is busy about twice that share
+                # share of a resident wave's cycles in which it executes a vector instruction, and how many waves are
+                # resident on average (SQ_WAVE_CYCLES counts quad-cycles; the chip holds 2048 waves of the
+                # large-batch build, two per SIMD): SIMD VALU busy = share x resident waves / 1024
                 valu["valu_active_share_of_wave_cycles"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"]
+                valu["mean_resident_waves"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (2.36e9 * kernel_ms * 1e-3)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_solve", "kernel_ms": kernel_ms,
