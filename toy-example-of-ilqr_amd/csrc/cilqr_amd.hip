@@ -1459,13 +1459,18 @@ static int ensure_alm(cilqr_handle* h, int B) {
     return CILQR_OK;
 }
 
-static int ensure_scratch(cilqr_handle* h, int B) {
+// fused = for the fused solve: its large-batch launches run persistent blocks, which use one scratch area per
+// resident block (at most 8 per CU) instead of one per trajectory
+static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     const int N = h->params[0].N;
     {
         int rc_alm = ensure_alm(h, B);
         if (rc_alm) return rc_alm;
     }
-    if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * (size_t)B))
+    size_t areas = (size_t)B;
+    if (fused && h->persistent_blocks && lone_two_per_simd(h, B) && (h->params[0].solve_type == 1 || (h->debug_flags == 0 && !h->profiling)))
+        areas = std::min<size_t>(areas, (size_t)8 * (size_t)h->num_cus);
+    if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
     // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
     if (!h->sh_ctl.p) {
@@ -1499,7 +1504,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     if (B < 1 || !d_x0 || !d_u_out || !d_x_out) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
     if (trace_cap < 0) return fail(CILQR_ERR_BAD_ARG, "trace_cap < 0");
     HIP_TRY(hipSetDevice(h->device));
-    rc = ensure_scratch(h, B);
+    rc = ensure_scratch(h, B, true);
     if (rc) return rc;
     Staged ids;
     ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
@@ -1579,6 +1584,8 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             a.sh_hints = nullptr;
             h->last_launch_shared = false;
         }
+        if (h->scratch.cap < sizeof(double) * scratch_doubles(a.N) * (size_t)(a.next ? grid : B))
+            return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
     }
