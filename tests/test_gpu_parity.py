@@ -776,6 +776,34 @@ def test_long_horizon_builds_across_horizons(pkg, orc_det, N, B):
         assert np.array_equal(a["res"][f][sel], ref["res"][f]), (N, f)
 
 
+def test_block_timeline_of_persistent_blocks(pkg):
+    """The development aid behind DESIGN.md's "filling the chip": every trajectory gets one record (start < end, the
+    block that solved it, its XCC); a large batch is solved by at most 8 blocks per CU that each pull several
+    trajectories, a small one by one block per trajectory; results do not depend on the recording."""
+    wl = pkg.workloads.config3(B=6000)
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    ref = eng.solve_batch(wl.x0)
+    eng.set_block_timeline(True)
+    out = eng.solve_batch(wl.x0)
+    tl = eng.block_timeline(wl.B)
+    small = eng.solve_batch(wl.x0[:300])
+    tl_small = eng.block_timeline(300)
+    eng.close()
+    eq_bits(ref["x"], out["x"], "x with the timeline on")
+    eq_bits(ref["x"][:300], small["x"], "x of the small batch")
+    assert (tl[:, 1] > tl[:, 0]).all() and (tl[:, 0] > 0).all()
+    assert ((tl[:, 3] >= 0) & (tl[:, 3] < 8)).all() and len(set(tl[:, 3].tolist())) == 8
+    blocks = np.unique(tl[:, 2])
+    assert 256 <= len(blocks) <= 2048 and blocks.max() < 2048      # persistent blocks: as many as the chip holds
+    per_block = np.bincount(tl[:, 2].astype(np.int64))
+    assert per_block.max() >= 2                                    # ... each solving several trajectories
+    # a block's solves do not overlap in time
+    order = np.lexsort((tl[:, 0], tl[:, 2]))
+    same = tl[order][1:, 2] == tl[order][:-1, 2]
+    assert (tl[order][1:, 0][same] >= tl[order][:-1, 1][same]).all()
+    assert len(np.unique(tl_small[:, 2])) == 300                   # helper range: one block per trajectory
+
+
 def test_rollout_policy_statistics(pkg, engines):
     """the adaptive policy's bookkeeping (in-kernel counters): every line search starts with exactly one rollout
     pass, second passes happen only after a rejected first trial, and on the benchmark-like batch the slab is
