@@ -64,6 +64,14 @@ def parse():
 
 
 def make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank):
+    w, B = _make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank)
+    if os.environ.get("CILQR_BENCH_ALM") == "1":  # the same batch with the augmented-Lagrangian solve type (not a BASELINE config)
+        w = pkg.workloads.Workload(w.name + "_alm", [pkg.copy_params(q, solve_type=1) for q in w.params], w.scenes, w.x0,
+                                   w.scenario_id, w.param_id, w.tick)
+    return w, B
+
+
+def _make_workload(pkg, cfg_id, per_gpu_batch, horizon, rank):
     wl = pkg.workloads
     if cfg_id == 2:
         B = per_gpu_batch or 1024

@@ -347,7 +347,7 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         double dV[2];
-        bool ok = backward_sweep<(DBG && !ALM), LG>(c, l, lamb, lane, dV, a.flags);
+        bool ok = backward_sweep<(DBG && !ALM), LG ? (ALM ? CILQR_GL_ROW_ALM : CILQR_GL_ROW) : 0>(c, l, lamb, lane, dV, a.flags);
         wave_sync();
         PROF_ADD(PH_BACKWARD);
         double new_J = J_cur;
@@ -1374,12 +1374,14 @@ static bool single_slot(const cilqr_handle* h, int B) {
 
 // does this batch run a build that keeps the cost expansion in global memory (k_solve's LG)?
 static bool global_expansion(const cilqr_handle* h, int B) {
-    if (!single_slot(h, B) || h->params[0].solve_type == 1 || h->global_expansion == 0) return false;
+    if (!single_slot(h, B) || h->global_expansion == 0) return false;
     const int N = h->params[0].N;
+    const int alm = h->params[0].solve_type == 1 ? 1 : 0;
     if (N + 1 <= CILQR_WAVE) return false; // (builds exist for two rows per lane only; shorter horizons fit anyway)
     // worth it where the LDS block with the expansion inside keeps a CU from holding the 8 wavefronts its registers
-    // allow (N >= 76): measured +30-40 % at N = 100, +6 % at N = 80, -5 % at N = 64 where nothing is gained
-    return h->global_expansion == 1 || lds_bytes(N, 64, 0, 1, 0) * 8 > 163840;
+    // allow (barrier mode: N >= 76; augmented Lagrangian, whose dense l_xx makes the block larger: every horizon
+    // above 63): measured +30-40 % at N = 100, +6 % at N = 80, -5 % at N = 64 (barrier) where nothing is gained
+    return h->global_expansion == 1 || lds_bytes(N, 64, alm, 1, 0) * 8 > 163840;
 }
 
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
@@ -1532,7 +1534,12 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         h->last_launch_shared = false;
         if (a.alm) {
             if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
-            else if (lone_two_per_simd(h, B)) { kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>; one = true; persistent = true; }
+            else if (lone_two_per_simd(h, B)) {
+                kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>;
+                if (global_expansion(h, B)) { kern = k_solve<true, 2, true, false, false, 2, 1, 0, true>; lg = true; }
+                one = true;
+                persistent = true;
+            }
             else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
         } else if (a.flags != 0) {
             kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;

@@ -184,10 +184,18 @@ __host__ __device__ inline int kd_doubles(int N, int slots) {
 #define CILQR_GL_LUU 12
 #define CILQR_GL_LXX22 14
 #define CILQR_GL_ZERO 15
-// The sweep reads them through a ring of 8 rows in LDS that is refilled four rows (= 64 doubles, one per lane) at a
-// time: the global load of a chunk is issued four steps before its rows are needed and costs two instructions.
-#define CILQR_GL_CHUNK 4
-#define CILQR_GL_RING (2 * CILQR_GL_CHUNK * CILQR_GL_ROW)
+// augmented-Lagrangian builds (l_xx dense, 16 entries): one 256-byte row per step,
+//   0-3 l_x | 4-5 l_u | 6-7 l_uu diagonal | 8-23 l_xx row-major | 24 zero | 25-31 unused
+#define CILQR_GL_ROW_ALM 32
+#define CILQR_GLA_LX 0
+#define CILQR_GLA_LU 4
+#define CILQR_GLA_LUU 6
+#define CILQR_GLA_LXX 8
+#define CILQR_GLA_ZERO 24
+// The sweep reads them through a ring of 128 doubles in LDS (8 rows, or 4 of the 256-byte rows) that is refilled 64
+// doubles — one per lane, four rows or two — at a time: the global load of a chunk is issued a chunk's steps before its
+// rows are needed and costs two instructions.
+#define CILQR_GL_RING 128
 __host__ __device__ inline int lds_doubles(int N, int alm, int slots, int lg = 0) {
     const int expansion = lg ? CILQR_GL_RING : 4 * (N + 1) + 2 * N + (alm ? 16 : 7) * (N + 1) + 2 * N;
     return 4 * (N + 1) + 2 * N + kd_doubles(N, slots) + expansion + CILQR_XCH + CILQR_CTLD + CILQR_CSTK_DOUBLES + CILQR_PROF_SLOTS;
@@ -270,7 +278,7 @@ __host__ __device__ inline size_t scratch_gl_offset(int N) { // rows of the cost
     return (head + 15) / 16 * 16;
 }
 __host__ __device__ inline size_t scratch_doubles(int N) {
-    return scratch_gl_offset(N) + (size_t)CILQR_GL_ROW * (size_t)(N + 1);
+    return scratch_gl_offset(N) + (size_t)CILQR_GL_ROW_ALM * (size_t)(N + 1); // (sized for the wider, ALM rows)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1378,7 +1386,6 @@ __device__ inline void model_jacobians(const Cst& c, const Lds& l, int lane) {
 // LG = true (barrier mode only): the expansion goes to the 128-byte rows of l.gl in global memory (CILQR_GL_ROW)
 template <bool ALM, bool LG = false>
 __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
-    static_assert(!(ALM && LG), "the global-memory expansion is built for barrier mode");
     const int N = c.N;
     gdouble_w* const grows = LG ? (gdouble_w*)l.gl : nullptr;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
@@ -1412,10 +1419,18 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
                 sl[j] = alm_slope(cv[j], rho, mu[j]);
                 mun[j] = alm_next_mu(c, mu[j], rho, cv[j]);
             }
-            l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + (sl[0] - sl[1]);
-            l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + (sl[2] - sl[3]);
-            l.luu[2 * (k - 1)] = 2 * c.k->w_acc + (sl[0] + sl[1]);
-            l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + (sl[2] + sl[3]);
+            if (LG) {
+                gdouble_w* rm = grows + (size_t)CILQR_GL_ROW_ALM * (k - 1);
+                rm[CILQR_GLA_LU] = 2 * (um0 * c.k->w_acc) + (sl[0] - sl[1]);
+                rm[CILQR_GLA_LU + 1] = 2 * (um1 * c.k->w_stl) + (sl[2] - sl[3]);
+                rm[CILQR_GLA_LUU] = 2 * c.k->w_acc + (sl[0] + sl[1]);
+                rm[CILQR_GLA_LUU + 1] = 2 * c.k->w_stl + (sl[2] + sl[3]);
+            } else {
+                l.lu[2 * (k - 1)] = 2 * (um0 * c.k->w_acc) + (sl[0] - sl[1]);
+                l.lu[2 * (k - 1) + 1] = 2 * (um1 * c.k->w_stl) + (sl[2] - sl[3]);
+                l.luu[2 * (k - 1)] = 2 * c.k->w_acc + (sl[0] + sl[1]);
+                l.luu[2 * (k - 1) + 1] = 2 * c.k->w_stl + (sl[2] + sl[3]);
+            }
             double px = e0 / hyp, py = e1 / hyp;
             if (d_sign < 0) { px = -px; py = -py; }
             const double nx = -px, ny = -py;
@@ -1529,6 +1544,21 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
                 h13 = h13 + (sf * (t.gf[1] * t.gf[2]) + srr * (t.gr[1] * t.gr[2]));
                 h33 = h33 + (sf * (t.gf[2] * t.gf[2]) + srr * (t.gr[2] * t.gr[2]));
             }
+        }
+        if (LG && ALM) {
+            gdouble_w* r = grows + (size_t)CILQR_GL_ROW_ALM * k;
+            r[CILQR_GLA_LX] = lx0 + b0;
+            r[CILQR_GLA_LX + 1] = lx1 + b1;
+            r[CILQR_GLA_LX + 2] = lx2 + b2;
+            r[CILQR_GLA_LX + 3] = lx3 + b3;
+            gdouble_w* hx = r + CILQR_GLA_LXX;
+            hx[0] = 2 * c.k->w_pos + h00; hx[1] = 0.0 + h01; hx[2] = 0.0; hx[3] = 0.0 + h03;
+            hx[4] = 0.0 + g10; hx[5] = 2 * c.k->w_pos + h11; hx[6] = 0.0; hx[7] = 0.0 + h13;
+            hx[8] = 0.0; hx[9] = 0.0; hx[10] = 2 * c.k->w_vel + h22; hx[11] = 0.0;
+            hx[12] = 0.0 + g30; hx[13] = 0.0 + g31; hx[14] = 0.0; hx[15] = 2 * c.k->w_yaw + h33;
+            r[CILQR_GLA_ZERO] = 0.0;
+            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
+            continue;
         }
         if (LG) {
             gdouble_w* r = grows + (size_t)CILQR_GL_ROW * k;
@@ -1757,8 +1787,16 @@ __device__ inline void lane_map_M(const Lds& l, int k, int j, int& off, int& str
 }
 
 // the same for an expansion held in the rows of l.gl: slots (doubles) inside the 128-byte row of a step
+template <int ROWD>
 __device__ inline void lane_map_gl(int lane, int& slot_q, int& slot_v) {
     const int rp = (lane >> 3) % 6, cc = lane & 7;
+    if (ROWD == CILQR_GL_ROW_ALM) { // dense l_xx
+        slot_q = CILQR_GLA_ZERO;
+        if (rp < 4 && cc < 4) slot_q = CILQR_GLA_LXX + 4 * rp + cc;
+        else if (rp >= 4 && cc == rp) slot_q = CILQR_GLA_LUU + (rp - 4);
+        slot_v = (rp < 4) ? CILQR_GLA_LX + rp : CILQR_GLA_LU + (rp - 4);
+        return;
+    }
     slot_q = CILQR_GL_ZERO;
     if (rp < 4 && cc < 4) {
         const int a = (rp < cc) ? rp : cc, b = (rp < cc) ? cc : rp;
@@ -1865,20 +1903,23 @@ __device__ inline double lane_bcast(double v) {
 __device__ inline double gl_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int row_off) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, row_off, 0));
 }
-template <bool LG = false>
+// ROWD = doubles per row of the expansion in global memory (CILQR_GL_ROW, CILQR_GL_ROW_ALM), 0 = expansion in LDS
+template <int ROWD = 0>
 __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
                                             int* fail_step = nullptr) {
+    constexpr bool LG = ROWD != 0;
+    constexpr int GL_CHUNK = LG ? CILQR_WAVE / ROWD : 4; // rows per chunk of 64 doubles
     const int N = c.N;
     const int rp = (lane >> 3) % 6, cc = lane & 7;
     const double* const base = l.x;
     LaneMap mp;
     make_lane_map<LG>(l, lane, mp);
-    constexpr int ROWB = CILQR_GL_ROW * (int)sizeof(double);
+    constexpr int ROWB = (LG ? ROWD : CILQR_GL_ROW) * (int)sizeof(double);
     __amdgpu_buffer_rsrc_t grs;
     unsigned goq = 0, gov = 0;
     if (LG) {
         int sq, sv;
-        lane_map_gl(lane, sq, sv);
+        lane_map_gl<ROWD>(lane, sq, sv);
         goq = 8u * (unsigned)sq;
         gov = 8u * (unsigned)sv;
         grs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(l.gl), 0, (N + 1) * ROWB, 0x00020000);
@@ -1919,23 +1960,23 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     unsigned alq = lds_addr(base + mp.lq + mp.slq * (N - 1));
     unsigned alv = lds_addr(base + mp.lv + mp.slv * (N - 1));
     const unsigned dlq = 8u * (unsigned)mp.slq, dlv = 8u * (unsigned)mp.slv;
-    constexpr int CHB = CILQR_GL_CHUNK * ROWB; // bytes per chunk
+    constexpr int CHB = GL_CHUNK * ROWB; // bytes per chunk (512)
     double chunk = 0.0;                        // this lane's double of the chunk in flight
     unsigned rq = 0, rv = 0;                   // this lane's two read addresses inside ring row 0
     if (LG) {
-        const int c0 = (N - 1) / CILQR_GL_CHUNK;
+        const int c0 = (N - 1) / GL_CHUNK;
         // (rows past N - 1 of the first chunk are not used; reads past row N return zero: the descriptor ends there)
         const double first = gl_load(grs, 8u * (unsigned)lane, c0 * CHB);
-        ((double*)l.ring)[(c0 & 1) * (CILQR_GL_CHUNK * CILQR_GL_ROW) + lane] = first;
+        ((double*)l.ring)[(c0 & 1) * CILQR_WAVE + lane] = first;
         if (c0 > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (c0 - 1) * CHB);
         rq = lds_addr(l.ring) + goq;
         rv = lds_addr(l.ring) + gov;
     }
     for (int i = N - 1; i >= 0; --i) {
-        if (LG && (i & (CILQR_GL_CHUNK - 1)) == CILQR_GL_CHUNK - 1 && i != N - 1) {
+        if (LG && (i & (GL_CHUNK - 1)) == GL_CHUNK - 1 && i != N - 1) {
             // the sweep enters chunk c: its rows arrived while chunk c + 1 was computed; fetch chunk c - 1
-            const int cch = i / CILQR_GL_CHUNK;
-            ((double*)l.ring)[(cch & 1) * (CILQR_GL_CHUNK * CILQR_GL_ROW) + lane] = chunk;
+            const int cch = i / GL_CHUNK;
+            ((double*)l.ring)[(cch & 1) * CILQR_WAVE + lane] = chunk;
             if (cch > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (cch - 1) * CHB);
         }
         // per-lane coefficients of this step (issued together with the cross-lane moves of pass 1, whose
@@ -1950,7 +1991,7 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         }
         double Lq, lv;
         if (LG) {
-            const unsigned ro = (unsigned)(i & (2 * CILQR_GL_CHUNK - 1)) * (unsigned)ROWB; // wave-uniform
+            const unsigned ro = (unsigned)(i & (2 * GL_CHUNK - 1)) * (unsigned)ROWB; // wave-uniform
             Lq = lds_load(rq + ro);
             lv = lds_load(rv + ro);
         } else {
@@ -2043,12 +2084,12 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     return true;
 }
 
-template <bool DBG, bool LG = false>
+template <bool DBG, int ROWD = 0>
 __device__ inline bool backward_sweep(const Cst& c, const Lds& l, double lamb, int lane, double dV[2], int flags,
                                       int* fail_step = nullptr) {
-    static_assert(!(DBG && LG), "the wave-uniform twin reads the expansion from LDS");
+    static_assert(!(DBG && ROWD != 0), "the wave-uniform twin reads the expansion from LDS");
     if (DBG && (flags & CILQR_DBG_UNIFORM_BACKWARD)) return backward_sweep_uniform(c, l, lamb, lane, dV, fail_step);
-    return backward_sweep_lanes<LG>(c, l, lamb, lane, dV, fail_step);
+    return backward_sweep_lanes<ROWD>(c, l, lamb, lane, dV, fail_step);
 }
 
 
