@@ -188,9 +188,9 @@ int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next,
  * 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
 
-/* Work sharing between blocks (horizons above 63, barrier mode, batches beyond the helper range): 1 (default) = blocks
- * whose trajectory is done stay — once every block of the launch has started — and cost line-search trials of the
- * trajectories still being solved; 0 = off.  A cost is a function of the trial trajectory alone, so the results
+/* Work sharing between blocks (horizons above 63, batches beyond the helper range): 1 (default) = blocks that find no
+ * trajectory left to solve (large batches run persistent blocks that pull trajectories from a counter) cost
+ * line-search trials of the trajectories still being solved; 0 = off.  A cost is a function of the trial trajectory alone, so the results
  * are identical either way; what changes is how long a launch waits for its slowest trajectories. */
 int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode);
 /* Counters of the last launch that shared work (waits for the device): out = { line searches announced, trial costs

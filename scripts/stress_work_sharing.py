@@ -29,7 +29,13 @@ def main():
             wl = pkg.workloads.config3(B=B, first=int(rng.integers(0, 50000)))
             wl = pkg.workloads.Workload(wl.name, [pkg.copy_params(q, N=N, max_iter=int(rng.integers(5, 60))) for q in wl.params],
                                         wl.scenes, wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+        alm = rng.integers(0, 4) == 0  # every fourth launch with the augmented-Lagrangian solve type
+        if alm:
+            wl = pkg.workloads.Workload(wl.name + "_alm", [pkg.copy_params(q, solve_type=1) for q in wl.params], wl.scenes, wl.x0,
+                                        wl.scenario_id, wl.param_id, wl.tick)
         eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+        if alm:
+            eng.set_helper_mode(0)  # lone wavefronts whatever the batch: the builds that share work
         ref = None
         for rep in range(3):
             for mode in (1, 0, 1):

@@ -106,7 +106,7 @@ __device__ inline bool ids_valid(const BatchArgs& a, int b) {
 // until every trajectory of the launch has finished.  `me` only spreads the helpers over the open searches.
 // (not inlined: it runs once, after the solve, with nothing live — inlined, its copy of the trial costing costs the
 //  solve loop 27 more spilled vector registers)
-template <int NCH, int NC>
+template <int NCH, int NC, bool ALM>
 __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, int lane, int me) {
     unsigned* const ctl = a.sh_ctl;
     if (sh_add_u(ctl + SH_HELPERS, 1u, lane) >= (unsigned)a.sh_max_helpers) return; // enough of them already
@@ -141,6 +141,10 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
                 wave_sync();
                 idx0h = rq->idx0;
                 slot_b = rq->slot; // the owner block's scratch area (its slab)
+                if (ALM) { // the owner's multipliers (global memory) and its penalty weight of this search
+                    al2 = load_alm(a, bb, N);
+                    al2.rho = dm_from_bits(rq->rho_bits);
+                }
                 stage_window(c2, l, idx0h, a.W, lane);
                 const int* hints = a.sh_hints + (size_t)bb * (N + 2);
                 for (int k = lane; k <= N; k += CILQR_WAVE) l.ridx[k] = hints[k];
@@ -149,8 +153,8 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
                 cur_seq = seq;
             }
             double J1[1];
-            total_cost_trials<false, NCH, false, 1>(c2, l, al2, a.scratch + (size_t)slot_b * scratch_doubles(N), t, 1, lane, idx0h,
-                                                    0, &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
+            total_cost_trials<false, NCH, ALM, 1>(c2, l, al2, a.scratch + (size_t)slot_b * scratch_doubles(N), t, 1, lane, idx0h,
+                                                  0, &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
             if (lane == 0) sh_st64(&rq->J[t], dm_to_bits(J1[0]));
             (void)sh_add_u(ctl + SH_HELPED, 1u, lane);
             worked = true;
@@ -215,7 +219,7 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
     const long long tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    static_assert(!SHARE || (!HELP && !ALM && !PROF && !DBG && NTP == 1), "work sharing: lone wavefronts, barrier mode");
+    static_assert(!SHARE || (!HELP && !PROF && NTP == 1), "work sharing: lone wavefronts costing one trial per pass");
     const bool share = SHARE && a.sh_ctl != nullptr;
     const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
@@ -402,7 +406,7 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
                     (sh_st != 0u || (CILQR_MAX_ALPHA_TRIALS - t0 >= CILQR_SH_MIN_OPEN &&
                                      __builtin_amdgcn_readfirstlane((int)sh_probe) != 0))) {
                     sh_st = sh_owner_step(a.sh_ctl, rq, a.sh_hints + (size_t)b * (N + 2), l.ridx, &l.ctld[CTLD_JM], b, slot, N, t0,
-                                          idx0, sh_seq, sh_st, lane);
+                                          idx0, ALM ? dm_to_bits(al.rho) : 0ULL, sh_seq, sh_st, lane);
                     foreign = (sh_st & SH_ST_FOREIGN) != 0u;
                     if (foreign) Jp[0] = l.ctld[CTLD_JM];
                 }
@@ -560,7 +564,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
         const int N = NC ? NC : a.N;
         Lds l;
         carve(l, g_lds, N, a.W, ALM ? 1 : 0, (HELP || NTP == 2) ? 2 : 1, LG ? 1 : 0);
-        share_help<NCH, NC>(a, l, N, lane, (int)blockIdx.x);
+        share_help<NCH, NC, ALM>(a, l, N, lane, (int)blockIdx.x);
     }
 }
 
@@ -1481,7 +1485,7 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     }
     // work sharing between blocks (builds of horizons above 63, barrier mode): one request and one row of hints per
     // trajectory
-    if (two_rows(h) && h->params[0].solve_type != 1 && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
+    if (two_rows(h) && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
         HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
         h->sh_req.release(); h->sh_hints.release();
         if (h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) || h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
@@ -1536,9 +1540,15 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
             else if (lone_two_per_simd(h, B)) {
                 kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>;
-                if (global_expansion(h, B)) { kern = k_solve<true, 2, true, false, false, 2, 1, 0, true>; lg = true; }
+                if (global_expansion(h, B)) { kern = k_solve<true, 2, true, false, false, 2, 1, 0, true, true>; lg = true; }
                 one = true;
                 persistent = true;
+                if (h->share && lg && h->sh_req.p) { // (the ALM build with work sharing is the two-row one)
+                    a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
+                    a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
+                    a.sh_hints = static_cast<int*>(h->sh_hints.p);
+                    h->last_launch_shared = true;
+                }
             }
             else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
         } else if (a.flags != 0) {

@@ -1172,7 +1172,8 @@ struct ShareReq {
     int slot;       // which scratch area holds its slab (the owner block's)
     int pad1;
     unsigned long long J[CILQR_MAX_ALPHA_TRIALS];
-    unsigned long long pad2[2];
+    unsigned long long rho_bits; // augmented Lagrangian: the owner's penalty weight (its multipliers are in global memory)
+    unsigned long long pad2;
 };
 static_assert(sizeof(ShareReq) == 192, "ShareReq layout");
 enum { SH_NEXT = 0 /* persistent blocks: the next trajectory */, SH_FINISHED = 1, SH_HELPERS = 2, SH_ERROR = 3, SH_ANNOUNCED = 4,
@@ -1219,10 +1220,10 @@ __device__ inline void sh_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "
 
 // owner: announce the search whose trials t0 .. 19 sit in the slab; the owner keeps t0 and t0 + 1.  false = no slot free
 __device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx, int b, int slot, int N, int t0,
-                               int idx0, unsigned seq, int lane) {
+                               int idx0, unsigned long long rho_bits, unsigned seq, int lane) {
     for (int k = lane; k <= N; k += CILQR_WAVE) hints[k] = ridx[k];
     if (lane < CILQR_MAX_ALPHA_TRIALS) rq->J[lane] = CILQR_SH_PENDING;
-    if (lane == 0) { rq->idx0 = idx0; rq->slot = slot; }
+    if (lane == 0) { rq->idx0 = idx0; rq->slot = slot; rq->rho_bits = rho_bits; }
     sh_release(); // the slab, the hints and the marks are out before the claim word opens
     const unsigned own = (unsigned)((t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS);
     if (lane == 0) sh_st(&rq->claim, (seq << 16) | own);
@@ -1272,10 +1273,10 @@ __device__ inline bool sh_await(unsigned* ctl, ShareReq* rq, int t, int lane, do
 #define SH_ST_FOREIGN 0x80000000u
 __device__ __attribute__((noinline)) unsigned sh_owner_step(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx,
                                                             double* Jout, int b, int slot, int N, int t0, int idx0,
-                                                            unsigned seq, unsigned st, int lane) {
+                                                            unsigned long long rho_bits, unsigned seq, unsigned st, int lane) {
     st &= ~SH_ST_FOREIGN;
     if (!(st & SH_ST_ON)) {
-        const bool placed = sh_open(ctl, rq, hints, ridx, b, slot, N, t0, idx0, seq, lane);
+        const bool placed = sh_open(ctl, rq, hints, ridx, b, slot, N, t0, idx0, rho_bits, seq, lane);
         const int own0 = (t0 + 2 < CILQR_MAX_ALPHA_TRIALS) ? t0 + 2 : CILQR_MAX_ALPHA_TRIALS;
         st = SH_ST_ON | (placed ? SH_ST_PLACED : 0u) | ((unsigned)own0 << 8);
     }
