@@ -22,6 +22,11 @@ Workload (BASELINE.json `configs`):
   * --config 1: the reference's own case (scenario_two_straight, single ego, horizon 50) as a 10 Hz closed
     loop through the drop-in CILQRSolver.solve(), B = 1: per-tick latency next to the oracle on one core.
   * --config 2|3|4|5 selects any of them explicitly.
+  * Also timed by the default command (never the headline): `extra.closed_loop` — 8192 egos x 40 ticks of the
+    reference's planning loop (motion_planning.cpp:180-197) resident on the device, every tick warm-started from the
+    previous one (cilqr_solver.cpp:163-180), and `extra.config5_alm` — the headline batch with the augmented-Lagrangian
+    solve type (cilqr_solver.cpp:88-93).  Every extra is wrapped: a failing one is reported under its key and cannot
+    lose the headline line.
 
 metric = iLQR iterations/s = (sum over trajectories of executed iterations of the loop at
 /root/reference/src/cilqr_solver.cpp:110) * steps / wall time, whole job.
@@ -291,6 +296,91 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
             "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"}
 
 
+def device_identity(torch, local_rank):
+    """what identifies the GPU this rank drives: gathered from every rank so that the line shows N distinct devices"""
+    pr = torch.cuda.get_device_properties(local_rank)
+    bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff,
+                              getattr(pr, "pci_device_id", 0))
+    return {"local_rank": int(local_rank), "device": pr.name, "arch": getattr(pr, "gcnArchName", ""),
+            "pci_bus_id": bus, "uuid": str(getattr(pr, "uuid", "")), "compute_units": int(pr.multi_processor_count),
+            "pid": os.getpid()}
+
+
+def gather_objects(dist, obj, world):
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def closed_loop_run(pkg, torch, local_rank, rank, barrier, B=8192, ticks=40, N=50, check_egos=8):
+    """thousands of egos x ticks with the plan fed back on the device.  One handle, scenario
+    three_straight (the YAML that sets use_last_solution, config/scenario_three_straight.yaml:24; 8 obstacles), every
+    ego its own perturbed start; per tick one cilqr_solve_batch_device warm-started from its own previous u buffer
+    (cs:163-180) and one cilqr_advance_batch_device (ego <- x.row(1), obstacle window one tick on: mp:181,196-197).
+    No host round trip inside the timed region.  The first `check_egos` egos' states after every tick are kept (on the
+    device) for the comparison with stateful oracle solvers."""
+    cfg = pkg.GlobalConfig.get_instance("three_straight")
+    sc = pkg.build_scenario(cfg, "three_straight")
+    p = pkg.params_from_config(cfg, N=N, use_last_solution=1)
+    ticks = min(ticks, sc.obstacles.shape[1] - N - 1)
+    dev = torch.device("cuda", local_rank)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC11A00F2, first=rank * B)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), device=local_rank)
+    d_u = torch.zeros((B, N, 2), dtype=torch.float64, device=dev)
+    d_x = torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev)
+    d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_its = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+    d_hist = torch.zeros((ticks, check_egos, N + 1, 4), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    its_off = pkg.RESULT_DTYPE.fields["iters"][1]
+
+    def loop(record):
+        d_x0 = torch.from_numpy(x0).to(dev)
+        d_tick = torch.zeros(B, dtype=torch.int32, device=dev)
+        for t in range(ticks):
+            eng.solve_batch_device(B, d_x0.data_ptr(), 0, 0, d_tick.data_ptr(), d_u.data_ptr() if t else 0, d_u.data_ptr(),
+                                   d_x.data_ptr(), d_res.data_ptr(), 0, 0, st.cuda_stream)
+            if record:  # device-side, stream-ordered copies: iterations of this tick, plans of the sampled egos
+                d_its[t].copy_(d_res[:, its_off:its_off + 4].contiguous().view(torch.int32).view(B))
+                d_hist[t].copy_(d_x[:check_egos])
+            eng.advance_batch_device(B, d_x.data_ptr(), d_x0.data_ptr(), d_tick.data_ptr(), st.cuda_stream)
+
+    loop(True)  # warm-up pass (also the recorded one: the timed pass below does nothing but solve and advance)
+    barrier()
+    t0 = time.perf_counter()
+    loop(False)
+    barrier()
+    el = time.perf_counter() - t0
+    its = d_its.cpu().numpy()
+    hist = d_hist.cpu().numpy()
+    eng.close()
+    return {"elapsed": el, "iters_per_tick": its.sum(axis=1), "iters_total": float(its.sum()), "ticks": ticks, "B": B, "N": N,
+            "params": p, "scenario": sc, "x0": x0, "hist": hist, "M": int(sc.obstacles.shape[0])}
+
+
+def closed_loop_check(cl, check_egos=8):
+    """the sampled egos against one stateful oracle solver each (detmath build: the comparison is with ==)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle, Scene
+    orc = Oracle("det")
+    sc, p = cl["scenario"], cl["params"]
+    same = total = 0
+    for b in range(min(check_egos, cl["hist"].shape[1])):
+        s = orc.solver(p)
+        s.reset()
+        x = cl["x0"][b].copy()
+        for t in range(cl["ticks"]):
+            scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t)
+            r = s.solve(x, scene)
+            same += int(np.array_equal(r["x"], cl["hist"][t, b]))
+            total += 1
+            x = r["x"][1].copy()
+    return {"sampled_egos": int(min(check_egos, cl["hist"].shape[1])), "ego_ticks_compared": total,
+            "ego_ticks_bit_identical_to_det_oracle": same}
+
+
 def config1_closed_loop(args):
     """BASELINE configs[0]: scenario_two_straight, single ego, horizon 50, as the reference runs it — one
     CILQRSolver instance, solve() once per 0.1 s tick, ego <- row 1 of the plan (motion_planning.cpp:178-197) —
@@ -400,6 +490,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # which GPU does each rank drive?  Gathered before anything is timed: a multi-GPU line must show N distinct devices
+    ranks = gather_objects(dist, dict(rank=rank, **device_identity(torch, local_rank)), world)
+    distinct = len({(r["pci_bus_id"], r["uuid"]) for r in ranks}) == len(ranks)
+    if world > 1 and not distinct and os.environ.get("CILQR_BENCH_ONE_DEVICE") != "1":
+        if rank == 0:
+            print(json.dumps({"error": "ranks share a GPU: a scaling run needs one device per rank", "ranks": ranks}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.stdout.flush()
+        os._exit(3)
+
     cfg_id = args.config or 5
     wl, B = make_workload(pkg, cfg_id, args.batch, args.horizon, rank)
     N = wl.N
@@ -407,6 +509,9 @@ def main():
     elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier)
     stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, red_dev)
     value = stats[0] * args.steps / tmax
+    # every rank's own clock and kernel time: a straggler rank (or a GPU that throttles) is visible in the line
+    per_rank = gather_objects(dist, {"rank": rank, "elapsed_s": elapsed, "kernel_ms": kernel_ms,
+                                     "iterations_per_step": float(res["iters"].sum())}, world)
     gpu_u = gpu_x = None
     if rank == 0 and not args.no_cpu_baseline:
         nb = min(B, 1024)
@@ -416,29 +521,79 @@ def main():
 
     # the other workloads of the default command: config 2 (1024 trajectories per GPU), a latency measurement, and —
     # on several GPUs — BASELINE configs[3] (8192 trajectories of horizon 100 per rank)
-    def side_run(cfg, steps_side, note):
-        wl_s, B_s = make_workload(pkg, cfg, 0, 0, rank)
+    def side_run(cfg, steps_side, note, alm=False, cpu_check_rows=0):
+        wl_s, B_s = _make_workload(pkg, cfg, 0, 0, rank)
+        if alm:
+            wl_s = pkg.workloads.Workload(wl_s.name + "_alm", [pkg.copy_params(q, solve_type=1) for q in wl_s.params],
+                                          wl_s.scenes, wl_s.x0, wl_s.scenario_id, wl_s.param_id, wl_s.tick)
         run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
         el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier)
         st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, red_dev)
+        chk = None
+        if rank == 0 and cpu_check_rows and not args.no_cpu_baseline:
+            nb = min(B_s, cpu_check_rows)
+            chk = (run_s.d_u[:nb].cpu().numpy(), run_s.d_x[:nb].cpu().numpy(), nb)
         run_s.close()
+        pr_s = gather_objects(dist, kms_s, world)
         if rank != 0:
             return None
         rl = roofline_block(pkg, wl_s, res_s, kms_s, world)
-        return {"workload": wl_s.name, "baseline_config": cfg, "batch_per_gpu": B_s, "global_batch": int(st_s[8]),
+        cpu_chk = None
+        if chk is not None:  # the launch that was just timed against the oracle's libm build (checker only)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from oracle import Oracle
+            nb = chk[2]
+            ref = Oracle("libm").solve_batch(wl_s.params, oracle_scenes(wl_s), wl_s.x0[:nb], wl_s.scenario_id[:nb],
+                                             wl_s.param_id[:nb], wl_s.tick[:nb], n_threads=args.cpu_threads or usable_cores()[0])
+            cpu_chk = parity_check(chk[0], chk[1], res_s, ref)
+        return {"cpu_check": cpu_chk, "workload": wl_s.name, "baseline_config": cfg, "batch_per_gpu": B_s, "global_batch": int(st_s[8]),
                 "horizon": wl_s.N, "steps": steps_side, "value": st_s[0] * steps_side / tmax_s, "unit": "iLQR iterations/s",
                 "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": kms_s,
+                "kernel_ms_min_max_over_ranks": [float(min(pr_s)), float(max(pr_s))],
                 "iterations_per_launch_rank0": float(res_s["iters"].sum()),
                 "slowest_trajectory_iterations": int(res_s["iters"].max()),
+                "converged": int(st_s[2]), "max_lamb": int(st_s[3]), "max_iter": int(st_s[4]), "nan_costs": int(st_s[6]),
                 "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "note": note}
 
-    second = fourth = None
+    def closed_loop_extra():
+        cl = closed_loop_run(pkg, torch, local_rank, rank, barrier)
+        vec = np.array([cl["iters_total"], cl["B"] * cl["ticks"]], dtype=np.float64)
+        red, tmax_c = st_mod.reduce_stats(vec, cl["elapsed"], dist, red_dev)
+        if rank != 0:
+            return None
+        ipt = cl["iters_per_tick"]
+        out_c = {"workload": f"closed_loop_three_straight_B{cl['B']}_N{cl['N']}_ticks{cl['ticks']}", "egos_per_gpu": cl["B"],
+                 "ticks": cl["ticks"], "horizon": cl["N"], "obstacles": cl["M"],
+                 "value": red[0] / tmax_c, "unit": "iLQR iterations/s", "ego_ticks_per_s": red[1] / tmax_c,
+                 "ms_per_tick": tmax_c / cl["ticks"] * 1e3, "timed_region_s": tmax_c,
+                 "iterations_per_ego_tick_mean": float(cl["iters_total"] / (cl["B"] * cl["ticks"])),
+                 "iterations_per_ego_first_tick_cold": float(ipt[0] / cl["B"]),
+                 "iterations_per_ego_later_ticks_warm": float(ipt[1:].sum() / (cl["B"] * max(1, cl["ticks"] - 1))),
+                 "note": "cilqr_solve_batch_device warm-started from its own u buffer + cilqr_advance_batch_device per tick, "
+                         "no host round trip inside the timed region (mp:180-197, cs:163-180)"}
+        if not args.no_cpu_baseline:
+            out_c["cpu_check"] = closed_loop_check(cl)
+        return out_c
+
+    # Every extra is wrapped: the headline line must survive a failing side measurement.  (The extras run the same code
+    # on every rank, so a failure is the same failure everywhere and the ranks stay in step; a rank that failed alone
+    # would leave the others in a collective until the process group times out.)
+    def guarded(fn, *a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:  # noqa: BLE001 - reported in the line
+            return {"error": f"{type(e).__name__}: {e}"[:500]} if rank == 0 else None
+
+    second = fourth = closed = alm5 = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
-        second = side_run(2, max(args.steps, 20), "one launch of 1024 trajectories occupies a quarter of the chip's wave "
-                          "slots; its wall time is the slowest trajectory's (DESIGN.md)")
-        fourth = side_run(4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
-                          "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs; at fewer, the "
-                          "first ranks' shards)")
+        second = guarded(side_run, 2, max(args.steps, 20), "one launch of 1024 trajectories occupies a quarter of the chip's "
+                         "wave slots; its wall time is the slowest trajectory's (DESIGN.md)")
+        fourth = guarded(side_run, 4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
+                         "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs; at fewer, the "
+                         "first ranks' shards)", cpu_check_rows=512)
+        closed = guarded(closed_loop_extra)
+        alm5 = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm (cs:88-93, 253-261, "
+                       "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True)
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
@@ -459,7 +614,10 @@ def main():
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
                       ("config2_latency" if world == 1 else "config2_weak_scaling"): second,
-                      "config4_sharded": fourth},
+                      "config4_sharded": fourth, "closed_loop": closed, "config5_alm": alm5,
+                      "ranks": ranks, "distinct_devices": distinct, "per_rank": per_rank,
+                      "kernel_ms_min_max_over_ranks": [float(min(r["kernel_ms"] for r in per_rank)),
+                                                       float(max(r["kernel_ms"] for r in per_rank))]},
         }
         if cfg_id == 5:
             # convergence-vs-throughput view of the sweep: per barrier setting, over its 4096 solves
@@ -472,11 +630,14 @@ def main():
         if not args.no_cpu_baseline:
             cores, cores_note = usable_cores()
             threads = args.cpu_threads or cores
-            cb, r = cpu_baseline(pkg, wl, threads)
-            if cores_note:
-                cb["cores_note"] = cores_note
-            out["cpu_baseline"] = cb
-            out["extra"]["cpu_check"] = parity_check(gpu_u, gpu_x, res, r)
+            try:
+                cb, r = cpu_baseline(pkg, wl, threads)
+                if cores_note:
+                    cb["cores_note"] = cores_note
+                out["cpu_baseline"] = cb
+                out["extra"]["cpu_check"] = parity_check(gpu_u, gpu_x, res, r)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -154,7 +154,13 @@ int cilqr_solve_cache_stats(cilqr_handle* h, int64_t* uploads, int64_t* reuses);
 
 /* Same as cilqr_solve_batch with every array already resident in HBM; enqueues on `stream` (hipStream_t) and
  * returns without synchronising.  The index arrays are checked on the device: a trajectory with an id outside the
- * tables or too short an obstacle route is not solved and ends with CILQR_END_BAD_INPUT. */
+ * tables or too short an obstacle route is not solved and ends with CILQR_END_BAD_INPUT.
+ * ONE LAUNCH PER HANDLE AT A TIME: the scratch areas, the persistent blocks' trajectory counter and the work-sharing
+ * state belong to the handle.  Launches of one handle are therefore ordered on the device — a launch on another
+ * stream than the handle's previous one waits for it (hipStreamWaitEvent) — and do not overlap; independent batches
+ * that should overlap take one handle each (and one stream each).  A hand-off failure of the work sharing between
+ * blocks (a bounded wait that ran out: the owner then costs the trial itself, results stay correct) is reported by
+ * cilqr_solve_batch as CILQR_ERR_DEVICE and to device-entry callers through cilqr_work_sharing_stats()[3]. */
 int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
                              const int32_t* d_scenario_id, const int32_t* d_param_id,
                              const int32_t* d_tick, const double* d_last_u, double* d_u_out,
@@ -214,8 +220,11 @@ int cilqr_set_rollout_mode(cilqr_handle* h, int32_t mode);
  * applicable), [14] rollout passes of the first trial alone, [15] rollout passes of all 20 step sizes at once,
  * [16] of those, second passes after a rejected first trial.  out[B][17]. */
 #define CILQR_PROF_SLOTS 17
+/* (development library only — libcilqr_amd_dev.so, the same sources built with -DCILQR_DEV_BUILD: the production
+ *  library carries neither the cycle-accounting nor the testing-aid builds of the solve kernel and answers
+ *  CILQR_ERR_UNSUPPORTED to a request to switch them on; it does not read the CILQR_TUNE environment variable either) */
 int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled);
-/* Testing aid.  bit 0: always use the serial reference-point chain (cs:289-314 as written) instead
+/* Testing aid (development library only).  bit 0: always use the serial reference-point chain (cs:289-314 as written) instead
  * of the lane-parallel search + proof; bit 1: wave-uniform backward sweep instead of the
  * lane-parallel one.  Results must be identical either way. */
 int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags);

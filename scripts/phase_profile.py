@@ -20,9 +20,11 @@ if args.config == 2:
     wl = W.config2(B=args.batch or 1024, N=args.horizon)
 elif args.config == 3:
     wl = W.config3(B=args.batch or 8192, N=args.horizon)
+elif args.config == 4:
+    wl = W.config4(B=args.batch or 8192, N=100)
 else:
     wl = W.config5(B_base=args.batch or 4096, N=args.horizon)
-eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True)  # the cycle accounting lives in the development library
 ids = dict(scenario_id=wl.scenario_id, param_id=wl.param_id, tick=wl.tick)
 eng.solve_batch(wl.x0, **ids)
 eng.set_phase_profiling(True)
@@ -48,4 +50,11 @@ rep = {"workload": wl.name, "kernel_ms": ms, "iters_sum": int(res["iters"].sum()
        "ref_scan_fallbacks": int(cyc[:, 8].sum()), "ref_sampled_proofs": int(cyc[:, 13].sum()), "trial_cost_evals": int(cyc[:, 9].sum()),
        "slowest": {"iters": int(res["iters"][tot.argmax()]), "trials": int(res["ls_trials"][tot.argmax()]),
                    "phases": {n: int(cyc[tot.argmax(), i]) for i, n in enumerate(names[:6])}}}
+order = np.argsort(-tot)[:8]
+rep["slowest_8"] = [{"b": int(b), "iters": int(res["iters"][b]), "trials": int(res["ls_trials"][b]), "cycles": int(tot[b]),
+                     "trial_cost_cycles": int(cyc[b, 4]), "ref_points_cycles": int(cyc[b, 10]),
+                     "ref_scan_fallbacks": int(cyc[b, 8])} for b in order]
+rep["ref_scan_fallbacks_max_per_trajectory"] = int(cyc[:, 8].max())
+if os.environ.get("PHASE_OUT"):
+    np.save(os.environ["PHASE_OUT"], cyc)
 print(json.dumps(rep, indent=1))

@@ -25,6 +25,27 @@ def test_header_symbols_are_exported(pkg):
     assert set(names) == set(pkg._lib.SIGNATURES), set(names) ^ set(pkg._lib.SIGNATURES)
 
 
+def test_development_library_exports_the_same_abi(pkg):
+    """libcilqr_amd_dev.so (-DCILQR_DEV_BUILD: + testing aids, cycle accounting, CILQR_TUNE) is the same C-ABI; the
+    production library carries none of the testing-aid builds of the solve kernel."""
+    dev = ctypes.CDLL(str(pkg._lib.LIB_PATH_DEV))
+    for n in declared_symbols():
+        assert hasattr(dev, n), f"{n} missing from the development library"
+    dev.cilqr_version.restype = ctypes.c_char_p
+    assert b"dev" in dev.cilqr_version()
+    prod = pkg._lib.load()
+    assert b"dev" not in prod.cilqr_version()
+    # (the kernels' names are in the bundled code objects: DBG = true / PROF = true builds only in the dev library)
+    prod_bytes = pkg._lib.LIB_PATH.read_bytes()
+    dev_bytes = pkg._lib.LIB_PATH_DEV.read_bytes()
+    dbg = b"_Z7k_solveILb1ELi1ELb0ELb0ELb0E"   # k_solve<true, 1, false, false, false, ...>
+    prof = b"_Z7k_solveILb0ELi1ELb0ELb0ELb1E"  # k_solve<false, 1, false, false, true, ...>
+    assert dbg in dev_bytes and prof in dev_bytes
+    assert dbg not in prod_bytes and prof not in prod_bytes
+    assert b"CILQR_TUNE" in dev_bytes and b"CILQR_TUNE" not in prod_bytes
+    assert len(prod_bytes) < len(dev_bytes)
+
+
 def test_struct_layouts_match_header(pkg, built):
     """ctypes mirrors vs the C compiler's view of the structs."""
     import subprocess, tempfile

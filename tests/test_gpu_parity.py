@@ -32,12 +32,13 @@ def engines(pkg, scenarios):
     """one device engine per (scenario, N) as needed"""
     cache = {}
 
-    def get(name, N, **over):
-        key = (name, N, tuple(sorted(over.items())))
+    def get(name, N, dev=False, **over):
+        """dev=True: an engine on libcilqr_amd_dev.so (the testing aids and the cycle accounting live there)"""
+        key = (name, N, dev, tuple(sorted(over.items())))
         if key not in cache:
             cfg, sc = scenarios[name]
             p = pkg.params_from_config(cfg, N=N, **over)
-            eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+            eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=dev)
             cache[key] = (eng, p, sc)
         return cache[key]
 
@@ -276,16 +277,17 @@ def test_solve_param_sweep_and_mixed_scenarios(pkg, orc_det):
     eng.close()
 
 
-@pytest.mark.parametrize("cfg,rows", [(2, 1024), (3, 2048), (5, 4096)])
+@pytest.mark.parametrize("cfg,rows", [("2", 1024), ("3", 2048), ("5", 4096), ("4", 1024), ("2alm", 1024)])
 def test_libm_gap_is_input_conditioning(pkg, orc_det, cfg, rows):
     """Against the oracle built on glibc's libm (what the reference binary links), on BASELINE configs 2 (all 1024
-    trajectories), 3 and 5 (first 2048 / 4096):
+    trajectories), 3 and 5 (first 2048 / 4096), configs[3]'s rank-0 shard (first 1024: horizon 100, four scenarios,
+    three of them with the RearCenter-free CoG model and road borders) and config 2 with the augmented Lagrangian:
       * every trajectory whose REFERENCE result is determined to 1e-5 by its input — the libm build moves by
         <= 1e-5 when one component of x0 moves by one unit in the last place — is within 1e-5 on u, x and J_final;
       * every trajectory outside the 1e-5 band is one the libm build itself does not reproduce to 1e-5 under
-        such a move, and the HIP result is no further from it than 4x what that move does.
+        such a move, and the HIP result is no further from it than 1.5 x what that move does (measured: <= 0.96 x).
     (tests/libm_tolerance.py holds the diagnosis; VERDICT r01 asked for a near-tie criterion — the traces turn
-    out to part by smooth amplification under mostly identical decisions, not at near-ties, see DESIGN.md §2.)"""
+    out to part by smooth amplification under mostly identical decisions, not at near-ties, see DESIGN.md section 2.)"""
     import libm_tolerance as lt
     wl = lt.make_workload(pkg, cfg)
     sel = np.arange(rows)
@@ -299,14 +301,41 @@ def test_libm_gap_is_input_conditioning(pkg, orc_det, cfg, rows):
     hip_full = {k: np.zeros((wl.B,) + hip[k].shape[1:], dtype=hip[k].dtype) for k in ("u", "x", "res")}
     for k in hip_full:
         hip_full[k][sel] = hip[k]
-    rep = lt.analyse(wl, hip_full, threads=8, rows=sel)
+    rep = lt.analyse(wl, hip_full, threads=8, rows=sel, symmetric=(cfg == "4"))
+    brief = {k: v for k, v in rep.items() if k != "records"}
+    if cfg == "4":
+        # Horizon 100 over these scenarios is a chaotic map of the input: more than half of the solves are not
+        # reproduced to 1e-5 by the libm build ITSELF after a one-ulp move of x0 (profiles/r03_libm_tolerance.json:
+        # 5124 of the shard's 8192; three_straight is the tame one).  What can hold does: no trajectory is further from
+        # the libm result than twice what such a move does to one of the two builds (measured: <= 1.6 x).
+        assert rep["every_trajectory_obeys gap <= max(1e-5, 2 x spread)"], brief
+        assert rep["ill_conditioned (libm spread > 1e-5)"] > rows // 4, brief
+        return
+    assert rep["well_conditioned_outside_1e-5"] == 0, brief
+    assert rep["outside_1e-5"] == rep["outside_1e-5_with_spread_gt_1e-5"], brief
+    assert rep["max_gap_over_spread_outside"] is None or rep["max_gap_over_spread_outside"] <= 1.5, brief
+    assert rep["within_1e-5_frac"] >= 0.99, brief
+    if cfg in ("3", "5", "2alm"):  # the CoG-model bend scenario is well-conditioned throughout; so is config 2 under ALM
+        assert rep["outside_1e-5"] == 0 and rep["max_gap"] < 1e-7, brief
+
+
+def test_libm_gap_of_the_single_ego_closed_loop(pkg):
+    """BASELINE configs[0] (scenario_two_straight, one ego, horizon 50, 120 ticks): the libm build's loop and the HIP
+    path's loop part ways after a few ticks — the YAML start lies ON the reference line, where the lateral-constraint
+    gradient is 0/0-degenerate — and the tick that does it is a solve the libm build does not
+    reproduce itself under a one-ulp move of its input: every tick's solve, given the libm loop's own state, obeys the
+    same two rules as the batches above."""
+    import libm_tolerance as lt
+    rep = lt.analyse_config1(pkg, threads=8, gpu=True)
     brief = {k: v for k, v in rep.items() if k != "records"}
     assert rep["well_conditioned_outside_1e-5"] == 0, brief
     assert rep["outside_1e-5"] == rep["outside_1e-5_with_spread_gt_1e-5"], brief
-    assert rep["max_gap_over_spread_outside"] is None or rep["max_gap_over_spread_outside"] <= 4.0, brief
-    assert rep["within_1e-5_frac"] >= 0.98, brief
-    if cfg in (3, 5):  # the CoG-model bend scenario is well-conditioned throughout
-        assert rep["outside_1e-5"] == 0 and rep["max_gap"] < 1e-7, brief
+    assert rep["max_gap_over_spread_outside"] is None or rep["max_gap_over_spread_outside"] <= 1.5, brief
+    cl = rep["closed_loop"]
+    first = cl["first_tick_whose_entering_state_differs_by_more_than_1e-5"]
+    if first is not None:  # the solve of the tick before is on record as ill-conditioned
+        cause = cl["the_solve_that_caused_it (tick before, same input to both builds)"]
+        assert cause is None or cause["libm_spread_under_1ulp_x0"] > 1e-5, brief
 
 
 def test_batch_order_invariance(pkg, engines):
@@ -387,7 +416,7 @@ def test_api_contract_details(pkg, orc_det, scenarios):
 def test_serial_and_parallel_reference_search_agree(pkg, orc_det, engines):
     """the lane-parallel reference-point search (+ proof) and the serial chain of cs:289-314 give the
     same solves; with wild gains the proof must fail sometimes and the fallback must take over."""
-    eng, p, sc = engines("three_bend", 50, use_last_solution=0)
+    eng, p, sc = engines("three_bend", 50, dev=True, use_last_solution=0)
     x0 = pkg.workloads.perturbed_starts(sc.ego_state, 64, 4242)
     a = eng.solve_batch(x0, trace_cap=64)
     eng.set_debug_flags(pkg._lib.DBG_SERIAL_REF_SCAN)
@@ -418,7 +447,7 @@ def test_uniform_and_lane_parallel_backward_agree(pkg, orc_det, engines):
     """the two device formulations of backward_pass (wave-uniform / lane-parallel) are
     interchangeable bit for bit, on success and on failure."""
     for name, N, over in (("three_bend", 50, {}), ("two_straight", 30, {"w_acc": -40.0})):
-        eng, p, sc = engines(name, N, **over)
+        eng, p, sc = engines(name, N, dev=True, **over)
         us, xs = random_trajectories(pkg, orc_det, p, sc, 16, seed=21, rough=0.01)
         for lamb in (0.0, 8.0):
             a = eng.backward_pass(us, xs, lamb)
@@ -808,7 +837,7 @@ def test_rollout_policy_statistics(pkg, engines):
     """the adaptive policy's bookkeeping (in-kernel counters): every line search starts with exactly one rollout
     pass, second passes happen only after a rejected first trial, and on the benchmark-like batch the slab is
     written in a minority of the iterations."""
-    eng, p, sc = engines("two_straight", 50, use_last_solution=0)
+    eng, p, sc = engines("two_straight", 50, dev=True, use_last_solution=0)
     x0 = pkg.workloads.perturbed_starts(sc.ego_state, 256, 0xC11A0002)
     eng.set_phase_profiling(True)
     for helper in (0, 1):
@@ -1190,7 +1219,7 @@ def test_irregular_lane_tables_reference_search(pkg, orc_det, scenarios):
         out, refs = solve_both(pkg, orc_det, p, tab, x0)
         compare_solves(out, refs, f"lane={name}")
         # the same through the instrumented kernel: which proof levels did this table need?
-        eng = pkg.BatchedCILQR(p, tab)
+        eng = pkg.BatchedCILQR(p, tab, dev=True)
         eng.set_phase_profiling(True)
         out2 = eng.solve_batch(x0, trace_cap=128)
         cyc = eng.phase_cycles(len(x0))
@@ -1243,3 +1272,112 @@ def test_fuzz_random_parameter_sets(pkg, orc_det, scenarios):
         total_iters += int(out["res"]["iters"].sum())
         eng.close()
     assert total_iters > 1000
+
+
+# ---- round 3 -------------------------------------------------------------------------------------
+def test_production_library_refuses_the_testing_aids(pkg, scenarios):
+    """libcilqr_amd.so carries neither the DBG nor the PROF builds of the solve kernel (they live in
+    libcilqr_amd_dev.so): asking for them is an error, not a silent no-op."""
+    cfg, sc = scenarios["three_bend"]
+    eng = pkg.BatchedCILQR(pkg.params_from_config(cfg, N=30), pkg.SceneTable.from_scenario(sc))
+    for call in (lambda: eng.set_debug_flags(pkg._lib.DBG_SERIAL_REF_SCAN), lambda: eng.set_phase_profiling(True)):
+        with pytest.raises(pkg.CilqrError) as e:
+            call()
+        assert e.value.code == pkg._lib.ERR_UNSUPPORTED
+    eng.set_debug_flags(0)
+    eng.set_phase_profiling(False)
+    eng.close()
+
+
+def test_rows_that_stay_behind_the_chain_are_proven_in_parallel(pkg, orc_det):
+    """BASELINE configs[3] has solves (rank-0 shard: trajectories 1402 and 5317) whose trial trajectories slow down
+    and swerve so that for a score of consecutive rows the nearest lane sample lies BEHIND the index an earlier row has
+    reached: the chain of cs:289-314 stays put there.  The lane-parallel search takes the running maximum of its
+    candidates and proves the stay with one comparison per row; before, each of these solves' ~300 trial costs went
+    down the serial chain (45 of the launch's 52 ms).  Same bits as the oracle; the serial chain is now the exception."""
+    wl = pkg.workloads.config4(B=8192)
+    rows = np.array([1402, 5317, 121, 4607])
+    sub = pkg.workloads.Workload("sub", wl.params, wl.scenes, wl.x0[rows], wl.scenario_id[rows], wl.param_id[rows], wl.tick[rows])
+    eng = pkg.BatchedCILQR(sub.params, sub.scenes, dev=True)
+    eng.set_phase_profiling(True)
+    out = eng.solve_batch(sub.x0, sub.scenario_id, sub.param_id, sub.tick, trace_cap=128)
+    cyc = eng.phase_cycles(len(rows))
+    eng.close()
+    scenes = [oracle_scene_tab(t) for t in sub.scenes]
+    refs = []
+    for i in range(len(rows)):
+        s = orc_det.solver(sub.params[sub.param_id[i]])
+        refs.append(s.solve(sub.x0[i], scenes[sub.scenario_id[i]], trace_cap=128))
+    compare_solves(out, refs, "config 4 outliers (instrumented)")
+    trials, fallbacks = cyc[:, 9], cyc[:, 8]
+    assert trials[0] >= 300 and trials[1] >= 290
+    assert (fallbacks[:2] * 8 <= trials[:2]).all(), (fallbacks.tolist(), trials.tolist())
+    # and through the production library (persistent blocks need a big batch: the whole shard is covered by
+    # test_config4_every_rank_shard_and_stats; here the four as a small batch)
+    eng = pkg.BatchedCILQR(sub.params, sub.scenes)
+    out2 = eng.solve_batch(sub.x0, sub.scenario_id, sub.param_id, sub.tick, trace_cap=128)
+    eng.close()
+    compare_solves(out2, refs, "config 4 outliers")
+
+
+def oracle_scene_tab(tab, tick=0):
+    from oracle import Scene
+    return Scene(tab.lane_x, tab.lane_y, tab.lane_yaw, tab.obs, tab.road_borders, tab.ref_velo, tick)
+
+
+_ONE_HANDLE_TWO_STREAMS_SCRIPT = r"""
+import sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import cilqr_amd as pkg
+dev = torch.device("cuda", 0)
+# large batches: persistent blocks, whose trajectory counter and scratch areas belong to the launch in flight
+wa, wb = pkg.workloads.config3(B=4096), pkg.workloads.config3(B=4096, first=4096)
+N = wa.N
+eng = pkg.BatchedCILQR(wa.params, wa.scenes)
+refs = [eng.solve_batch(w.x0) for w in (wa, wb)]
+strs = [torch.cuda.Stream(dev) for _ in range(2)]
+d_x0 = [torch.from_numpy(w.x0).to(dev) for w in (wa, wb)]
+outs = [(torch.empty((4096, N, 2), dtype=torch.float64, device=dev), torch.empty((4096, N + 1, 4), dtype=torch.float64, device=dev),
+         torch.zeros((4096, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)) for _ in range(2)]
+torch.cuda.synchronize(dev)
+for rep in range(3):   # the SAME handle, alternating streams, no host synchronisation in between
+    for i in range(2):
+        u, x, r = outs[i]
+        eng.solve_batch_device(4096, d_x0[i].data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, 0, strs[i].cuda_stream)
+torch.cuda.synchronize(dev)
+for (u, x, r), ref in zip(outs, refs):
+    assert np.array_equal(u.cpu().numpy(), ref["u"]) and np.array_equal(x.cpu().numpy(), ref["x"])
+    res = np.frombuffer(r.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+    assert (res == ref["res"]).all()
+print("ONE-HANDLE-TWO-STREAMS-OK")
+"""
+
+
+def test_one_handle_on_two_streams_is_serialised():
+    """the control words, scratch areas and work-sharing state of a handle belong to its launch in flight.
+    A launch on another stream than the previous one now waits for it on the device (an event), so alternating
+    streams on one handle gives the right results instead of corrupting the trajectory counter."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ONE_HANDLE_TWO_STREAMS_SCRIPT, root], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ONE-HANDLE-TWO-STREAMS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_single_ego_cache_hit_still_checks_the_obstacle_horizon(pkg, scenarios):
+    """routes shorter than N + 1 that happen to match a prefix of the routes an earlier call uploaded were
+    solved from the cached samples; upstream throws std::out_of_range (ut:52-58) whatever was uploaded before."""
+    cfg, sc = scenarios["three_straight"]
+    solver = pkg.CILQRSolver(cfg, N=30)
+    x0 = sc.ego_state.copy()
+    solver.solve(x0, sc.lane, sc.target_velocity, sc.obstacles, sc.road_borders)   # uploads the full routes
+    for short in (sc.obstacles[:, :20], sc.obstacles[:, 5:25]):                     # a prefix / a sub-range of them
+        with pytest.raises(pkg.CilqrError) as e:
+            solver.solve(x0, sc.lane, sc.target_velocity, short, sc.road_borders)
+        assert e.value.code == pkg._lib.ERR_OBSTACLE_HORIZON
+    u, x = solver.solve(x0, sc.lane, sc.target_velocity, sc.obstacles[:, :31], sc.road_borders)  # exactly N + 1: fine
+    assert np.isfinite(x).all()

@@ -164,7 +164,8 @@ def test_libm_tolerance_diagnosis_on_the_detmath_twin(pkg, orc_det):
     rep = lt.analyse(wl, twin, threads=4)
     assert rep["well_conditioned_outside_1e-5"] == 0, {k: v for k, v in rep.items() if k != "records"}
     assert rep["outside_1e-5"] == rep["outside_1e-5_with_spread_gt_1e-5"]
-    assert rep["outside_1e-5"] >= 1  # trajectories 68, 116, 201, 222 of the benchmark batch
+    # (with this image's glibc trajectories 68, 116, 201, 222 of the benchmark batch leave the band; another libm may
+    #  produce none — the invariant is the one above, not their number)
     for r in rep["records"]:
-        assert r["gap"] <= 4.0 * r["libm_spread_under_1ulp_x0"]
+        assert r["gap"] <= 1.5 * r["libm_spread_under_1ulp_x0"]
         assert all(np.isfinite(v) and v >= 0 for v in r["smallest_decision_margin_at_split"].values())

@@ -10,6 +10,7 @@ import pathlib
 PKG_DIR = pathlib.Path(__file__).resolve().parent
 # CILQR_AMD_LIB: another build of the same library (A/B measurements of kernel changes on one GPU box)
 LIB_PATH = pathlib.Path(os.environ["CILQR_AMD_LIB"]) if os.environ.get("CILQR_AMD_LIB") else PKG_DIR / "libcilqr_amd.so"
+LIB_PATH_DEV = PKG_DIR / "libcilqr_amd_dev.so"
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -127,38 +128,49 @@ SIGNATURES = {
     "cilqr_build_routes": (C.c_int, [_P, _P, _I, _P, _I, _D, _P, _I, _D, _D, _P, _I, C.POINTER(_I), _P, _P]),
 }
 
-_lib = None
+_libs = {}
 
 
 class CilqrLibraryMissing(ImportError):
     pass
 
 
-def load():
-    """Load libcilqr_amd.so (once).  Raises CilqrLibraryMissing if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
+def lib_path(dev=False):
+    """libcilqr_amd.so, or — dev=True — libcilqr_amd_dev.so: the same sources built with -DCILQR_DEV_BUILD, which adds
+    the testing aids (cilqr_set_debug_flags), the in-kernel cycle accounting (cilqr_set_phase_profiling) and the
+    CILQR_TUNE environment switches.  CILQR_AMD_LIB / CILQR_AMD_LIB_DEV name other builds (A/B measurements)."""
+    env = os.environ.get("CILQR_AMD_LIB_DEV" if dev else "CILQR_AMD_LIB")
+    if env:
+        return pathlib.Path(env)
+    return PKG_DIR / ("libcilqr_amd_dev.so" if dev else "libcilqr_amd.so")
+
+
+def load(dev=False):
+    """Load the library (once per flavour).  Raises CilqrLibraryMissing if it has not been built."""
+    key = bool(dev)
+    if key in _libs:
+        return _libs[key]
+    path = lib_path(dev)
+    if not path.exists():
         raise CilqrLibraryMissing(
-            f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The CILQR solve path has no CPU/Python fallback.")
-    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    lib = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[key] = lib
     return lib
 
 
 class CilqrError(RuntimeError):
-    def __init__(self, code, where):
-        msg = load().cilqr_last_error()
+    def __init__(self, code, where, lib=None):
+        msg = (lib or load()).cilqr_last_error()
         self.code = code
         super().__init__(f"{where} failed with code {code}: {msg.decode() if msg else ''}")
 
 
-def check(code, where):
+def check(code, where, lib=None):
     if code != OK:
-        raise CilqrError(code, where)
+        raise CilqrError(code, where, lib)

@@ -1,5 +1,10 @@
-"""In-tree build of libcilqr_amd.so (hipcc, gfx950).  Compiled with -ffp-contract=off — parity
-with the CPU restatement depends on it."""
+"""In-tree build of libcilqr_amd.so (production) and libcilqr_amd_dev.so (the same sources with
+-DCILQR_DEV_BUILD: + the testing-aid and cycle-accounting builds of the solve kernel, + CILQR_TUNE).  hipcc, gfx950,
+-ffp-contract=off — parity with the CPU restatement depends on it.
+
+The solve kernel has ~20 builds (template instantiations); they are compiled in CILQR_SOLVE_GROUPS groups
+(csrc/cilqr_solve_inst.hip, -DCILQR_INST_GROUP=g) next to the host file, in parallel, and linked into one library."""
+import concurrent.futures
 import os
 import pathlib
 import shutil
@@ -9,9 +14,11 @@ PKG = pathlib.Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcilqr_amd.so"
+LIB_DEV = PKG / "libcilqr_amd_dev.so"
+OBJ = PKG / "build"
+GROUPS = 8
 
-HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
-             "-Wno-unused-result"]
+HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result"]
 
 
 def _newer(target, sources):
@@ -28,17 +35,36 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-def build_library(force=False, verbose=False):
-    srcs = [CSRC / "cilqr_amd.hip", CSRC / "scenario.cpp"]
-    deps = srcs + [CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
-                   pathlib.Path(__file__)]  # the flags live in this file
-    if not force and _newer(LIB, deps):
-        return LIB
-    cmd = [hipcc_path()] + HIP_FLAGS + [str(s) for s in srcs] + ["-o", str(LIB)]
+def _deps():
+    return [CSRC / "cilqr_amd.hip", CSRC / "cilqr_solve_inst.hip", CSRC / "scenario.cpp", CSRC / "cilqr_kernels.hpp",
+            CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
+            pathlib.Path(__file__)]  # the flags live in this file
+
+
+def _run(cmd, verbose):
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=str(CSRC))
-    return LIB
+        print(" ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], check=True, cwd=str(CSRC))
+
+
+def build_library(force=False, verbose=False, dev=False, out=None, jobs=None):
+    lib = pathlib.Path(out) if out else (LIB_DEV if dev else LIB)
+    if not force and _newer(lib, _deps()):
+        return lib
+    hipcc = hipcc_path()
+    tag = "dev" if dev else "prod"
+    objdir = OBJ / (tag if out is None else tag + "_" + lib.stem)
+    objdir.mkdir(parents=True, exist_ok=True)
+    defs = ["-DCILQR_DEV_BUILD"] if dev else []
+    units = [(CSRC / "cilqr_amd.hip", objdir / "cilqr_amd.o", []), (CSRC / "scenario.cpp", objdir / "scenario.o", [])]
+    units += [(CSRC / "cilqr_solve_inst.hip", objdir / f"solve_inst_{g}.o", [f"-DCILQR_INST_GROUP={g}"]) for g in range(GROUPS)]
+    jobs = jobs or min(len(units), os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        futs = [ex.submit(_run, [hipcc] + HIP_FLAGS + defs + extra + ["-c", src, "-o", obj], verbose) for src, obj, extra in units]
+        for f in futs:
+            f.result()
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in units] + ["-o", lib], verbose)
+    return lib
 
 
 def build_examples(force=False, verbose=False):
@@ -59,5 +85,6 @@ def build_examples(force=False, verbose=False):
 
 def build_all(force=False, verbose=False):
     lib = build_library(force, verbose)
+    build_library(force, verbose, dev=True)
     build_examples(force, verbose)
     return lib

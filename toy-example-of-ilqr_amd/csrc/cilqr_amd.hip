@@ -14,559 +14,17 @@
 #include <string>
 #include <vector>
 
-#include "cilqr_device.hpp"
+#include "cilqr_kernels.hpp"
 
-using namespace cilqr;
+// every build of k_solve is instantiated in cilqr_solve_inst.hip (one compilation per group, run in parallel)
+#define CILQR_X_EXTERN(g, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE) \
+    extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE> CILQR_SOLVE_SIGNATURE;
+CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
+#undef CILQR_X_EXTERN
 
 // ------------------------------------------------------------------------------------------------
-// kernels
+// piecewise kernels
 // ------------------------------------------------------------------------------------------------
-extern __shared__ double g_lds[];
-
-#ifndef CILQR_SOLVE_WAVES_PER_SIMD
-#define CILQR_SOLVE_WAVES_PER_SIMD 1
-#endif
-
-struct BatchArgs {
-    const cilqr_params* params;
-    const DevScene* scenes;
-    const int32_t* scenario_id; // may be null
-    const int32_t* param_id;    // may be null
-    const int32_t* tick;        // may be null
-    double* scratch;            // [grid][scratch_doubles(N)]
-    long long* prof;            // optional [B][CILQR_PROF_SLOTS] cycles per phase + counters (null = off)
-    int B;
-    int N;
-    int n_params, n_scenes;     // table sizes: the fused solve checks its ids against them
-    int W;                      // capacity (samples) of the per-trajectory LDS lane window
-    int flags;                  // CILQR_DBG_* (testing aids)
-    int tier;                   // line-search rollouts: -1 adaptive (default), 0 always all 20 step sizes in one
-                                // pass, 1 always the first trial alone first (cilqr_set_rollout_mode)
-    // augmented-Lagrangian state kept by the handle (solve_type alm): [B][N][alm_C], [B]
-    double* alm_mu;
-    double* alm_mu_next;
-    double* alm_rho;
-    int alm_C;
-    int alm;                    // 1 when the handle's parameter sets use the ALM solve type
-    // work sharing between blocks (k_solve's SHARE; null = off): counters + slots, one request and one row of
-    // reference-index hints per trajectory
-    unsigned* sh_ctl;
-    ShareReq* sh_req;
-    int* sh_hints;              // [B][N + 2]
-    int sh_max_helpers;         // blocks that stay to help (the others leave when they are done)
-    int sh_min_t0;              // a search is announced once this many of its trials have been rejected
-    int sh_backoff;             // an idle helper looks again after 1 us, doubling up to 2^sh_backoff us
-    unsigned* next;             // persistent blocks (large batches): the next trajectory to hand out; null = one block
-                                // per trajectory
-    long long* timeline;        // optional [B][4]: start / end of the solve of trajectory b (constant 100 MHz clock), the
-                                // index of the block that solved it, the XCC it ran on (cilqr_set_block_timeline; null = off)
-};
-
-__device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
-    AlmSt al;
-    al.C = a.alm_C;
-    al.mu = a.alm_mu ? a.alm_mu + (size_t)b * N * a.alm_C : nullptr;
-    al.mu_next = a.alm_mu_next ? a.alm_mu_next + (size_t)b * N * a.alm_C : nullptr;
-    al.rho = a.alm_rho ? a.alm_rho[b] : 1.0;
-    return al;
-}
-
-// phase ids of the optional in-kernel cycle accounting
-enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST = 4, PH_ACCEPT = 5, PH_TOTAL = 6, PH_ITERS = 7, PH_REF_FALLBACKS = 8, PH_TRIALS = 9, PH_TC_REF = 10, PH_TC_STAGE = 11, PH_TC_SUM = 12, PH_TC_SAMPLED = 13, PH_ROLL_FIRST = 14, PH_ROLL_ALL = 15, PH_ROLL_SECOND = 16 };
-#define PROF_T0() long long t_ph_ = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0
-#define PROF_ADD(ph)                                                  \
-    do {                                                              \
-        if (PROF && a.prof) {                                         \
-            long long t_now_ = (long long)__builtin_readcyclecounter(); \
-            if (lane == 0) ph_acc[ph] += t_now_ - t_ph_;              \
-            t_ph_ = t_now_;                                           \
-        }                                                             \
-    } while (0)
-
-__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l, int lane) {
-    int pid = a.param_id ? a.param_id[b] : 0;
-    int sid = a.scenario_id ? a.scenario_id[b] : 0;
-    int tk = a.tick ? a.tick[b] : 0;
-    make_cst(c, a.params[pid], a.scenes[sid], tk, l.ck, lane);
-}
-
-// The device-pointer entry point cannot check its index arrays on the host.  A trajectory whose ids point
-// outside the tables, or whose obstacle routes end before tick + N + 1 (upstream: RoutingLine::operator[]
-// throws std::out_of_range, ut:52-58), is not solved: NaN outputs, end_reason CILQR_END_BAD_INPUT.
-__device__ inline bool ids_valid(const BatchArgs& a, int b) {
-    const int pid = a.param_id ? a.param_id[b] : 0;
-    const int sid = a.scenario_id ? a.scenario_id[b] : 0;
-    const int tk = a.tick ? a.tick[b] : 0;
-    if ((unsigned)pid >= (unsigned)a.n_params || (unsigned)sid >= (unsigned)a.n_scenes || tk < 0) return false;
-    const DevScene& s = a.scenes[sid];
-    return !(s.M > 0 && (long long)tk + a.N + 1 > (long long)s.T);
-}
-
-// A block whose own trajectory is done costs open line-search trials of the blocks still running (see ShareReq)
-// until every trajectory of the launch has finished.  `me` only spreads the helpers over the open searches.
-// (not inlined: it runs once, after the solve, with nothing live — inlined, its copy of the trial costing costs the
-//  solve loop 27 more spilled vector registers)
-template <int NCH, int NC, bool ALM>
-__device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, int lane, int me) {
-    unsigned* const ctl = a.sh_ctl;
-    if (sh_add_u(ctl + SH_HELPERS, 1u, lane) >= (unsigned)a.sh_max_helpers) return; // enough of them already
-    int cur_b = -1, idx0h = 0, nfb = 0, idle = 0, slot_b = 0;
-    unsigned cur_seq = 0;
-    Cst c2;
-    AlmSt al2;
-    al2.mu = nullptr; al2.mu_next = nullptr; al2.rho = 1.0; al2.C = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) { // (bounded: a launch lasts milliseconds, this is seconds)
-        if (sh_ld_u(ctl + SH_FINISHED, lane) >= (unsigned)a.B) break;
-        const unsigned sv = sh_ld(ctl + SH_SLOT0 + lane); // the 64 slots, one per lane
-        unsigned long long open = __ballot(sv != 0u);
-        const int rot = (me * 7 + spin) & 63;
-        if (rot) open = (open >> rot) | (open << (64 - rot));
-        bool worked = false;
-        while (open && !worked) {
-            const int j = __builtin_ctzll(open);
-            open &= open - 1;
-            const int bb = (int)__shfl((int)sv, (j + rot) & 63, CILQR_WAVE) - 1;
-            if (bb < 0 || bb >= a.B) continue;
-            ShareReq* rq = a.sh_req + bb;
-            const unsigned v = sh_ld_u(&rq->claim, lane);
-            const unsigned next = v & 0xffu;
-            if (next >= (unsigned)CILQR_MAX_ALPHA_TRIALS) continue; // closed, or every trial handed out
-            if (sh_cas_u(&rq->claim, v, v + 1u, lane) != v) continue; // somebody else moved it: look again later
-            const int t = (int)next;
-            const unsigned seq = v >> 16;
-            if (bb != cur_b || seq != cur_seq) {
-                sh_acquire(); // the owner's slab, hints and row-0 index of this search
-                load_cst(c2, a, bb, l, lane);
-                if (NC) c2.N = NC;
-                wave_sync();
-                idx0h = rq->idx0;
-                slot_b = rq->slot; // the owner block's scratch area (its slab)
-                if (ALM) { // the owner's multipliers (global memory) and its penalty weight of this search
-                    al2 = load_alm(a, bb, N);
-                    al2.rho = dm_from_bits(rq->rho_bits);
-                }
-                stage_window(c2, l, idx0h, a.W, lane);
-                const int* hints = a.sh_hints + (size_t)bb * (N + 2);
-                for (int k = lane; k <= N; k += CILQR_WAVE) l.ridx[k] = hints[k];
-                wave_sync();
-                cur_b = bb;
-                cur_seq = seq;
-            }
-            double J1[1];
-            total_cost_trials<false, NCH, ALM, 1>(c2, l, al2, a.scratch + (size_t)slot_b * scratch_doubles(N), t, 1, lane, idx0h,
-                                                  0, &nfb, J1, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
-            if (lane == 0) sh_st64(&rq->J[t], dm_to_bits(J1[0]));
-            (void)sh_add_u(ctl + SH_HELPED, 1u, lane);
-            worked = true;
-        }
-        // nothing to do: look again after 1 us, backing off
-        if (worked) idle = 0;
-        else {
-            idle = (idle < a.sh_backoff) ? idle + 1 : a.sh_backoff;
-            for (int r = 0; r < (1 << idle); ++r) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-}
-
-// Which trajectory a block solves.  Workgroups go to the chip's eight XCDs round-robin (block i to XCD i mod 8) and
-// each XCD works through its own share, so a batch whose work per trajectory correlates with the index mod 8 — a
-// parameter sweep laid out setting-fastest (config 5: setting = b mod 16), scenarios dealt out in turn (config 4:
-// b mod 4) — loads the XCDs unevenly: measured 0.85 ... 1.27 of the mean, the launch waiting for the fullest.  Each
-// group of eight consecutive trajectories is therefore rotated by a hash of its number before it is dealt out to the
-// eight XCDs (a bijection; the last, partial group keeps its order): config 5 92.8 -> 80.6 ms, config 4 67.3 -> 56 ms.
-__device__ inline int trajectory_of_block(unsigned blk, int B) {
-    const unsigned q = blk >> 3, k = blk & 7u;
-    if ((q + 1u) * 8u > (unsigned)B) return (int)blk;
-    const unsigned h = (q * 0x9E3779B1u) >> 29;
-    return (int)(8u * q + ((k + h) & 7u));
-}
-
-// CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381)
-// DBG = true compiles the testing-aid paths in (cilqr_set_debug_flags); the production
-// instantiation carries neither their code nor their registers.
-// HELP = true: the block has a second wavefront that does nothing but cost every other trial of the
-// line search (slot 1) while the main wavefront costs the ones in between (slot 0); used when the
-// batch is too small to fill the chip with one wavefront per trajectory.  Control words in LDS:
-// CTL_MODE of an iteration: 0 = no line search (the backward pass failed), 1 = the slab holds all 20 trial
-// trajectories, 2 = only the first trial exists so far (in the first-trial buffer; the main wave costs it alone)
-enum { CTL_MODE = 0, CTL_EXIT = 2, CTL_IDX0 = 3, CTL_W0 = 4, CTL_W = 5 };
-// doubles: the helper's / the main wave's cost of the current pass (two slots each, alternating), and what the
-// helper needs to reach the main wave's verdicts on its own
-enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
-#define BLOCK_BAR()            \
-    do {                       \
-        if (HELP) __syncthreads(); \
-    } while (0)
-
-// WPS = waves per SIMD the register allocation must allow (2 for big batches: more resident
-// trajectories at the price of a few spills)
-// NTP = trials costed per pass after the first when there is no helper wavefront: 2 overlaps the two
-// trials' latencies inside one wavefront (pays while SIMDs hold one or two wavefronts: +5 % at B = 1536-2048);
-// 1 keeps fewer values live (27 instead of 68 spilled registers) and is the faster choice once every SIMD
-// holds two wavefronts anyway (+1.5 % at B >= 3072)
-// NC = horizon known at compile time (0: taken from the parameter table): every LDS offset but the lane window's
-// and every row count become constants — fewer live scalar registers, addresses folded into instruction offsets
-// LG = the cost expansion (l_x, l_u, l_xx, l_uu) lives in global memory instead of LDS (CILQR_GL_ROW): large batches
-// of long horizons, where the LDS block of a trajectory would cap the CU at 5 wavefronts
-// SHARE = blocks that have finished help the ones still running with their line searches (ShareReq; lone wavefronts,
-// barrier mode, one trial per pass); switched on per launch by a.sh_ctl
-// solve_one = the solve of trajectory b by the calling block; `slot` = which scratch area (slab, ...) it uses
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE>
-__device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const int slot, const double* __restrict__ x0,
-                                          const double* __restrict__ last_u, double* __restrict__ u_out,
-                                          double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
-                                          cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
-    const int lane = threadIdx.x & (CILQR_WAVE - 1);
-    const int wave = HELP ? (threadIdx.x >> 6) : 0;
-    const long long tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    static_assert(!SHARE || (!HELP && !PROF && NTP == 1), "work sharing: lone wavefronts costing one trial per pass");
-    const bool share = SHARE && a.sh_ctl != nullptr;
-    const int N = NC ? NC : a.N; // one horizon per handle
-    if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
-        if (share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
-        if (wave == 0) {
-            const double qnan = dm_from_bits(0x7ff8000000000000ULL);
-            for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = qnan;
-            for (int e = lane; e < 2 * N; e += CILQR_WAVE) u_out[(size_t)b * 2 * N + e] = qnan;
-            if (lane == 0 && res_out) {
-                cilqr_result r;
-                r.J_init = qnan; r.J_final = qnan; r.iters = 0; r.end_reason = CILQR_END_BAD_INPUT;
-                r.final_status = CILQR_RUNNING; r.ls_trials = 0; r.cost_evals = 0; r.trace_len = 0;
-                res_out[b] = r;
-            }
-        }
-        return;
-    }
-    Lds l;
-    constexpr int SLOTS = (HELP || NTP == 2) ? 2 : 1; // trials costed concurrently (the host sizes the LDS block alike)
-    carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS, LG ? 1 : 0);
-    Cst c;
-    load_cst(c, a, b, l, lane);
-    if (NC) c.N = NC;
-    double* scr = a.scratch + (size_t)slot * scratch_doubles(N);
-    if (LG) l.gl = scr + scratch_gl_offset(N);
-    double* first = scr + slab_doubles(N); // the first-trial buffer
-    AlmSt al = load_alm(a, b, N);
-    if (HELP && wave == 1) {
-        // ---- helper wavefront: costs trial 2p + 1 of every pass p, mirrors the main wave's control flow ----
-        __syncthreads(); // B0: window, ridx, x, u staged by the main wave
-        const int idx0h = l.ctli[CTL_IDX0];
-        l.w0 = l.ctli[CTL_W0];
-        l.W = l.ctli[CTL_W];
-        int nfb = 0;
-        for (int itr = 0; itr < c.max_iter; ++itr) {
-            __syncthreads(); // B1: K, d, trial slab of this iteration are ready (or the backward pass failed)
-            const int mode = l.ctli[CTL_MODE];
-            if (mode) {
-                if (ALM) al.rho = l.ctld[CTLD_RHO];
-                const double Jc = l.ctld[CTLD_JCUR], dV0 = l.ctld[CTLD_DV], dV1 = l.ctld[CTLD_DV + 1];
-                const double conv_thr = c.k->conv_thr, accept_thr = c.k->accept_thr;
-                int t0 = 0;
-                bool over = false;
-                if (mode == 2) {
-                    // the main wave costs the first trial on its own; if the search goes on it rolls the others out
-                    __syncthreads(); // B2s: its cost is in LDS
-                    if (trial_verdict(Jc, l.ctld[CTLD_JM], 0, dV0, dV1, conv_thr, accept_thr) != 0) over = true;
-                    else { __syncthreads(); /* B3: the slab is filled */ t0 = 1; }
-                }
-                if (!over) {
-                    for (int par = 0; t0 < CILQR_MAX_ALPHA_TRIALS; t0 += 2, par ^= 1) {
-                        double J1[1] = {0.0};
-                        const bool mine = (t0 + 1 < CILQR_MAX_ALPHA_TRIALS);
-                        if (mine) {
-                            total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, scr, t0 + 1, 1, lane, idx0h, a.flags, &nfb, J1, nullptr, 1);
-                            if (lane == 0) l.ctld[CTLD_JH + par] = J1[0];
-                        }
-                        __syncthreads(); // B2: both costs of this pass are in LDS (slots alternate between passes)
-                        // the same verdict the main wave reaches (trial_verdict is a pure function of these numbers)
-                        const double J0 = l.ctld[CTLD_JM + par];
-                        if (trial_verdict(Jc, J0, t0, dV0, dV1, conv_thr, accept_thr) != 0) break;
-                        if (mine && trial_verdict(Jc, J1[0], t0 + 1, dV0, dV1, conv_thr, accept_thr) != 0) break;
-                    }
-                }
-            }
-            __syncthreads(); // B4
-            if (l.ctli[CTL_EXIT]) break;
-        }
-        return;
-    }
-    // the main wavefront carries the serial chain of the solve: it wins issue arbitration against the helper
-    // wavefront (of another block) it shares its SIMD with
-    if (HELP) __builtin_amdgcn_s_setprio(2);
-    if (ALM && last_u == nullptr) {
-        // cs:88-93: fresh multipliers unless this call continues a previous solution
-        al.rho = c.k->alm_rho_init;
-        for (int e = lane; e < N * al.C; e += CILQR_WAVE) { al.mu[e] = 0.0; al.mu_next[e] = 0.0; }
-        wave_sync();
-    }
-
-    // the cycle accounting lives in LDS (written by lane 0 only): as a register array it would cost the profiling
-    // build 34 vector registers and push spill reloads into the backward loop
-    long long* const ph_acc = l.prof;
-    if (PROF && a.prof) {
-        for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) ph_acc[e] = 0;
-        wave_sync();
-    }
-    const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
-    PROF_T0();
-    const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
-    int idx0;
-    init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
-    double J_cur = total_cost_lds<ALM>(c, l, al, lane);
-    const double J_init = J_cur;
-    PROF_ADD(PH_INIT);
-    if (HELP) {
-        if (lane == 0) { l.ctli[CTL_IDX0] = idx0; l.ctli[CTL_W0] = l.w0; l.ctli[CTL_W] = l.W; }
-        __syncthreads(); // B0
-    }
-
-    double lamb = c.k->init_lamb;
-    int status = CILQR_RUNNING;
-    int iters = 0, ls_trials = 0, cost_evals = 1, tl = 0;
-    int end_reason = CILQR_END_MAX_ITER;
-    int flag = 0;
-    int n_fallback = 0;
-    // Line-search rollouts.  88 % / 71 % of the iterations of BASELINE configs 2 / 5 accept the first trial
-    // (profiles/r02_trial_depth_histogram.json), 6-14 % try all 20 and the rest is spread evenly between.  An
-    // iteration therefore either rolls out alpha = 1 alone into the small first-trial buffer and only on
-    // rejection all step sizes into the slab ("shallow"), or all of them at once ("deep") when the previous
-    // iteration's search went beyond its first trial — failed searches come in runs.  One extra rollout pass on
-    // ~2 % of the iterations buys slab writes on 13-30 % of them instead of all.
-    bool deep_next = false;
-    ShareReq* const rq = share ? a.sh_req + b : nullptr;
-    unsigned sh_seq = 1; // the searches of this trajectory that were announced, counted (a closed request holds the next number)
-    for (int itr = 0; itr < c.max_iter; ++itr) {
-        // are there idle blocks?  (asked here, needed after the backward sweep: the answer's latency is hidden)
-        unsigned sh_probe = 0;
-        if (share && lane == 0) sh_probe = sh_ld(a.sh_ctl + SH_HELPERS);
-        // ---- iter_step ----
-        cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
-        if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
-        // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
-        if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
-            cost_and_model_derivatives<ALM, LG>(c, l, al, lane);
-        } else {
-            model_jacobians(c, l, lane); // the gains of the failed pass sit where A, B were
-        }
-        PROF_ADD(PH_DERIV);
-        status = CILQR_RUNNING;
-        double dV[2];
-        bool ok = backward_sweep<(DBG && !ALM), LG ? (ALM ? CILQR_GL_ROW_ALM : CILQR_GL_ROW) : 0>(c, l, lamb, lane, dV, a.flags);
-        wave_sync();
-        PROF_ADD(PH_BACKWARD);
-        double new_J = J_cur;
-        int trials = 0, alpha_idx = -1;
-        if (!ok) {
-            status = CILQR_BACKWARD_PASS_FAIL;
-            if (HELP) {
-                if (lane == 0) l.ctli[CTL_MODE] = 0;
-                __syncthreads(); // B1
-            }
-        } else {
-            flag = 0;
-            const bool deep = (a.tier == 0) || (a.tier < 0 && deep_next);
-            bool have_all = false; // the slab holds all 20 trial trajectories of this iteration
-            bool done = false;
-            int t0 = 0;
-            unsigned sh_st = 0;    // work sharing: state of this search's announcement (SH_ST_*), 0 = not announced
-            bool sh_local = false; // cost the trial here although a helper delivered it
-            int par = 0; // helper mode: which pair of cost slots this pass uses
-            // The line search of cs:354-372.  The costs are produced pass by pass — alpha = 1 alone (usually
-            // accepted), then NTP trials per pass (two with a helper wavefront) — and consumed strictly in order.
-            // One call site each for the rollout, the costing and the acceptance keeps the loop body small.
-            while (t0 < CILQR_MAX_ALPHA_TRIALS && !done) {
-                if (t0 == 0 || !have_all) {
-                    // t0 == 0: the iteration's first rollout pass; t0 == 1 without the slab: the first trial
-                    // was rejected, now the other step sizes (lane 0 repeats the first trial: the same bits)
-                    const bool all = deep || t0 == 1;
-                    if (t0 == 1) restore_gains_head(l, first, N, lane);
-                    rollout_trials(c, l, all ? scr : first, lane, all ? CILQR_MAX_ALPHA_TRIALS : 1, all ? CILQR_MAX_ALPHA_TRIALS : 1);
-                    have_all = all;
-                    PROF_ADD(PH_ROLLOUT);
-                    if (PROF && a.prof && lane == 0) ph_acc[t0 == 1 ? PH_ROLL_SECOND : (all ? PH_ROLL_ALL : PH_ROLL_FIRST)] += 1;
-                    if (HELP) {
-                        if (t0 == 0 && lane == 0) {
-                            l.ctli[CTL_MODE] = all ? 1 : 2;
-                            l.ctld[CTLD_RHO] = al.rho; l.ctld[CTLD_JCUR] = J_cur; l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1];
-                        }
-                        __syncthreads(); // B1 (first pass) / B3 (second pass)
-                    }
-                    // the stage-cost scratch lies over the gains of the first steps: a shallow iteration may
-                    // still need them for its second pass
-                    if (!all) save_gains_head(l, first, N, lane);
-                }
-                const double* src = have_all ? scr : first;
-                const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
-                double Jp[CILQR_NT];
-                int nt = (t0 == 0) ? 1 : NTP;
-                if (HELP && have_all) nt = 2; // this wave costs trial t0 (slot 0), the helper trial t0 + 1 (slot 1)
-                if (t0 + nt > CILQR_MAX_ALPHA_TRIALS) nt = CILQR_MAX_ALPHA_TRIALS - t0;
-                bool foreign = false; // the cost of trial t0 comes from another block
-                if (SHARE && share && have_all && t0 >= a.sh_min_t0 && !sh_local &&
-                    (sh_st != 0u || (CILQR_MAX_ALPHA_TRIALS - t0 >= CILQR_SH_MIN_OPEN &&
-                                     __builtin_amdgcn_readfirstlane((int)sh_probe) != 0))) {
-                    sh_st = sh_owner_step(a.sh_ctl, rq, a.sh_hints + (size_t)b * (N + 2), l.ridx, &l.ctld[CTLD_JM], b, slot, N, t0,
-                                          idx0, ALM ? dm_to_bits(al.rho) : 0ULL, sh_seq, sh_st, lane);
-                    foreign = (sh_st & SH_ST_FOREIGN) != 0u;
-                    if (foreign) Jp[0] = l.ctld[CTLD_JM];
-                }
-                if (SHARE && foreign) {
-                    // nothing to compute
-                } else if (HELP || nt == 1) {
-                    double J1[1];
-                    total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, src, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
-                                                        (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr, 0, as);
-                    Jp[0] = J1[0];
-                    if (HELP) {
-                        if (lane == 0) l.ctld[CTLD_JM + par] = J1[0];
-                        __syncthreads(); // B2 (B2s for the lone first trial of a shallow iteration)
-                        if (have_all) {
-                            Jp[1] = l.ctld[CTLD_JH + par];
-                            par ^= 1;
-                        }
-                    }
-                } else if (NTP > 1) {
-                    total_cost_trials<DBG, NCH, ALM, CILQR_NT>(c, l, al, src, t0, nt, lane, idx0, a.flags, &n_fallback,
-                                                               Jp, (PROF && a.prof) ? &ph_acc[PH_TC_REF] : nullptr);
-                }
-                PROF_ADD(PH_TRIAL_COST);
-                if (SHARE && foreign && trial_verdict(J_cur, Jp[0], t0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr) == 2) {
-                    // the accepted trial's lane indices are needed too: cost it here (the same bits) and accept then
-                    sh_local = true;
-                    continue;
-                }
-                sh_local = false;
-                for (int tt = 0; tt < nt && !done; ++tt) {
-                    const int t = t0 + tt;
-                    new_J = Jp[tt];
-                    trials++;
-                    const int verdict = trial_verdict(J_cur, new_J, t, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
-                    if (verdict == 1) {
-                        status = CILQR_CONVERGED;
-                        alpha_idx = t;
-                        done = true;
-                    } else if (verdict == 2) {
-                        if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
-                        flag = 1;
-                        alpha_idx = t;
-                        accept_trial(c, l, src, t, tt, lane, as);
-                        PROF_ADD(PH_ACCEPT);
-                        J_cur = new_J;
-                        done = true;
-                    }
-                }
-                t0 += nt;
-            }
-            if (SHARE && sh_st != 0u) { // (before anything touches the slab again)
-                sh_owner_close(a.sh_ctl, rq, b, sh_seq, sh_st, (t0 > 0 ? t0 - 1 : 0), lane);
-                sh_seq++;
-            }
-            deep_next = (trials > 1);
-            if (!done) {
-                status = CILQR_FORWARD_PASS_FAIL;
-                if (ALM) { // cs:377-378
-                    for (int e = lane; e < N * al.C; e += CILQR_WAVE) al.mu[e] = al.mu_next[e];
-                    double r = (1 + c.k->alm_gamma) * al.rho;
-                    al.rho = (c.k->max_rho < r) ? c.k->max_rho : r;
-                    wave_sync();
-                }
-            }
-        }
-        // ---- back in solve (cs:113-141) ----
-        iters++;
-        ls_trials += trials;
-        cost_evals += trials;
-        if (status == CILQR_BACKWARD_PASS_FAIL || status == CILQR_FORWARD_PASS_FAIL) {
-            double la = lamb * c.k->lamb_amplify;
-            lamb = (c.k->lamb_amplify < la) ? la : c.k->lamb_amplify;
-        } else if (status == CILQR_RUNNING) {
-            lamb *= c.k->lamb_decay;
-        }
-        if (trace_out && tl < trace_cap && lane == 0) {
-            cilqr_trace_rec r;
-            r.status = status; r.trials = trials; r.accepted = flag; r.alpha_idx = alpha_idx;
-            r.lamb = lamb; r.new_J = new_J;
-            trace_out[(size_t)b * trace_cap + tl] = r;
-        }
-        tl++;
-        bool leave = false;
-        if (lamb > c.k->max_lamb) { end_reason = CILQR_END_MAX_LAMB; leave = true; }
-        else if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; leave = true; }
-        if (HELP) {
-            if (lane == 0) l.ctli[CTL_EXIT] = (leave || itr + 1 >= c.max_iter) ? 1 : 0;
-            __syncthreads(); // B4
-        }
-        if (leave) break;
-    }
-    if (ALM) {
-        J_cur = total_cost_lds<ALM>(c, l, al, lane); // J_final := get_total_cost(u_ret, x_ret) with the final multipliers
-        if (lane == 0) a.alm_rho[b] = al.rho;
-    }
-    // results: u, x of the last accepted trajectory
-    for (int k = lane; k <= N; k += CILQR_WAVE) {
-        double* xo = x_out + ((size_t)b * (N + 1) + k) * 4;
-        xo[0] = l.x[4 * k]; xo[1] = l.x[4 * k + 1]; xo[2] = l.x[4 * k + 2]; xo[3] = l.x[4 * k + 3];
-        if (k < N) {
-            double* uo = u_out + ((size_t)b * N + k) * 2;
-            uo[0] = l.u[2 * k]; uo[1] = l.u[2 * k + 1];
-        }
-    }
-    if (PROF && a.prof && lane == 0) {
-        ph_acc[PH_TOTAL] = (long long)__builtin_readcyclecounter() - t_begin;
-        ph_acc[PH_ITERS] = iters;
-        ph_acc[PH_REF_FALLBACKS] = n_fallback;
-        ph_acc[PH_TRIALS] = ls_trials;
-        for (int e = 0; e < CILQR_PROF_SLOTS; ++e) a.prof[(size_t)b * CILQR_PROF_SLOTS + e] = ph_acc[e];
-    }
-    if (lane == 0 && res_out) {
-        cilqr_result r;
-        r.J_init = J_init; r.J_final = J_cur; r.iters = iters; r.end_reason = end_reason;
-        r.final_status = status; r.ls_trials = ls_trials; r.cost_evals = cost_evals;
-        r.trace_len = (trace_out && tl > trace_cap) ? trace_cap : tl;
-        res_out[b] = r;
-    }
-    if (a.timeline && lane == 0) {
-        long long* tl_rec = a.timeline + 4 * (size_t)b;
-        tl_rec[0] = tl_start;
-        tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        tl_rec[2] = blockIdx.x;
-        tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
-    }
-    if (SHARE && share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
-}
-
-// The solve kernel.  Small batches: one block per trajectory (in the XCD-aware order above).  Large batches (a.next
-// set): PERSISTENT blocks — as many as the chip holds at once — that pull trajectories from a counter until none is
-// left.  The hardware's workgroup dispatcher hands blocks out in order, round-robin over the XCDs, and waits whenever
-// the XCD whose turn it is has no room: with solves of 1 to 8 ms a freed slot stood empty for 157 us (median; 7 % of
-// all slot time) before the next block began; pulling, the next solve begins 3 us after the last (measured with
-// cilqr_set_block_timeline, scripts/block_timeline.py: config 5 82.4 -> 75.8 ms).  Pulling also evens out the XCDs,
-// and a launch touches one scratch area per resident block instead of one per trajectory.  A block that finds no
-// trajectory left turns to the line searches of the blocks still running (SHARE builds).
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
-          bool SHARE = false>
-__global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
-k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
-        double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
-        cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
-    const int lane = threadIdx.x & (CILQR_WAVE - 1);
-    const bool persistent = !HELP && a.next != nullptr;
-    if (!persistent && (int)blockIdx.x >= a.B) return;
-    for (;;) { // (one call site: a second inlined copy of the solve costs the loop ~70 spilled vector registers; out of
-               //  line, with the arguments on the stack, a solve takes 7 % longer)
-        const unsigned b = persistent ? sh_add_u(a.next, 1u, lane) : (unsigned)trajectory_of_block(blockIdx.x, a.B);
-        if (b >= (unsigned)a.B) break;
-        solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE>(a, (int)b, persistent ? (int)blockIdx.x : (int)b, x0, last_u,
-                                                                      u_out, x_out, res_out, trace_out, trace_cap);
-        if (!persistent) break;
-    }
-    if (SHARE && persistent && a.sh_ctl != nullptr) {
-        const int N = NC ? NC : a.N;
-        Lds l;
-        carve(l, g_lds, N, a.W, ALM ? 1 : 0, (HELP || NTP == 2) ? 2 : 1, LG ? 1 : 0);
-        share_help<NCH, NC, ALM>(a, l, N, lane, (int)blockIdx.x);
-    }
-}
 
 __device__ inline void stage_xu(const Lds& l, int N, const double* x, const double* u, int lane) {
     for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) l.x[e] = x[e];
@@ -637,6 +95,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     __syncthreads();
     int idx0;
     ref_indices_lds(c, l, lane, idx0, a.W); // indices of the current trajectory: the guesses for its trials
+    seed_trial_indices(l, N, 1, lane);
     double* scr = a.scratch + (size_t)b * scratch_doubles(N);
     AlmSt al = load_alm(a, b, N);
     rollout_trials(c, l, scr, lane, n_alpha);
@@ -891,7 +350,29 @@ struct cilqr_handle {
                                // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
     int prof_B = 0;
     DevBuf st[16];
+    // resident blocks per CU of each persistent build (asked once per kernel and LDS size, not on every launch)
+    struct Occ { const void* kern; size_t shm; int per_cu; };
+    std::vector<Occ> occ;
+    // one launch per handle at a time: the control words, the scratch areas and the work-sharing state belong to the
+    // launch in flight.  A launch on another stream than the previous one waits for it (event, device side).
+    hipEvent_t ev_launch = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
 };
+
+// Persistent launches use one scratch area per resident block: never more than this many per CU, whatever the
+// occupancy query says (8 = two wavefronts per SIMD; ensure_scratch sizes the areas with the same number)
+#define CILQR_MAX_BLOCKS_PER_CU 8
+static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out) {
+    for (const auto& e : h->occ)
+        if (e.kern == kern && e.shm == shm) { *out = e.per_cu; return CILQR_OK; }
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CILQR_WAVE, shm));
+    per_cu = per_cu < 1 ? 1 : (per_cu > CILQR_MAX_BLOCKS_PER_CU ? CILQR_MAX_BLOCKS_PER_CU : per_cu);
+    h->occ.push_back({kern, shm, per_cu});
+    *out = per_cu;
+    return CILQR_OK;
+}
 
 // LDS lane window: enough samples for the horizon at 1.5x the target speed (anything beyond it is
 // still correct — lookups outside the window read global memory), a multiple of 64, <= 1024.
@@ -941,7 +422,11 @@ static int check_ready(cilqr_handle* h) {
 }
 
 extern "C" const char* cilqr_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.1 (gfx950, wave64, fp64)"; }
+#ifdef CILQR_DEV_BUILD
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.3-dev (gfx950, wave64, fp64; testing aids + cycle accounting)"; }
+#else
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.3 (gfx950, wave64, fp64)"; }
+#endif
 
 extern "C" int cilqr_create(int device, cilqr_handle** out) {
     if (!out) return fail(CILQR_ERR_BAD_ARG, "out is null");
@@ -952,7 +437,9 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
     HIP_TRY(hipSetDevice(device));
     cilqr_handle* h = new cilqr_handle();
     h->device = device;
-    // tuning experiments only (A/B runs on one box): CILQR_TUNE="helper_max_batch=1536,single_trial_min_batch=2560,..."
+#ifdef CILQR_DEV_BUILD
+    // tuning experiments only (A/B runs on one box, development library): CILQR_TUNE="helper_max_batch=1536,share=0,..."
+    // The production library does not read the environment: a variable must not change launch shapes in a deployed planner.
     if (const char* t = std::getenv("CILQR_TUNE")) {
         std::string sv(t);
         size_t pos = 0;
@@ -961,9 +448,11 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
             if (e == std::string::npos) e = sv.size();
             const std::string kv = sv.substr(pos, e - pos);
             const size_t eq = kv.find('=');
+            bool known = false;
             if (eq != std::string::npos) {
                 const std::string k = kv.substr(0, eq);
                 const int v = std::atoi(kv.c_str() + eq + 1);
+                known = true;
                 if (k == "helper_max_batch") h->helper_max_batch = v;
                 else if (k == "helper_max_batch_two_rows") h->helper_max_batch_two_rows = v;
                 else if (k == "occ2_min_batch") h->occ2_min_batch = v;
@@ -974,10 +463,13 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "share_min_t0") h->share_min_t0 = v;
                 else if (k == "share_backoff") h->share_backoff = v;
                 else if (k == "persistent_blocks") h->persistent_blocks = v;
+                else known = false;
             }
+            if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
             pos = e + 1;
         }
     }
+#endif
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -986,6 +478,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_launch, hipEventDisableTiming));
     *out = h;
     return CILQR_OK;
 }
@@ -1019,6 +512,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     if (h->one.dev) (void)hipFree(h->one.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_launch) (void)hipEventDestroy(h->ev_launch);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CILQR_OK;
@@ -1032,6 +526,9 @@ extern "C" int cilqr_set_timing(cilqr_handle* h, int32_t enabled) {
 
 extern "C" int cilqr_set_phase_profiling(cilqr_handle* h, int32_t enabled) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+#ifndef CILQR_DEV_BUILD
+    if (enabled) return fail(CILQR_ERR_UNSUPPORTED, "cycle accounting is built into libcilqr_amd_dev.so only");
+#endif
     h->profiling = enabled != 0;
     return CILQR_OK;
 }
@@ -1083,6 +580,9 @@ extern "C" int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, doubl
 
 extern "C" int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+#ifndef CILQR_DEV_BUILD
+    if (flags) return fail(CILQR_ERR_UNSUPPORTED, "the testing aids are built into libcilqr_amd_dev.so only");
+#endif
     h->debug_flags = flags;
     return CILQR_OK;
 }
@@ -1349,8 +849,9 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
 // above 63), barrier mode: those blocks help each other's line searches once they are done (k_solve's SHARE), which
 // beats the helper wavefront from 1536 trajectories on (N = 64 ... 80: 17.4 vs 20.0 ms at N = 72, B = 2048; below
 // that the helper wavefront is 10-20 % ahead) and from 512 on for N >= 96 (config 4's mix: 17.1 vs 28.2 ms at 1024,
-// 26.1 vs 50.0 at 2048; the two tie below).  The augmented-Lagrangian builds have no work sharing: their helper range
-// grows with the horizon as measured before it existed.
+// 26.1 vs 50.0 at 2048; the two tie below).  Of the augmented-Lagrangian builds only the one that keeps the cost
+// expansion in global memory (two rows per lane, large batches) shares work; the helper range of the others grows with
+// the horizon as measured before work sharing existed.
 static bool two_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE; }
 static bool wants_helper(const cilqr_handle* h, int B) {
     if (h->helper_mode >= 0) return h->helper_mode == 1;
@@ -1475,7 +976,7 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     }
     size_t areas = (size_t)B;
     if (fused && h->persistent_blocks && lone_two_per_simd(h, B) && (h->params[0].solve_type == 1 || (h->debug_flags == 0 && !h->profiling)))
-        areas = std::min<size_t>(areas, (size_t)8 * (size_t)h->num_cus);
+        areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
     if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
     // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
@@ -1527,6 +1028,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         a.timeline = static_cast<long long*>(h->tl.p);
         h->tl_B = B;
     }
+    if (h->launched && h->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_launch, 0)); // (see cilqr_handle::ev_launch)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     {
         const bool two = (a.N + 1 > CILQR_WAVE);
@@ -1537,10 +1039,10 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         bool one = false, lg = false, persistent = false;
         h->last_launch_shared = false;
         if (a.alm) {
-            if (help) kern = two ? k_solve<true, 2, true, true, false> : k_solve<true, 1, true, true, false>;
+            if (help) kern = two ? k_solve<CILQR_ALM_DBG, 2, true, true, false> : k_solve<CILQR_ALM_DBG, 1, true, true, false>;
             else if (lone_two_per_simd(h, B)) {
-                kern = two ? k_solve<true, 2, true, false, false, 2, 1> : k_solve<true, 1, true, false, false, 2, 1>;
-                if (global_expansion(h, B)) { kern = k_solve<true, 2, true, false, false, 2, 1, 0, true, true>; lg = true; }
+                kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1> : k_solve<CILQR_ALM_DBG, 1, true, false, false, 2, 1>;
+                if (global_expansion(h, B)) { kern = k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true>; lg = true; }
                 one = true;
                 persistent = true;
                 if (h->share && lg && h->sh_req.p) { // (the ALM build with work sharing is the two-row one)
@@ -1550,12 +1052,14 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
                     h->last_launch_shared = true;
                 }
             }
-            else kern = two ? k_solve<true, 2, true, false, false> : k_solve<true, 1, true, false, false>;
+            else kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false> : k_solve<CILQR_ALM_DBG, 1, true, false, false>;
+#ifdef CILQR_DEV_BUILD
         } else if (a.flags != 0) {
             kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
         } else if (a.prof) {
             kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
                         : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
+#endif
         } else if (help) {
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
             if (a.N == 50) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 50>;
@@ -1590,8 +1094,9 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         if (persistent && h->persistent_blocks) {
             // as many blocks as the chip holds at once; they pull trajectories from the counter
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CILQR_WAVE, shm));
-            const int cap = (per_cu > 0 ? per_cu : 1) * h->num_cus;
+            rc = blocks_per_cu(h, reinterpret_cast<const void*>(kern), shm, &per_cu);
+            if (rc) return rc;
+            const int cap = per_cu * h->num_cus;
             grid = B < cap ? B : cap;
             a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
             HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
@@ -1611,6 +1116,9 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed_pending = true;
     }
+    HIP_TRY(hipEventRecord(h->ev_launch, s));
+    h->last_stream = s;
+    h->launched = true;
     return CILQR_OK;
 }
 
@@ -1695,6 +1203,9 @@ extern "C" int cilqr_solve(cilqr_handle* h, const double* x0, const cilqr_scenar
     auto& o = h->one;
     const int N = h->params[0].N;
     const size_t L = (size_t)sc->L;
+    // upstream: RoutingLine::operator[] throws std::out_of_range (ut:52-58) — whether or not the routes happen to
+    // match what an earlier call uploaded
+    if (sc->M > 0 && sc->T < N + 1) return fail(CILQR_ERR_OBSTACLE_HORIZON, "obstacle route shorter than N + 1");
     int d = -1;
     if (o.valid && same_doubles(sc->lane_x, o.lane_x, L) && same_doubles(sc->lane_y, o.lane_y, L) &&
         same_doubles(sc->lane_yaw, o.lane_yaw, L) && sc->road_borders[0] == o.borders[0] &&
@@ -1716,7 +1227,6 @@ extern "C" int cilqr_solve(cilqr_handle* h, const double* x0, const cilqr_scenar
         }
     }
     if (d < 0) {
-        if (sc->M > 0 && sc->T < N + 1) return fail(CILQR_ERR_OBSTACLE_HORIZON, "obstacle route shorter than N + 1");
         o.valid = false;
         int rc = set_scenarios_impl(h, sc, 1);
         if (rc) return rc;

@@ -422,26 +422,83 @@ __device__ inline int local_min_near(const Cst& c, const Lds& l, double px, doub
     double cur = lane_d2(c, l, px, py, j);
     double nxt = lane_d2(c, l, px, py, j + 1);
     double prv = lane_d2(c, l, px, py, (j > lo) ? j - 1 : j);
+    // dec(i) = "d(i+1) < d(i)" with the reference's comparison.  A guess that is a few samples off (the small steps of
+    // a line search) is settled by the first trips below; one that is far off — the first trial of an iteration of a
+    // long horizon moves the late rows by a hundred samples and more — is found by doubling steps and bisection
+    // between a sample where the distance still decreases and one where it does not (dec(a) && !dec(b) is kept
+    // throughout, so whatever the profile looks like in between the result has the two facts above): O(log) round
+    // trips to the lane table instead of one per four samples forward / one per sample backward.
     if (dist_less(nxt, cur)) {
         j += 1;
         cur = nxt;
-        for (;;) {
-            double n1 = lane_d2(c, l, px, py, j + 1);
-            double n2 = lane_d2(c, l, px, py, j + 2);
-            double n3 = lane_d2(c, l, px, py, j + 3);
-            double n4 = lane_d2(c, l, px, py, j + 4);
-            bool f1 = dist_less(n1, cur), f2 = dist_less(n2, n1), f3 = dist_less(n3, n2), f4 = dist_less(n4, n3);
-            int adv = f1 ? (f2 ? (f3 ? (f4 ? 4 : 3) : 2) : 1) : 0;
-            j += adv;
-            cur = (adv == 0) ? cur : ((adv == 1) ? n1 : ((adv == 2) ? n2 : ((adv == 3) ? n3 : n4)));
-            if (adv < 4) break;
+        double n1 = lane_d2(c, l, px, py, j + 1);
+        double n2 = lane_d2(c, l, px, py, j + 2);
+        double n3 = lane_d2(c, l, px, py, j + 3);
+        double n4 = lane_d2(c, l, px, py, j + 4);
+        bool f1 = dist_less(n1, cur), f2 = dist_less(n2, n1), f3 = dist_less(n3, n2), f4 = dist_less(n4, n3);
+        int adv = f1 ? (f2 ? (f3 ? (f4 ? 4 : 3) : 2) : 1) : 0;
+        j += adv;
+        cur = (adv == 0) ? cur : ((adv == 1) ? n1 : ((adv == 2) ? n2 : ((adv == 3) ? n3 : n4)));
+        if (adv == 4) {
+            // dec(j - 1) holds; look further out in doubling steps (the table end stops every walk: d(L) = +inf)
+            int a = j - 1, step = 4;
+            double qb;
+            for (;;) {
+                int b = a + step;
+                b = (b > c.L - 1) ? c.L - 1 : b;
+                qb = lane_d2(c, l, px, py, b);
+                if (!dist_less(lane_d2(c, l, px, py, b + 1), qb)) { j = b; break; }
+                a = b;
+                step *= 2;
+            }
+            // dec(a), !dec(j), a < j
+            while (j - a > 1) {
+                const int mid = a + ((j - a) >> 1);
+                const double qm = lane_d2(c, l, px, py, mid);
+                if (dist_less(lane_d2(c, l, px, py, mid + 1), qm)) a = mid;
+                else { j = mid; qb = qm; }
+            }
+            cur = qb;
         }
-    } else {
-        while (j > lo) {
-            if (dist_less(cur, prv)) break; // strictly decreasing into j: the reference would not stop at j-1
-            j -= 1;
-            cur = prv; // and d(j+1) < d(j) was just found false for the new j
-            prv = lane_d2(c, l, px, py, (j > lo) ? j - 1 : j);
+    } else if (j > lo && !dist_less(cur, prv)) {
+        // !dec(j) and !dec(j - 1): the minimum lies behind the guess.  The next four samples back in one trip ...
+        const int j1 = j - 1;
+        const double p2 = lane_d2(c, l, px, py, (j1 - 1 > lo) ? j1 - 1 : lo);
+        const double p3 = lane_d2(c, l, px, py, (j1 - 2 > lo) ? j1 - 2 : lo);
+        const double p4 = lane_d2(c, l, px, py, (j1 - 3 > lo) ? j1 - 3 : lo);
+        const double p5 = lane_d2(c, l, px, py, (j1 - 4 > lo) ? j1 - 4 : lo);
+        // candidate m = j1 - t needs (m == lo or dec(m - 1)); !dec(m) is known for m = j1 and follows for each further
+        // step back from the failed dec of the step before
+        if (j1 == lo || dist_less(prv, p2)) { j = j1; cur = prv; }
+        else if (j1 - 1 == lo || dist_less(p2, p3)) { j = j1 - 1; cur = p2; }
+        else if (j1 - 2 == lo || dist_less(p3, p4)) { j = j1 - 2; cur = p3; }
+        else if (j1 - 3 == lo || dist_less(p4, p5)) { j = j1 - 3; cur = p4; }
+        else {
+            // ... then doubling steps back: !dec(b) at b = j1 - 4 (> lo here), look for an a < b with dec(a), or reach lo
+            int b = j1 - 4, step = 4;
+            double qb = p5;
+            int a;
+            bool found = false;
+            for (;;) {
+                a = b - step;
+                a = (a < lo) ? lo : a;
+                const double qa = lane_d2(c, l, px, py, a);
+                if (dist_less(lane_d2(c, l, px, py, a + 1), qa)) { found = true; break; }
+                b = a;
+                qb = qa;
+                if (a == lo) break;
+                step *= 2;
+            }
+            if (found) {
+                while (b - a > 1) {
+                    const int mid = a + ((b - a) >> 1);
+                    const double qm = lane_d2(c, l, px, py, mid);
+                    if (dist_less(lane_d2(c, l, px, py, mid + 1), qm)) a = mid;
+                    else { b = mid; qb = qm; }
+                }
+            }
+            j = b; // found: dec(b - 1) && !dec(b); not found: b == lo && !dec(lo)
+            cur = qb;
         }
     }
     *q_m = cur;
@@ -739,11 +796,23 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
     long long t0 = sub ? (long long)__builtin_readcyclecounter() : 0;
     // this lane's rows of the trials, fetched once
     double xk[NTR][NCH][4], uk[NTR][NCH][2], um[NTR][NCH][2];
-    int guess[NCH];
+    // Where each row starts looking: at the index the trial costed LAST in this slot has on that row (the rows of
+    // l.tidx are kept from trial to trial; the solve seeds them with the current trajectory's indices).  Inside a
+    // search that is the trial one or two step sizes up — as close as the current trajectory, which the seed and every
+    // accepted trial make it equal to.  It matters where the chain of cs:289-314 is unstable: a trajectory whose rows
+    // see two local minima of the distance (a lane that swerves) can sit on one branch while every trial, however
+    // small its step, chains along the other, 200 samples away; guessing from the current trajectory sends each of
+    // those trials down the serial chain (config 4: 304 trials of one solve, 45 of the launch's 52 ms), guessing from
+    // the previous trial only the first of a run.
+    int guess[NTR][NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int k = lane + CILQR_WAVE * ch;
-        guess[ch] = (k <= N) ? l.ridx[k] : idx0;
+    for (int tt = 0; tt < NTR; ++tt) {
+        const int* tix = l.tidx + (slot0 + tt) * (N + 2);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int k = lane + CILQR_WAVE * ch;
+            guess[tt][ch] = (k <= N) ? tix[k] : idx0;
+        }
     }
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) {
@@ -765,9 +834,10 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) proven[tt] = (tt >= nt);
     if (!(flags & CILQR_DBG_SERIAL_REF_SCAN)) {
-        // level 1: every row looks for its candidate near the index the current trajectory has on that row
+        // level 1: every row looks for its candidate — a local minimum of its distance profile — near its guess
         // (unchanged for the small steps of a failing line search: three samples and done) ...
         double qm[NTR][NCH];
+        int cand[NTR][NCH];
 #pragma unroll
         for (int tt = 0; tt < NTR; ++tt) {
             if (tt >= nt) continue;
@@ -776,37 +846,88 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
             for (int ch = 0; ch < NCH; ++ch) {
                 const int k = lane + CILQR_WAVE * ch;
                 qm[tt][ch] = 0.0;
+                cand[tt][ch] = 0;
                 if (k <= N) {
                     int m = idx0;
                     if (k > 0) {
-                        int g = guess[ch];
+                        int g = guess[tt][ch];
                         g = (g < idx0) ? idx0 : g;
                         g = (g > c.L - 1) ? c.L - 1 : g;
                         m = local_min_near(c, l, xk[tt][ch][0], xk[tt][ch][1], g, idx0, &qm[tt][ch]);
                     }
+                    cand[tt][ch] = m;
                     tix[k] = m;
                 }
             }
         }
         wave_sync();
-        // ... then the proof that the chain of cs:289-314 visits exactly these: row k's scan starts at
-        // m[k-1]; it must decrease strictly up to m[k] and stop there.  The two comparisons at m[k] come
-        // with the candidate; the interior is covered by the convexity certificate, else sample by sample.
+        // ... then the proof that the chain of cs:289-314 visits exactly these.  Row k's scan starts at idx[k-1] and
+        // only moves forward.  Where the candidates ascend, idx[k] = m[k] iff the distance decreases strictly from
+        // m[k-1] up to m[k] and stops there: the two comparisons at m[k] come with the candidate, the interior is
+        // covered by the convexity certificate, else sample by sample.  Where a candidate lies BEHIND the chain — the
+        // vehicle slows down, backs up or swerves and its nearest sample falls behind the one an earlier row has
+        // reached — the chain stays where it is, provided the distance does not decrease there: idx = the running
+        // maximum p of the candidates, and row k with m[k] <= p[k-1] has to show not d(p + 1) < d(p) at p = p[k-1]
+        // (one comparison; it came with the candidate when m[k] = p).  By induction from idx[0] = idx0.
+        // (config 4 has solves in which a score of rows stay behind on every trial trajectory: without the running
+        //  maximum each of their 300 trial costs went down the serial chain, through global memory: 45 ms of a 52 ms launch)
 #pragma unroll
         for (int tt = 0; tt < NTR; ++tt) {
             if (tt >= nt) continue;
-            const int* tix = l.tidx + (slot0 + tt) * (N + 2);
+            int* tix = l.tidx + (slot0 + tt) * (N + 2);
+            int lo_[NCH], hi_[NCH];
+            bool mono = true;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = lane + CILQR_WAVE * ch;
+                lo_[ch] = idx0;
+                hi_[ch] = cand[tt][ch];
+                if (k >= 1 && k <= N) {
+                    lo_[ch] = tix[k - 1];
+                    mono = mono && (lo_[ch] <= hi_[ch]);
+                }
+            }
+            if (__ballot(!mono) != 0ULL) {
+                // some candidate lies behind: running maximum over the rows (lane order, chunk after chunk)
+                wave_sync();
+                int carry = idx0;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = lane + CILQR_WAVE * ch;
+                    int v = (k <= N) ? cand[tt][ch] : 0;
+#pragma unroll
+                    for (int d = 1; d < CILQR_WAVE; d <<= 1) {
+                        const int o = __shfl_up(v, d, CILQR_WAVE);
+                        v = (lane >= d && o > v) ? o : v;
+                    }
+                    v = (carry > v) ? carry : v;
+                    carry = __shfl(v, CILQR_WAVE - 1, CILQR_WAVE);
+                    hi_[ch] = v;
+                    if (k <= N) tix[k] = v;
+                }
+                wave_sync();
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int k = lane + CILQR_WAVE * ch;
+                    if (k >= 1 && k <= N) lo_[ch] = tix[k - 1];
+                }
+            }
             bool ok = true, sampled = false;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int k = lane + CILQR_WAVE * ch;
                 if (k >= 1 && k <= N) {
-                    const int lo = tix[k - 1], hi = tix[k];
-                    bool good = (lo <= hi);
-                    if (good && hi - lo >= 2 && !convex_interior(c, qm[tt][ch], lo, hi)) {
-                        sampled = true;
-                        if (!verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], lo, hi))
-                            good = verify_interval(c, l, xk[tt][ch][0], xk[tt][ch][1], lo, hi);
+                    const int lo = lo_[ch], hi = hi_[ch];
+                    bool good = true;
+                    if (hi > lo) { // (then hi is this row's candidate)
+                        if (hi - lo >= 2 && !convex_interior(c, qm[tt][ch], lo, hi)) {
+                            sampled = true;
+                            if (!verify_window_fast(l, xk[tt][ch][0], xk[tt][ch][1], lo, hi))
+                                good = verify_interval(c, l, xk[tt][ch][0], xk[tt][ch][1], lo, hi);
+                        }
+                    } else if (cand[tt][ch] != lo) { // the chain stays at lo, ahead of this row's candidate
+                        good = !dist_less(lane_d2(c, l, xk[tt][ch][0], xk[tt][ch][1], lo + 1),
+                                          lane_d2(c, l, xk[tt][ch][0], xk[tt][ch][1], lo));
                     }
                     ok = ok && good;
                 }
@@ -1114,6 +1235,13 @@ __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, i
     // one loop per vehicle model: only that model's polynomial constants are live inside it
     if (c.rp == 0) rollout_trials_rp<0>(c, l, scr, lane, n_alpha, as);
     else rollout_trials_rp<1>(c, l, scr, lane, n_alpha, as);
+}
+
+// the rows of l.tidx start out as the current trajectory's indices (see the guesses of total_cost_trials)
+__device__ inline void seed_trial_indices(const Lds& l, int N, int slots, int lane) {
+    for (int s = 0; s < slots; ++s)
+        for (int k = lane; k <= N; k += CILQR_WAVE) l.tidx[s * (N + 2) + k] = l.ridx[k];
+    wave_sync();
 }
 
 // copy trial `a` (costed in slot `slot` of the last pass, whose index row is still in l.tidx) into the current trajectory

@@ -65,20 +65,26 @@ class SceneTable:
 class BatchedCILQR:
     """A device handle with its parameter table and scenario tables; batch entry points."""
 
-    def __init__(self, params, scenes=None, device=0):
-        self._lib = _lib.load()
+    def __init__(self, params, scenes=None, device=0, dev=False):
+        """dev=True loads libcilqr_amd_dev.so: the build that carries the testing aids (set_debug_flags) and the
+        in-kernel cycle accounting (set_phase_profiling); same kernels, same results otherwise."""
+        self._lib = _lib.load(dev)
+        self.dev = bool(dev)
         self._h = C.c_void_p()
-        check(self._lib.cilqr_create(int(device), C.byref(self._h)), "cilqr_create")
+        self._check(self._lib.cilqr_create(int(device), C.byref(self._h)), "cilqr_create")
         self.device = int(device)
         self.set_params(params)
         if scenes is not None:  # solve_one() brings its scenario with every call
             self.set_scenarios(scenes)
 
+    def _check(self, code, where):
+        check(code, where, self._lib)
+
     # -- tables -------------------------------------------------------------------------------
     def set_params(self, params):
         plist = list(params) if isinstance(params, (list, tuple)) else [params]
         arr = (CilqrParams * len(plist))(*[copy_params(p) for p in plist])
-        check(self._lib.cilqr_set_params(self._h, arr, len(plist)), "cilqr_set_params")
+        self._check(self._lib.cilqr_set_params(self._h, arr, len(plist)), "cilqr_set_params")
         self.params = plist
         self.N = int(plist[0].N)
 
@@ -86,7 +92,7 @@ class BatchedCILQR:
         slist = list(scenes) if isinstance(scenes, (list, tuple)) else [scenes]
         self._scenes = slist  # keep host arrays alive during the upload
         arr = (CilqrScenarioDesc * len(slist))(*[s.desc() for s in slist])
-        check(self._lib.cilqr_set_scenarios(self._h, arr, len(slist)), "cilqr_set_scenarios")
+        self._check(self._lib.cilqr_set_scenarios(self._h, arr, len(slist)), "cilqr_set_scenarios")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -110,7 +116,7 @@ class BatchedCILQR:
         x = np.empty((B, N + 1, 4))
         res = np.zeros(B, dtype=RESULT_DTYPE)
         trace = np.zeros((B, trace_cap), dtype=TRACE_DTYPE) if trace_cap > 0 else None
-        check(self._lib.cilqr_solve_batch(self._h, B, _p(x0), _p(sid), _p(pid), _p(tk), _p(lu), _p(u), _p(x),
+        self._check(self._lib.cilqr_solve_batch(self._h, B, _p(x0), _p(sid), _p(pid), _p(tk), _p(lu), _p(u), _p(x),
                                           _p(res), _p(trace), int(trace_cap)), "cilqr_solve_batch")
         out = {"u": u, "x": x, "res": res}
         if trace is not None:
@@ -127,91 +133,91 @@ class BatchedCILQR:
         x = np.empty((N + 1, 4))
         res = np.zeros(1, dtype=RESULT_DTYPE)
         d = scene.desc()
-        check(self._lib.cilqr_solve(self._h, _p(x0), C.byref(d), _p(lu), _p(u), _p(x), _p(res)), "cilqr_solve")
+        self._check(self._lib.cilqr_solve(self._h, _p(x0), C.byref(d), _p(lu), _p(u), _p(x), _p(res)), "cilqr_solve")
         return u, x, res[0]
 
     def solve_cache_stats(self):
         up, re = C.c_int64(0), C.c_int64(0)
-        check(self._lib.cilqr_solve_cache_stats(self._h, C.byref(up), C.byref(re)), "cilqr_solve_cache_stats")
+        self._check(self._lib.cilqr_solve_cache_stats(self._h, C.byref(up), C.byref(re)), "cilqr_solve_cache_stats")
         return int(up.value), int(re.value)
 
     def solve_batch_device(self, B, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u, d_x, d_res,
                            d_trace=0, trace_cap=0, stream=0):
         """Raw device-pointer form (ints): enqueue on `stream`, no synchronisation."""
-        check(self._lib.cilqr_solve_batch_device(self._h, int(B), d_x0, d_scenario_id or None, d_param_id or None,
+        self._check(self._lib.cilqr_solve_batch_device(self._h, int(B), d_x0, d_scenario_id or None, d_param_id or None,
                                                  d_tick or None, d_last_u or None, d_u, d_x, d_res or None,
                                                  d_trace or None, int(trace_cap), stream or None),
               "cilqr_solve_batch_device")
 
     def advance_batch_device(self, B, d_x, d_x0, d_tick=0, stream=0):
         """ego_state = x.row(1) and tick += 1 for every trajectory, on the device (raw pointers as ints)"""
-        check(self._lib.cilqr_advance_batch_device(self._h, int(B), d_x, d_x0, d_tick or None, stream or None),
+        self._check(self._lib.cilqr_advance_batch_device(self._h, int(B), d_x, d_x0, d_tick or None, stream or None),
               "cilqr_advance_batch_device")
 
     def set_timing(self, on=True):
-        check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
+        self._check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
 
     def set_phase_profiling(self, on=True):
-        check(self._lib.cilqr_set_phase_profiling(self._h, 1 if on else 0), "cilqr_set_phase_profiling")
+        self._check(self._lib.cilqr_set_phase_profiling(self._h, 1 if on else 0), "cilqr_set_phase_profiling")
 
     def phase_cycles(self, B):
         """[B][10]: cycles of init, derivatives, backward, rollout, trial cost, accept, total; then
         iterations, serial-ref-scan fallbacks, trials"""
         out = np.zeros((B, _lib.PROF_SLOTS), dtype=np.int64)
-        check(self._lib.cilqr_get_phase_cycles(self._h, _p(out), int(B)), "cilqr_get_phase_cycles")
+        self._check(self._lib.cilqr_get_phase_cycles(self._h, _p(out), int(B)), "cilqr_get_phase_cycles")
         return out
 
     def set_helper_mode(self, mode):
         """-1 automatic, 0 one wavefront per trajectory, 1 main + helper wavefront"""
-        check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
+        self._check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
 
     def set_rollout_mode(self, mode):
         """-1 adaptive, 0 all 20 step sizes in one rollout pass, 1 the first trial alone first"""
-        check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
+        self._check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
 
 
     def set_block_timeline(self, on=True):
-        check(self._lib.cilqr_set_block_timeline(self._h, 1 if on else 0), "cilqr_set_block_timeline")
+        self._check(self._lib.cilqr_set_block_timeline(self._h, 1 if on else 0), "cilqr_set_block_timeline")
 
     def block_timeline(self, B):
         """[B][4] int64: start, end (100 MHz ticks), block index, XCC of the block that solved each trajectory"""
         out = np.zeros((B, 4), dtype=np.int64)
-        check(self._lib.cilqr_get_block_timeline(self._h, _p(out), int(B)), "cilqr_get_block_timeline")
+        self._check(self._lib.cilqr_get_block_timeline(self._h, _p(out), int(B)), "cilqr_get_block_timeline")
         return out
 
     def set_work_sharing(self, mode):
         """1 (default): finished blocks cost line-search trials of the trajectories still being solved (horizons
         above 63, barrier mode, large batches); 0: off.  Same results either way."""
-        check(self._lib.cilqr_set_work_sharing(self._h, int(mode)), "cilqr_set_work_sharing")
+        self._check(self._lib.cilqr_set_work_sharing(self._h, int(mode)), "cilqr_set_work_sharing")
 
     def work_sharing_stats(self):
         """counters of the last launch that shared work: searches announced, trial costs delivered by other blocks,
         blocks that stayed to help, error flag"""
         out = (C.c_uint32 * 4)()
-        check(self._lib.cilqr_work_sharing_stats(self._h, out), "cilqr_work_sharing_stats")
+        self._check(self._lib.cilqr_work_sharing_stats(self._h, out), "cilqr_work_sharing_stats")
         return {"announced": int(out[0]), "helped": int(out[1]), "helpers": int(out[2]), "error": int(out[3])}
     def set_debug_flags(self, flags):
-        check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
+        self._check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
     def set_alm_state(self, mu=None, rho=None):
         B = (mu.shape[0] if mu is not None else np.asarray(rho).shape[0])
         mu = None if mu is None else _f64(mu)
         rho = None if rho is None else _f64(rho)
-        check(self._lib.cilqr_set_alm_state(self._h, int(B), _p(mu), _p(rho)), "cilqr_set_alm_state")
+        self._check(self._lib.cilqr_set_alm_state(self._h, int(B), _p(mu), _p(rho)), "cilqr_set_alm_state")
 
     def get_alm_state(self, B):
         cols = C.c_int32(0)
-        check(self._lib.cilqr_get_alm_state(self._h, int(B), None, None, None, C.byref(cols)), "cilqr_get_alm_state")
+        self._check(self._lib.cilqr_get_alm_state(self._h, int(B), None, None, None, C.byref(cols)), "cilqr_get_alm_state")
         mu = np.empty((B, self.N, cols.value))
         mun = np.empty((B, self.N, cols.value))
         rho = np.empty(B)
-        check(self._lib.cilqr_get_alm_state(self._h, int(B), _p(mu), _p(mun), _p(rho), C.byref(cols)),
+        self._check(self._lib.cilqr_get_alm_state(self._h, int(B), _p(mu), _p(mun), _p(rho), C.byref(cols)),
               "cilqr_get_alm_state")
         return mu, mun, rho
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
-        check(self._lib.cilqr_last_kernel_ms(self._h, C.byref(ms)), "cilqr_last_kernel_ms")
+        self._check(self._lib.cilqr_last_kernel_ms(self._h, C.byref(ms)), "cilqr_last_kernel_ms")
         return float(ms.value)
 
     # -- pieces --------------------------------------------------------------------------------
@@ -219,7 +225,7 @@ class BatchedCILQR:
         x0 = _f64(x0).reshape(-1, 4)
         B = x0.shape[0]
         x = np.empty((B, self.N + 1, 4))
-        check(self._lib.cilqr_init_traj_batch(self._h, B, _p(x0), _p(_i32(param_id)), _p(x)), "cilqr_init_traj_batch")
+        self._check(self._lib.cilqr_init_traj_batch(self._h, B, _p(x0), _p(_i32(param_id)), _p(x)), "cilqr_init_traj_batch")
         return x
 
     def ref_points(self, x, scenario_id=None, param_id=None):
@@ -227,7 +233,7 @@ class BatchedCILQR:
         B = x.shape[0]
         ref = np.empty((B, self.N + 1, 3))
         idx = np.empty((B, self.N + 1), dtype=np.int32)
-        check(self._lib.cilqr_ref_points_batch(self._h, B, _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
+        self._check(self._lib.cilqr_ref_points_batch(self._h, B, _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
                                                _p(ref), _p(idx)), "cilqr_ref_points_batch")
         return ref, idx
 
@@ -236,7 +242,7 @@ class BatchedCILQR:
         x = _f64(x).reshape(-1, self.N + 1, 4)
         B = x.shape[0]
         J = np.empty(B)
-        check(self._lib.cilqr_total_cost_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
+        self._check(self._lib.cilqr_total_cost_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)), _p(_i32(param_id)),
                                                _p(_i32(tick)), _p(J)), "cilqr_total_cost_batch")
         return J
 
@@ -250,7 +256,7 @@ class BatchedCILQR:
         nu = np.empty((B, n_alpha, N, 2))
         nx = np.empty((B, n_alpha, N + 1, 4))
         J = np.empty((B, n_alpha))
-        check(self._lib.cilqr_forward_pass_batch(self._h, B, _p(u), _p(x), _p(d), _p(K), _p(_i32(scenario_id)),
+        self._check(self._lib.cilqr_forward_pass_batch(self._h, B, _p(u), _p(x), _p(d), _p(K), _p(_i32(scenario_id)),
                                                  _p(_i32(param_id)), _p(_i32(tick)), int(n_alpha), _p(nu), _p(nx),
                                                  _p(J)), "cilqr_forward_pass_batch")
         return nu, nx, J
@@ -262,7 +268,7 @@ class BatchedCILQR:
         B = x.shape[0]
         out = {"l_x": np.empty((B, N + 1, 4)), "l_u": np.empty((B, N, 2)), "l_xx": np.empty((B, N + 1, 4, 4)),
                "l_uu": np.empty((B, N, 2, 2)), "A": np.empty((B, N, 4, 4)), "B": np.empty((B, N, 4, 2))}
-        check(self._lib.cilqr_cost_derivatives_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)),
+        self._check(self._lib.cilqr_cost_derivatives_batch(self._h, B, _p(u), _p(x), _p(_i32(scenario_id)),
                                                      _p(_i32(param_id)), _p(_i32(tick)), _p(out["l_x"]),
                                                      _p(out["l_u"]), _p(out["l_xx"]), _p(out["l_uu"]), _p(out["A"]),
                                                      _p(out["B"])), "cilqr_cost_derivatives_batch")
@@ -278,7 +284,7 @@ class BatchedCILQR:
         K = np.empty((B, N, 2, 4))
         dV = np.empty((B, 2))
         status = np.empty(B, dtype=np.int32)
-        check(self._lib.cilqr_backward_pass_batch(self._h, B, _p(u), _p(x), _p(lamb), _p(_i32(scenario_id)),
+        self._check(self._lib.cilqr_backward_pass_batch(self._h, B, _p(u), _p(x), _p(lamb), _p(_i32(scenario_id)),
                                                   _p(_i32(param_id)), _p(_i32(tick)), _p(d), _p(K), _p(dV),
                                                   _p(status)), "cilqr_backward_pass_batch")
         return d, K, dV, status
@@ -287,7 +293,7 @@ class BatchedCILQR:
         x = _f64(x).ravel()
         y = None if y is None else _f64(y).ravel()
         out = np.empty_like(x)
-        check(self._lib.cilqr_detmath_eval(self._h, int(func), _p(x), _p(y), x.shape[0], _p(out)), "cilqr_detmath_eval")
+        self._check(self._lib.cilqr_detmath_eval(self._h, int(func), _p(x), _p(y), x.shape[0], _p(out)), "cilqr_detmath_eval")
         return out
 
 
