@@ -396,15 +396,19 @@ def config1_closed_loop(args):
     solver = pkg.CILQRSolver(cfg, N=N)
     obs_full = sc.obstacles
     x0 = sc.ego_state.copy()
-    lat, its, states = [], [], [x0.copy()]
+    lat, its, states, kms = [], [], [x0.copy()], []
     for t in range(ticks):
         t0 = time.perf_counter()
         u, x = solver.solve(x0, sc.lane, sc.target_velocity, obs_full[:, t:], sc.road_borders)
         lat.append(time.perf_counter() - t0)
+        if t == 0:
+            solver._engine.set_timing(True)  # HIP events around the kernel from the second tick on
+        else:
+            kms.append(solver._engine.last_kernel_ms())
         its.append(int(solver.last_result["iters"]))
         x0 = x[1].copy()
         states.append(x0.copy())
-    lat, its = np.array(lat), np.array(its)
+    lat, its, kms = np.array(lat), np.array(its), np.array(kms)
     out = {"metric": "iLQR iterations/sec (batch x horizon)", "value": float(its[1:].sum() / lat[1:].sum()),
            "unit": "iLQR iterations/s", "n_gpus": 1, "steps": int(ticks), "warmup": 1,
            "ms_per_step": float(lat[1:].mean() * 1e3), "higher_is_better": True, "scaling": "weak",
@@ -416,6 +420,9 @@ def config1_closed_loop(args):
                      "solve_latency_ms": {"first_tick_incl_setup": float(lat[0] * 1e3), "mean": float(lat[1:].mean() * 1e3),
                                           "p50": float(np.median(lat[1:]) * 1e3), "max": float(lat[1:].max() * 1e3)},
                      "iterations_per_tick_mean": float(its.mean()), "iterations_total": int(its.sum()),
+                     "tick_split_ms": {"wall_mean": float(lat[1:].mean() * 1e3), "kernel_mean (HIP events)": float(kms.mean()),
+                                       "everything_else_mean (argument comparison, pinned staging, H2D, launch, D2H, "
+                                       "stream synchronisation, Python binding)": float(lat[1:].mean() * 1e3 - kms.mean())},
                      "note": "latency of the drop-in solve(): scenario tables re-used across ticks when unchanged, "
                              "host buffers in/out, one stream synchronisation per tick"}}
     if not args.no_cpu_baseline:
