@@ -289,6 +289,9 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
                 valu["mean_resident_waves"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (2.36e9 * kernel_ms * 1e-3)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_is": "bytes crossing the L2 <-> fabric boundary per launch (Infinity Cache + HBM; the counters cannot "
+                          "tell the two apart: profiles/r03_traffic_calibration.json), from the counter passes of the same "
+                          "command — a static file, not this run",
             "kernel": "k_solve", "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",

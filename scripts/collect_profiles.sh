@@ -44,7 +44,7 @@ $BENCH --config 2 --streams 4 --steps 40 --warmup 3 $ONLY > "$OUT/bench_pipeline
 fi
 
 # 5. in-kernel phase accounting
-for c in 2 3 5; do
+for c in 2 3 5 4; do
     $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
 done
 
@@ -55,3 +55,15 @@ CILQR_FORCE_DIST=1 $BENCH --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_f
 # 7. BASELINE configs[0]: single ego, closed loop through the drop-in solve()
 $BENCH --config 1 > "$OUT/bench_config1.json" 2> "$OUT/bench_config1.err"
 ls "$OUT" | head -80
+
+# 8. how the launches fill the chip: block timelines (raw records kept next to the summaries)
+for c in 3 4 5; do
+    TIMELINE_OUT="$OUT/timeline_c$c.npy" $PY $ROOT/scripts/block_timeline.py $c > "$OUT/timeline_config$c.json" 2> "$OUT/timeline_config$c.err"
+done
+
+# 9. where the wave-cycles go (SQ wait / active counters), headline and the two 8192-trajectory launches
+for a in "5 c5" "3 c3" "4 c4"; do set -- $a; $ROOT/scripts/stall_counters.sh $TAG "--config $1" $2 > /dev/null 2>&1; done
+
+# 10. the N > 1 code path of bench.py rehearsed with two processes on this one GPU (statistics over gloo): not a measurement
+CILQR_BENCH_ONE_DEVICE=1 CILQR_BENCH_BACKEND=gloo $PY -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+    --master-port 29577 $ROOT/bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/two_rank.json" 2> "$OUT/two_rank.err"

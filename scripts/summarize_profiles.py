@@ -83,9 +83,14 @@ for wl in ("c5", "c3", "c2", "c2b16k", "c4"):
         "kernel": f.get("kernel"),
         "source": f"profiles/{tag}_pmc.json: rocprofv3 --pmc <group> --kernel-trace -- python bench.py <workload> --steps 3 "
                   "--warmup 1 --no-cpu-baseline --no-extras, one counter group per pass (scripts/collect_profiles.sh); "
-                  "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 tallies 128-B read requests at 64 B "
-                  "(MI355X_MICROARCH.md, HBM section), so the read side is doubled — an upper bound for this kernel's "
-                  "mostly 8-byte gathers; WRITE_SIZE taken as reported",
+                  "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB = bytes that cross the L2 <-> fabric boundary, i.e. Infinity "
+                  "Cache + HBM together, NOT HBM alone.  Calibrated with known-byte kernels in this solver's access widths "
+                  "through the same passes (profiles/r03_traffic_calibration.json): FETCH_SIZE reports exactly half the "
+                  "fetched bytes for coalesced 16-B AND 8-B reads (128-B requests tallied at 64 B) and one 64-B tally (one "
+                  "128-B line) per 8-B read at the slab's 160-B stride; WRITE_SIZE reports the written bytes as they are "
+                  "(1.00 coalesced, 1.04 for the rollout's 160-byte rows); a 64 MiB working set re-read eight times — served "
+                  "by the 256 MiB Infinity Cache after the first pass — counts the same as a 1 GiB one, so cache hits there "
+                  "ARE counted",
         "FETCH_SIZE_KiB_per_launch": f["FETCH_SIZE"],
         "WRITE_SIZE_KiB_per_launch": w["WRITE_SIZE"],
         "hbm_bytes_per_launch_raw": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
@@ -123,7 +128,7 @@ if b:
                "sequential_value": b["value"], "pipelined": b["extra"]["pipelined"]},
               open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
 
-for c in (2, 3, 5):
+for c in (2, 3, 5, 4):
     p = os.path.join(src, f"phase_config{c}.json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_phase_config{c}.json"))
@@ -143,6 +148,32 @@ if b:
                "what": "bench.py's multi-GPU branch on one rank: init_process_group('nccl') = RCCL, dist.barrier(), the SUM "
                        "and MAX all-reduces of the statistics, destroy_process_group",
                "bench_line": b, "stderr_tail": err}, open(os.path.join(dst, f"{tag}_force_dist.json"), "w"), indent=1)
+for c in (3, 4, 5):
+    p = os.path.join(src, f"timeline_config{c}.json")
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_timeline_config{c}.json"))
+    # the raw per-trajectory records (start, end, block, XCC): what scripts/schedule_sim.py replays
+    p = os.path.join(src, f"timeline_c{c}.npy")
+    if os.path.exists(p) and c in (3, 4):
+        import numpy as np
+        tl = np.load(p)
+        np.savez_compressed(os.path.join(dst, f"{tag}_timeline_c{c}_raw.npz"), start_end_block_xcc=tl)
+b = last_json(os.path.join(src, "two_rank.json"))
+if b:
+    json.dump({"command": "CILQR_BENCH_ONE_DEVICE=1 CILQR_BENCH_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 "
+                          "bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu-baseline",
+               "what": "REHEARSAL of bench.py's N > 1 code path with two processes on the one-GPU box (both ranks on GPU 0, "
+                       "statistics reduced over gloo): it shows the line a multi-GPU run prints — rank identities, per-rank "
+                       "kernel times, guarded extras — not a measurement", "bench_line": b},
+              open(os.path.join(dst, f"{tag}_two_rank_rehearsal.json"), "w"), indent=1)
+if bench:
+    e = bench.get("extra", {})
+    if e.get("closed_loop"):
+        json.dump({"command": "python bench.py (default command, extra.closed_loop)", **e["closed_loop"]},
+                  open(os.path.join(dst, f"{tag}_closed_loop.json"), "w"), indent=1)
+    if e.get("config5_alm"):
+        json.dump({"command": "python bench.py (default command, extra.config5_alm)", **e["config5_alm"]},
+                  open(os.path.join(dst, f"{tag}_alm.json"), "w"), indent=1)
 b = last_json(os.path.join(src, "bench_config1.json"))
 if b:
     json.dump(b, open(os.path.join(dst, f"{tag}_config1.json"), "w"), indent=1)
