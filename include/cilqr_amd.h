@@ -203,6 +203,15 @@ int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode);
  * delivered by other blocks, blocks that stayed to help, 1 if a claimed trial was not delivered in time — the owner
  * then costs it itself and cilqr_solve_batch reports CILQR_ERR_DEVICE }. */
 int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]);
+/* Resumable solves (long horizons — two rows per lane — in batches that take more than one round of the chip's resident
+ * blocks): a solve runs `iters` iterations at a time; in between its state (x, u, lane indices, a dozen scalars: what
+ * cilqr_solver.cpp:110-141 carries from one iteration to the next) is parked in HBM and its number queued, and blocks pull
+ * fresh trajectories before parked ones — so the solves that will take 100 iterations are well under way when the short
+ * ones are done, instead of starting late and finishing alone.  Same results bit for bit (whoever resumes a solve
+ * computes the same numbers).  Default 32; 0 = every solve runs to its end in one go.  cilqr_resume_stats: how many
+ * times a solve was parked in the handle's last such launch. */
+int cilqr_set_resume_iters(cilqr_handle* h, int32_t iters);
+int cilqr_resume_stats(cilqr_handle* h, uint32_t* parked);
 
 /* Line-search rollouts (forward_pass for the step sizes of cs:354): -1 (default) = adaptive — an iteration rolls
  * out alpha = 1 alone and the other 19 step sizes only once that trial is rejected, unless the previous

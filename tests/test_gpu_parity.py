@@ -1381,3 +1381,41 @@ def test_single_ego_cache_hit_still_checks_the_obstacle_horizon(pkg, scenarios):
         assert e.value.code == pkg._lib.ERR_OBSTACLE_HORIZON
     u, x = solver.solve(x0, sc.lane, sc.target_velocity, sc.obstacles[:, :31], sc.road_borders)  # exactly N + 1: fine
     assert np.isfinite(x).all()
+
+
+def test_resumable_solves_are_transparent(pkg, orc_det):
+    """Long horizons in batches larger than the chip's 2048 resident blocks run RESUMABLE solves: a slice of iterations,
+    the state parked in HBM (x, u, lane indices, the scalars cs:110-141 carries), the solve queued and picked up again by
+    whichever block is free — fresh trajectories first.  Whatever the slice length, with and without the work sharing
+    between blocks, every output — decision traces included — is the one of the unsliced solve and of the oracle."""
+    wl = pkg.workloads.config4(B=4096)
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    ids = (wl.scenario_id, wl.param_id, wl.tick)
+    eng.set_resume_iters(0)
+    whole = eng.solve_batch(wl.x0, *ids, trace_cap=128)
+    assert eng.resume_stats() == 0
+    for iters, share in ((8, 1), (32, 1), (5, 0), (100000, 1)):
+        eng.set_resume_iters(iters)
+        eng.set_work_sharing(share)
+        out = eng.solve_batch(wl.x0, *ids, trace_cap=128)
+        parked = eng.resume_stats()
+        for k in ("u", "x"):
+            eq_bits(whole[k], out[k], f"{k} with {iters} iterations per slice, sharing {share}")
+        assert (whole["res"] == out["res"]).all() and (whole["trace"] == out["trace"]).all(), (iters, share)
+        if iters <= 32:
+            assert parked > 4096 // 4, (iters, parked)   # most solves of this mix outlast a slice
+        else:
+            assert parked == 0
+    eng.close()
+    scenes = [oracle_scene_tab(t) for t in wl.scenes]
+    rows = np.r_[0:24, 1402, 4081]
+    refs = [orc_det.solver(wl.params[wl.param_id[b]]).solve(wl.x0[b], scenes[wl.scenario_id[b]], trace_cap=128) for b in rows]
+    sub = {k: whole[k][rows] for k in ("u", "x", "res", "trace")}
+    compare_solves(sub, refs, "resumable (config 4, first rows)")
+    # a batch that fits the chip at once has nothing to reorder: its solves run whole
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    eng.set_resume_iters(8)
+    small = eng.solve_batch(wl.x0[:1800], wl.scenario_id[:1800], wl.param_id[:1800], wl.tick[:1800])
+    assert eng.resume_stats() == 0
+    eq_bits(small["x"], whole["x"][:1800], "small batch")
+    eng.close()

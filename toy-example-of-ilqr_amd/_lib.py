@@ -113,6 +113,8 @@ SIGNATURES = {
     "cilqr_set_rollout_mode": (C.c_int, [_P, _I]),
     "cilqr_set_work_sharing": (C.c_int, [_P, _I]),
     "cilqr_work_sharing_stats": (C.c_int, [_P, _P]),
+    "cilqr_set_resume_iters": (C.c_int, [_P, _I]),
+    "cilqr_resume_stats": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "cilqr_set_alm_state": (C.c_int, [_P, _I, _P, _P]),
     "cilqr_get_alm_state": (C.c_int, [_P, _I, _P, _P, _P, C.POINTER(_I)]),
     "cilqr_init_traj_batch": (C.c_int, [_P, _I, _P, _P, _P]),

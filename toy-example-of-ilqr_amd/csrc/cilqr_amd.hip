@@ -17,8 +17,8 @@
 #include "cilqr_kernels.hpp"
 
 // every build of k_solve is instantiated in cilqr_solve_inst.hip (one compilation per group, run in parallel)
-#define CILQR_X_EXTERN(g, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE) \
-    extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE> CILQR_SOLVE_SIGNATURE;
+#define CILQR_X_EXTERN(g, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES) \
+    extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES> CILQR_SOLVE_SIGNATURE;
 CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
 #undef CILQR_X_EXTERN
 
@@ -340,6 +340,12 @@ struct cilqr_handle {
     int tl_B = 0;
     bool last_launch_shared = false;
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
+    // resumable solves (k_solve's RES: the two-row builds in persistent launches): iterations per slice, 0 = off.  A
+    // launch whose batch fits the chip at once (no second round of trajectories) has nothing to reorder and runs whole.
+    int resume_iters = 32;
+    DevBuf park, rq;
+    int park_B = 0, park_N = 0;
+    unsigned last_parked = 0;
     DevBuf sh_ctl, sh_req, sh_hints;
     int sh_B = 0, sh_N = 0;
     int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
@@ -463,6 +469,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "share_min_t0") h->share_min_t0 = v;
                 else if (k == "share_backoff") h->share_backoff = v;
                 else if (k == "persistent_blocks") h->persistent_blocks = v;
+                else if (k == "resume_iters") h->resume_iters = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -502,6 +509,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     h->d_scenes.release();
     h->scratch.release();
     h->sh_ctl.release(); h->sh_req.release(); h->sh_hints.release();
+    h->park.release(); h->rq.release();
     h->tl.release();
     h->alm_mu.release();
     h->alm_mu_next.release();
@@ -600,6 +608,13 @@ extern "C" int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode) {
     return CILQR_OK;
 }
 
+extern "C" int cilqr_set_resume_iters(cilqr_handle* h, int32_t iters) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    if (iters < 0 || iters > 100000) return fail(CILQR_ERR_BAD_ARG, "iterations per slice must be in [0, 100000]");
+    h->resume_iters = iters;
+    return CILQR_OK;
+}
+
 extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
     if (!h || !out) return fail(CILQR_ERR_BAD_ARG, "null argument");
     out[0] = out[1] = out[2] = out[3] = 0;
@@ -609,6 +624,16 @@ extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
     unsigned w[SH_SLOT0];
     HIP_TRY(hipMemcpy(w, h->sh_ctl.p, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = w[SH_ANNOUNCED]; out[1] = w[SH_HELPED]; out[2] = w[SH_HELPERS]; out[3] = w[SH_ERROR];
+    h->last_parked = w[SH_PARKED];
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_resume_stats(cilqr_handle* h, uint32_t* parked) {
+    if (!h || !parked) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    uint32_t tmp[4];
+    int rc = cilqr_work_sharing_stats(h, tmp);
+    if (rc) return rc;
+    *parked = h->last_parked;
     return CILQR_OK;
 }
 
@@ -920,6 +945,11 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.sh_backoff = h->share_backoff < 0 ? 0 : (h->share_backoff > 8 ? 8 : h->share_backoff);
     a.timeline = nullptr;
     a.next = nullptr;
+    a.park = nullptr;
+    a.rq = nullptr;
+    a.ctl = static_cast<unsigned*>(h->sh_ctl.p);
+    a.rq_cap = 0;
+    a.res_iters = 0;
     return a;
 }
 
@@ -986,6 +1016,14 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     }
     // work sharing between blocks (builds of horizons above 63, barrier mode): one request and one row of hints per
     // trajectory
+    if (fused && two_rows(h) && h->resume_iters > 0 && (B > h->park_B || N != h->park_N || !h->park.p)) {
+        HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
+        h->park.release(); h->rq.release();
+        if (h->park.ensure(sizeof(double) * park_doubles(N) * (size_t)B) || h->rq.ensure(sizeof(unsigned long long) * (size_t)B))
+            return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
+        h->park_B = B;
+        h->park_N = N;
+    }
     if (two_rows(h) && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
         HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
         h->sh_req.release(); h->sh_hints.release();
@@ -1042,7 +1080,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             if (help) kern = two ? k_solve<CILQR_ALM_DBG, 2, true, true, false> : k_solve<CILQR_ALM_DBG, 1, true, true, false>;
             else if (lone_two_per_simd(h, B)) {
                 kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1> : k_solve<CILQR_ALM_DBG, 1, true, false, false, 2, 1>;
-                if (global_expansion(h, B)) { kern = k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true>; lg = true; }
+                if (global_expansion(h, B)) { kern = k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false>; lg = true; }
                 one = true;
                 persistent = true;
                 if (h->share && lg && h->sh_req.p) { // (the ALM build with work sharing is the two-row one)
@@ -1068,12 +1106,12 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             // (two rows per lane: built with work sharing between blocks, which a.sh_ctl switches on.  Shorter horizons
             //  are not: a trial costs 5 us there, the hand-over of a search about 10, and the build costs the solve loop
             //  3 % in spilled registers — measured: config 5 -5 %, config 3 -33 % with it, config 4 +25 %)
-            kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, true> : k_solve<false, 1, false, false, false, 2, 1>;
+            kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, true, true> : k_solve<false, 1, false, false, false, 2, 1>;
             if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
-            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, false, true>;
+            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, false, true, true>;
             if (global_expansion(h, B)) {
-                kern = k_solve<false, 2, false, false, false, 2, 1, 0, true, true>;
-                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true, true>;
+                kern = k_solve<false, 2, false, false, false, 2, 1, 0, true, true, true>;
+                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true, true, true>;
                 lg = true;
             }
             one = true;
@@ -1100,6 +1138,15 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             grid = B < cap ? B : cap;
             a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
             HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+            // resumable solves: the builds that carry them (two rows per lane, persistent), batches that take more than
+            // one round of the resident blocks
+            if (two && !a.alm && h->resume_iters > 0 && B > grid && h->park.p && h->park_B >= B && h->park_N == a.N) {
+                a.park = static_cast<double*>(h->park.p);
+                a.rq = static_cast<unsigned long long*>(h->rq.p);
+                HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
+                a.rq_cap = h->park_B;
+                a.res_iters = h->resume_iters;
+            }
         } else {
             a.sh_ctl = nullptr; // (the work sharing rides on the persistent blocks)
             a.sh_req = nullptr;

@@ -1304,8 +1304,12 @@ struct ShareReq {
     unsigned long long pad2;
 };
 static_assert(sizeof(ShareReq) == 192, "ShareReq layout");
-enum { SH_NEXT = 0 /* persistent blocks: the next trajectory */, SH_FINISHED = 1, SH_HELPERS = 2, SH_ERROR = 3, SH_ANNOUNCED = 4,
-       SH_HELPED = 5, SH_SLOT0 = 8 };
+// (the words that many blocks hammer sit 64 bytes apart: one L2 line serves ~90 atomics per microsecond, and the
+//  owners' once-per-iteration look at SH_HELPING must not queue behind two thousand idle blocks polling the queue)
+enum { SH_NEXT = 0 /* persistent blocks: the next trajectory */, SH_FINISHED = 16, SH_HELPING = 32 /* blocks helping right now */,
+       SH_Q_RESV = 48, SH_Q_HEAD = 64 /* queue of parked trajectories (resumable solves) */,
+       SH_HELPERS = 80 /* blocks that went helping (count) */, SH_ERROR = 81, SH_ANNOUNCED = 82, SH_HELPED = 83, SH_PARKED = 84,
+       SH_SLOT0 = 96 };
 #define CILQR_SH_NSLOT 64
 #define CILQR_SH_WORDS (SH_SLOT0 + CILQR_SH_NSLOT)
 #define CILQR_SH_PENDING 0x7ff8c11a5ea7ed00ULL /* a NaN no arithmetic produces */
@@ -1345,6 +1349,66 @@ __device__ inline unsigned sh_cas_u(unsigned* p, unsigned expected, unsigned des
 }
 __device__ inline void sh_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ inline void sh_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+// ---------------------------------------------------------------------------------------------
+// Resumable solves (k_solve's RES; long horizons in large batches).  A launch of 8192 trajectories on 2048 resident
+// wavefronts ends with a long tail: the solves that take 100 iterations are as long as a third of the launch, and the
+// ones that happen to be pulled late finish alone.  A solve therefore runs at most `res_iters` iterations at a time;
+// then its state — x, u, the lane indices and a dozen scalars, 5.3 KB at N = 100: exactly what cs:110-141 carries
+// from one iteration to the next — is parked in global memory and its number queued; blocks pull fresh trajectories
+// while there are any and parked ones after that, so every long solve is well under way when the short ones are done.
+// Whoever resumes it computes the same bits: the cost expansion of an unchanged trajectory (kept in LDS after a failed
+// pass, cs:469-475) is recomputed from the same inputs.  (scripts/schedule_sim.py replays measured launches through
+// this policy: configs[3]'s shard 51.1 -> 47.0 ms at 32 iterations per slice.)
+// Hand-over between blocks (which sit on different XCDs as a rule: their L2s are not coherent): every word of the
+// parked state is stored and loaded as an 8-byte agent-scope atomic (write-through / L1-bypassing on gfx950) — a valid
+// publication form on its own; an agent-scope release / acquire pair per park would write back and invalidate whole
+// L2s hundreds of times per millisecond in mid-launch (measured: the launch three times as long).
+// Queue: q[cap] 64-bit entries, cap >= batch (a trajectory is queued at most once at a time), entry = (push number + 1)
+// << 32 | trajectory; the launch starts with q zeroed.  push: the state's stores have completed (s_waitcnt), take a
+// number (SH_Q_RESV), store the entry.  pop: the entry at SH_Q_HEAD carries that head's number once it is there;
+// compare-and-swap the head.  State layout per trajectory (doubles): x | u | scalars | ridx (two per double).
+#define CILQR_PARK_SCALARS 16
+__host__ __device__ inline size_t park_doubles(int N) {
+    return (size_t)(4 * (N + 1) + 2 * N + CILQR_PARK_SCALARS + (N + 2) / 2 + 1);
+}
+__device__ inline void park_st(double* p, double v) { sh_st64(reinterpret_cast<unsigned long long*>(p), dm_to_bits(v)); }
+__device__ inline double park_ld(const double* p) { return dm_from_bits(sh_ld64(reinterpret_cast<const unsigned long long*>(p))); }
+__device__ inline void rq_push(unsigned* ctl, unsigned long long* q, unsigned cap, unsigned b, int lane) {
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's stores of the parked state have completed
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const unsigned s = __hip_atomic_fetch_add(ctl + SH_Q_RESV, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_st64(q + (s % cap), ((unsigned long long)(s + 1u) << 32) | (unsigned long long)b);
+        (void)__hip_atomic_fetch_add(ctl + SH_PARKED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// a parked trajectory if one is queued, else -1; never waits
+__device__ inline int rq_pop(unsigned* ctl, const unsigned long long* q, unsigned cap, int lane) {
+    int b = -1;
+    if (lane == 0) {
+        for (int tries = 0; tries < 64; ++tries) {
+            const unsigned h = sh_ld(ctl + SH_Q_HEAD);
+            const unsigned long long e = sh_ld64(q + (h % cap));
+            if ((unsigned)(e >> 32) != h + 1u) break; // nothing there (yet)
+            unsigned expect = h;
+            if (__hip_atomic_compare_exchange_strong(ctl + SH_Q_HEAD, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                b = (int)(unsigned)(e & 0xffffffffULL);
+                break;
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(b);
+}
+__device__ inline bool rq_nonempty(const unsigned* ctl, const unsigned long long* q, unsigned cap, int lane) {
+    int d = 0;
+    if (lane == 0) {
+        const unsigned h = sh_ld(ctl + SH_Q_HEAD);
+        d = ((unsigned)(sh_ld64(q + (h % cap)) >> 32) == h + 1u) ? 1 : 0;
+    }
+    return __builtin_amdgcn_readfirstlane(d) != 0;
+}
 
 // owner: announce the search whose trials t0 .. 19 sit in the slab; the owner keeps t0 and t0 + 1.  false = no slot free
 __device__ inline bool sh_open(unsigned* ctl, ShareReq* rq, int* hints, const int* ridx, int b, int slot, int N, int t0,

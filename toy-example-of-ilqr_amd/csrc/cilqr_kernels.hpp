@@ -47,6 +47,12 @@ struct BatchArgs {
                                 // per trajectory
     long long* timeline;        // optional [B][4]: start / end of the solve of trajectory b (constant 100 MHz clock), the
                                 // index of the block that solved it, the XCC it ran on (cilqr_set_block_timeline; null = off)
+    // resumable solves (k_solve's RES; null / 0 = every solve runs to its end in one go)
+    double* park;               // [B][park_doubles(N)] state of the solves that were interrupted
+    unsigned long long* rq;     // [rq_cap] queue of their numbers (counters in the control words: SH_Q_*)
+    unsigned* ctl;              // the launch's control words
+    int rq_cap;
+    int res_iters;              // iterations per slice
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -96,7 +102,13 @@ __device__ inline bool ids_valid(const BatchArgs& a, int b) {
 template <int NCH, int NC, bool ALM>
 __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, int lane, int me) {
     unsigned* const ctl = a.sh_ctl;
-    if (sh_add_u(ctl + SH_HELPERS, 1u, lane) >= (unsigned)a.sh_max_helpers) return; // enough of them already
+    // enough helpers already?  (a look first: the read-modify-write only when there is a chance)
+    if (sh_ld_u(ctl + SH_HELPING, lane) >= (unsigned)a.sh_max_helpers) return; // (a look first: no read-modify-write without a chance)
+    if (sh_add_u(ctl + SH_HELPING, 1u, lane) >= (unsigned)a.sh_max_helpers) {
+        (void)sh_add_u(ctl + SH_HELPING, 0u - 1u, lane);
+        return;
+    }
+    (void)sh_add_u(ctl + SH_HELPERS, 1u, lane);
     int cur_b = -1, idx0h = 0, nfb = 0, idle = 0, slot_b = 0;
     unsigned cur_seq = 0;
     Cst c2;
@@ -153,6 +165,7 @@ __device__ __attribute__((noinline)) void share_help(BatchArgs a, Lds l, int N, 
             for (int r = 0; r < (1 << idle); ++r) __builtin_amdgcn_s_sleep(32);
         }
     }
+    (void)sh_add_u(ctl + SH_HELPING, 0u - 1u, lane);
 }
 
 // Which trajectory a block solves.  Workgroups go to the chip's eight XCDs round-robin (block i to XCD i mod 8) and
@@ -198,8 +211,32 @@ enum { CTLD_JH = 0, CTLD_JM = 2, CTLD_JCUR = 4, CTLD_DV = 5, CTLD_RHO = 7 };
 // SHARE = blocks that have finished help the ones still running with their line searches (ShareReq; lone wavefronts,
 // barrier mode, one trial per pass); switched on per launch by a.sh_ctl
 // solve_one = the solve of trajectory b by the calling block; `slot` = which scratch area (slab, ...) it uses
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE>
-__device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const int slot, const double* __restrict__ x0,
+// A parked solve's state between global memory (8-byte agent-scope atomics, see rq_push) and the block's LDS: x, u, the
+// lane indices, and the solve's scalars through 12 doubles of LDS (`sc`).  Out of line: it runs once per slice, and
+// inlined its loops raise the register pressure of the whole solve (80 -> 153 spilled vector registers).
+__device__ __attribute__((noinline)) void park_copy(double* pk, double* lx, double* lu, int* ridx, double* sc, int N, int lane,
+                                                    int store) {
+    double* const pk_sc = pk + 4 * (N + 1) + 2 * N;
+    unsigned* const pk_ix = reinterpret_cast<unsigned*>(pk_sc + CILQR_PARK_SCALARS);
+    if (store) {
+        for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) park_st(pk + e, lx[e]);
+        for (int e = lane; e < 2 * N; e += CILQR_WAVE) park_st(pk + 4 * (N + 1) + e, lu[e]);
+        for (int k = lane; k <= N; k += CILQR_WAVE) sh_st(pk_ix + k, (unsigned)ridx[k]);
+        if (lane < 12) park_st(pk_sc + lane, sc[lane]);
+    } else {
+        for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) lx[e] = park_ld(pk + e);
+        for (int e = lane; e < 2 * N; e += CILQR_WAVE) lu[e] = park_ld(pk + 4 * (N + 1) + e);
+        for (int k = lane; k <= N; k += CILQR_WAVE) ridx[k] = (int)sh_ld(pk_ix + k);
+        if (lane < 12) sc[lane] = park_ld(pk_sc + lane);
+    }
+    wave_sync();
+}
+
+// RES = resumable: the solve runs a.res_iters iterations at a time and is parked in between (see rq_push); `resumed` = this
+// call continues a parked solve.  Returns true when the solve was parked again (its number has been queued).
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE, bool RES>
+__device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const int slot, const bool resumed,
+                                          const double* __restrict__ x0,
                                           const double* __restrict__ last_u, double* __restrict__ u_out,
                                           double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
                                           cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
@@ -207,10 +244,13 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     const int wave = HELP ? (threadIdx.x >> 6) : 0;
     const long long tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     static_assert(!SHARE || (!HELP && !PROF && NTP == 1), "work sharing: lone wavefronts costing one trial per pass");
+    static_assert(!RES || (!HELP && !PROF && !ALM), "resumable solves: lone wavefronts, barrier mode (the multipliers of the "
+                                                      "augmented Lagrangian are large arrays written with plain stores)");
+    const bool res_on = RES && a.park != nullptr;
     const bool share = SHARE && a.sh_ctl != nullptr;
     const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
-        if (share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
+        if (share || res_on) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
         if (wave == 0) {
             const double qnan = dm_from_bits(0x7ff8000000000000ULL);
             for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = qnan;
@@ -222,7 +262,7 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
                 res_out[b] = r;
             }
         }
-        return;
+        return false;
     }
     Lds l;
     constexpr int SLOTS = (HELP || NTP == 2) ? 2 : 1; // trials costed concurrently (the host sizes the LDS block alike)
@@ -275,12 +315,12 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
             __syncthreads(); // B4
             if (l.ctli[CTL_EXIT]) break;
         }
-        return;
+        return false;
     }
     // the main wavefront carries the serial chain of the solve: it wins issue arbitration against the helper
     // wavefront (of another block) it shares its SIMD with
     if (HELP) __builtin_amdgcn_s_setprio(2);
-    if (ALM && last_u == nullptr) {
+    if (ALM && last_u == nullptr && !(RES && resumed)) {
         // cs:88-93: fresh multipliers unless this call continues a previous solution
         al.rho = c.k->alm_rho_init;
         for (int e = lane; e < N * al.C; e += CILQR_WAVE) { al.mu[e] = 0.0; al.mu_next[e] = 0.0; }
@@ -296,12 +336,30 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     }
     const long long t_begin = (PROF && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     PROF_T0();
-    const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
     int idx0;
-    init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
-    seed_trial_indices(l, N, SLOTS, lane);
-    double J_cur = total_cost_lds<ALM>(c, l, al, lane);
-    const double J_init = J_cur;
+    double J_cur, J_init;
+    double r_lamb = 0.0;  // the other scalars of a resumed solve, applied where the solve's own are set up
+    int r_status = 0, r_iters = 0, r_trials = 0, r_evals = 0, r_tl = 0, r_flag = 0, r_deep = 0, r_seq = 1;
+    double* const pk = (RES && res_on) ? a.park + (size_t)b * park_doubles(N) : nullptr;
+    if (RES && resumed) {
+        // the parked state: x, u, lane indices (the window is staged again from the same row-0 index)
+        double* const sc_ = l.xch; // (12 doubles: the sweep's constants and, behind them, the helper-mode words — free here)
+        park_copy(pk, l.x, l.u, l.ridx, sc_, N, lane, 0);
+        idx0 = uniform_int((int)sc_[10]);
+        stage_window(c, l, idx0, a.W, lane);
+        seed_trial_indices(l, N, SLOTS, lane);
+        J_cur = sc_[0];
+        J_init = sc_[1];
+        r_lamb = sc_[2]; r_status = (int)sc_[3]; r_iters = (int)sc_[4]; r_trials = (int)sc_[5]; r_evals = (int)sc_[6];
+        r_tl = (int)sc_[7]; r_flag = (int)sc_[8]; r_deep = (int)sc_[9]; r_seq = (int)sc_[11];
+        wave_sync();
+    } else {
+        const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
+        init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
+        seed_trial_indices(l, N, SLOTS, lane);
+        J_cur = total_cost_lds<ALM>(c, l, al, lane);
+        J_init = J_cur;
+    }
     PROF_ADD(PH_INIT);
     if (HELP) {
         if (lane == 0) { l.ctli[CTL_IDX0] = idx0; l.ctli[CTL_W0] = l.w0; l.ctli[CTL_W] = l.W; }
@@ -314,6 +372,8 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     int end_reason = CILQR_END_MAX_ITER;
     int flag = 0;
     int n_fallback = 0;
+    int itr0 = 0;              // resumable solves: the iteration this slice starts at
+    bool fresh_expansion = false; // ... and its first iteration expands afresh whatever the status says (see below)
     // Line-search rollouts.  88 % / 71 % of the iterations of BASELINE configs 2 / 5 accept the first trial
     // (profiles/r02_trial_depth_histogram.json), 6-14 % try all 20 and the rest is spread evenly between.  An
     // iteration therefore either rolls out alpha = 1 alone into the small first-trial buffer and only on
@@ -323,21 +383,37 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     bool deep_next = false;
     ShareReq* const rq = share ? a.sh_req + b : nullptr;
     unsigned sh_seq = 1; // the searches of this trajectory that were announced, counted (a closed request holds the next number)
-    for (int itr = 0; itr < c.max_iter; ++itr) {
+    if (RES && resumed) {
+        lamb = r_lamb;
+        status = uniform_int(r_status);
+        iters = uniform_int(r_iters);
+        ls_trials = uniform_int(r_trials);
+        cost_evals = uniform_int(r_evals);
+        tl = uniform_int(r_tl);
+        flag = uniform_int(r_flag);
+        deep_next = uniform_int(r_deep) != 0;
+        sh_seq = (unsigned)uniform_int(r_seq);
+        itr0 = iters;
+        fresh_expansion = true; // the expansion a failed pass keeps (cs:469-475) stayed behind with the block that parked
+    }
+    bool parked = false;
+    for (int itr = itr0; itr < c.max_iter; ++itr) {
         // are there idle blocks?  (asked here, needed after the backward sweep: the answer's latency is hidden)
         unsigned sh_probe = 0;
-        if (share && lane == 0) sh_probe = sh_ld(a.sh_ctl + SH_HELPERS);
+        if (share && lane == 0) sh_probe = sh_ld(a.sh_ctl + SH_HELPING);
         // ---- iter_step ----
         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
         if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
         // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
-        if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP) {
+        if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP || (RES && fresh_expansion)) {
+            // (resumed after a failed pass: the same trajectory expanded again — the same bits as the kept expansion)
             cost_and_model_derivatives<ALM, LG>(c, l, al, lane);
         } else {
             model_jacobians(c, l, lane); // the gains of the failed pass sit where A, B were
         }
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
+        if (RES) fresh_expansion = false;
         double dV[2];
         bool ok = backward_sweep<(DBG && !ALM), LG ? (ALM ? CILQR_GL_ROW_ALM : CILQR_GL_ROW) : 0>(c, l, lamb, lane, dV, a.flags);
         wave_sync();
@@ -485,6 +561,25 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
             __syncthreads(); // B4
         }
         if (leave) break;
+        if (RES && res_on && itr + 1 - itr0 >= a.res_iters && itr + 1 < c.max_iter) {
+            // the slice is over: park, unless nothing else wants this block (then carry on for another slice)
+            if (sh_ld_u(a.next, lane) < (unsigned)a.B || rq_nonempty(a.ctl, a.rq, (unsigned)a.rq_cap, lane)) { parked = true; break; }
+            itr0 = itr + 1;
+        }
+    }
+    if (RES && parked) {
+        // park: what cs:110-141 carries from one iteration to the next
+        double* const sc_ = l.xch;
+        if (lane == 0) {
+            sc_[0] = J_cur; sc_[1] = J_init; sc_[2] = lamb; sc_[3] = (double)status; sc_[4] = (double)iters;
+            sc_[5] = (double)ls_trials; sc_[6] = (double)cost_evals; sc_[7] = (double)tl; sc_[8] = (double)flag;
+            sc_[9] = deep_next ? 1.0 : 0.0; sc_[10] = (double)idx0; sc_[11] = (double)sh_seq;
+        }
+        wave_sync();
+        park_copy(pk, l.x, l.u, l.ridx, sc_, N, lane, 1);
+        if (a.timeline && lane == 0 && !resumed) a.timeline[4 * (size_t)b] = tl_start;
+        rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
+        return true;
     }
     if (ALM) {
         J_cur = total_cost_lds<ALM>(c, l, al, lane); // J_final := get_total_cost(u_ret, x_ret) with the final multipliers
@@ -515,12 +610,13 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
     }
     if (a.timeline && lane == 0) {
         long long* tl_rec = a.timeline + 4 * (size_t)b;
-        tl_rec[0] = tl_start;
+        if (!(RES && resumed)) tl_rec[0] = tl_start;  // (a resumed solve keeps the start of its first slice)
         tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
         tl_rec[2] = blockIdx.x;
         tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
     }
-    if (SHARE && share) (void)sh_add_u(a.sh_ctl + SH_FINISHED, 1u, lane);
+    if ((SHARE && share) || (RES && res_on)) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
+    return false;
 }
 
 // The solve kernel.  Small batches: one block per trajectory (in the XCD-aware order above).  Large batches (a.next
@@ -532,7 +628,7 @@ __device__ __forceinline__ void solve_one(const BatchArgs& a, const int b, const
 // and a launch touches one scratch area per resident block instead of one per trajectory.  A block that finds no
 // trajectory left turns to the line searches of the blocks still running (SHARE builds).
 template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
-          bool SHARE = false>
+          bool SHARE = false, bool RES = false>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -540,12 +636,28 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const bool persistent = !HELP && a.next != nullptr;
     if (!persistent && (int)blockIdx.x >= a.B) return;
+    const bool res_on = RES && persistent && a.park != nullptr;
+    bool fresh_left = true;
     for (;;) { // (one call site: a second inlined copy of the solve costs the loop ~70 spilled vector registers; out of
                //  line, with the arguments on the stack, a solve takes 7 % longer)
-        const unsigned b = persistent ? sh_add_u(a.next, 1u, lane) : (unsigned)trajectory_of_block(blockIdx.x, a.B);
-        if (b >= (unsigned)a.B) break;
-        solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE>(a, (int)b, persistent ? (int)blockIdx.x : (int)b, x0, last_u,
-                                                                      u_out, x_out, res_out, trace_out, trace_cap);
+        unsigned b = (unsigned)a.B;
+        bool resumed = false;
+        if (!persistent) b = (unsigned)trajectory_of_block(blockIdx.x, a.B);
+        else if (fresh_left) b = sh_add_u(a.next, 1u, lane);
+        if (b >= (unsigned)a.B) {
+            if (!res_on) break;
+            // resumable solves: no fresh trajectory left — a parked one, else this block is done.  (No solve is stranded:
+            // a block only gets here after FINISHING a solve, so every unfinished solve is either running on a block that
+            // is still in this loop or queued; and a block that parks a solve comes straight back for one.)
+            fresh_left = false;
+            const int pb = rq_pop(a.ctl, a.rq, (unsigned)a.rq_cap, lane);
+            if (pb < 0) break;
+            b = (unsigned)pb;
+            resumed = true;
+        }
+        (void)solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES>(a, (int)b, persistent ? (int)blockIdx.x : (int)b,
+                                                                                 resumed, x0, last_u, u_out, x_out, res_out,
+                                                                                 trace_out, trace_cap);
         if (!persistent) break;
     }
     if (SHARE && persistent && a.sh_ctl != nullptr) {
@@ -557,7 +669,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------------
-// The builds of k_solve the library carries: X(group, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE).
+// The builds of k_solve the library carries: X(group, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES).
 // `group` = which compilation of cilqr_solve_inst.hip instantiates it (toy-example-of-ilqr_amd/build.py runs the
 // groups in parallel).  The production library carries neither the testing-aid builds (DBG: cilqr_set_debug_flags)
 // nor the cycle-accounting builds (PROF: cilqr_set_phase_profiling); the development library, libcilqr_amd_dev.so
@@ -569,33 +681,33 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
 #define CILQR_ALM_DBG false
 #endif
 #define CILQR_SOLVE_VARIANTS_PROD(X)                                            \
-    X(0, false, 1, false, false, false, 1, CILQR_NT, 0, false, false)           \
-    X(0, false, 2, false, false, false, 1, CILQR_NT, 0, false, false)           \
-    X(1, false, 1, false, true, false, 1, CILQR_NT, 0, false, false)            \
-    X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false)            \
-    X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false)           \
-    X(2, false, 2, false, true, false, 1, CILQR_NT, 100, false, false)          \
-    X(3, false, 1, false, false, false, 2, 1, 0, false, false)                  \
-    X(3, false, 2, false, false, false, 2, 1, 0, false, true)                   \
-    X(4, false, 1, false, false, false, 2, 1, 50, false, false)                 \
-    X(4, false, 2, false, false, false, 2, 1, 100, false, true)                 \
-    X(5, false, 2, false, false, false, 2, 1, 0, true, true)                    \
-    X(5, false, 2, false, false, false, 2, 1, 100, true, true)                  \
-    X(6, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false)     \
-    X(6, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false)     \
-    X(7, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false)           \
-    X(7, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false)           \
-    X(0, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true)             \
-    X(1, CILQR_ALM_DBG, 1, true, false, false, 1, CILQR_NT, 0, false, false)    \
-    X(2, CILQR_ALM_DBG, 2, true, false, false, 1, CILQR_NT, 0, false, false)
+    X(0, false, 1, false, false, false, 1, CILQR_NT, 0, false, false, false)           \
+    X(0, false, 2, false, false, false, 1, CILQR_NT, 0, false, false, false)           \
+    X(1, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false)            \
+    X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false)            \
+    X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false, false)           \
+    X(2, false, 2, false, true, false, 1, CILQR_NT, 100, false, false, false)          \
+    X(3, false, 1, false, false, false, 2, 1, 0, false, false, false)                  \
+    X(3, false, 2, false, false, false, 2, 1, 0, false, true, true)                   \
+    X(4, false, 1, false, false, false, 2, 1, 50, false, false, false)                 \
+    X(4, false, 2, false, false, false, 2, 1, 100, false, true, true)                 \
+    X(5, false, 2, false, false, false, 2, 1, 0, true, true, true)                    \
+    X(5, false, 2, false, false, false, 2, 1, 100, true, true, true)                  \
+    X(6, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false)     \
+    X(6, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false)     \
+    X(7, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false)           \
+    X(7, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false)           \
+    X(0, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false)             \
+    X(1, CILQR_ALM_DBG, 1, true, false, false, 1, CILQR_NT, 0, false, false, false)    \
+    X(2, CILQR_ALM_DBG, 2, true, false, false, 1, CILQR_NT, 0, false, false, false)
 #ifdef CILQR_DEV_BUILD
 #define CILQR_SOLVE_VARIANTS_DEV(X)                                             \
-    X(3, true, 1, false, false, false, 1, CILQR_NT, 0, false, false)            \
-    X(4, true, 2, false, false, false, 1, CILQR_NT, 0, false, false)            \
-    X(5, false, 1, false, true, true, 1, CILQR_NT, 0, false, false)             \
-    X(6, false, 2, false, true, true, 1, CILQR_NT, 0, false, false)             \
-    X(7, false, 1, false, false, true, 1, CILQR_NT, 0, false, false)            \
-    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false)
+    X(3, true, 1, false, false, false, 1, CILQR_NT, 0, false, false, false)            \
+    X(4, true, 2, false, false, false, 1, CILQR_NT, 0, false, false, false)            \
+    X(5, false, 1, false, true, true, 1, CILQR_NT, 0, false, false, false)             \
+    X(6, false, 2, false, true, true, 1, CILQR_NT, 0, false, false, false)             \
+    X(7, false, 1, false, false, true, 1, CILQR_NT, 0, false, false, false)            \
+    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false, false)
 #else
 #define CILQR_SOLVE_VARIANTS_DEV(X)
 #endif

@@ -196,6 +196,18 @@ class BatchedCILQR:
         out = (C.c_uint32 * 4)()
         self._check(self._lib.cilqr_work_sharing_stats(self._h, out), "cilqr_work_sharing_stats")
         return {"announced": int(out[0]), "helped": int(out[1]), "helpers": int(out[2]), "error": int(out[3])}
+
+    def set_resume_iters(self, iters):
+        """iterations per slice of the resumable solves (long horizons in batches larger than the chip holds at once);
+        0 = off.  Same results either way."""
+        self._check(self._lib.cilqr_set_resume_iters(self._h, int(iters)), "cilqr_set_resume_iters")
+
+    def resume_stats(self):
+        """how many times a solve was parked in the last launch that ran resumable solves"""
+        n = C.c_uint32(0)
+        self._check(self._lib.cilqr_resume_stats(self._h, C.byref(n)), "cilqr_resume_stats")
+        return int(n.value)
+
     def set_debug_flags(self, flags):
         self._check(self._lib.cilqr_set_debug_flags(self._h, int(flags)), "cilqr_set_debug_flags")
 
