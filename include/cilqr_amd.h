@@ -240,7 +240,9 @@ int cilqr_set_debug_flags(cilqr_handle* h, int32_t flags);
 int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B);
 /* Development aid: when enabled, the fused solve records per trajectory when the block that solved it started and
  * ended (constant 100 MHz clock), that block's index and the XCC (chiplet) it ran on — out[B][4] — which shows how
- * the launch fills the chip over time (scripts/block_timeline.py). */
+ * the launch fills the chip over time (scripts/block_timeline.py).  A launch that runs resumable solves has no one
+ * block per trajectory: there the record holds the start of the first slice, the end of the last, MINUS the time the
+ * solve was actually running (100 MHz ticks, summed over its slices) in place of the block index, and the last XCC. */
 int cilqr_set_block_timeline(cilqr_handle* h, int32_t enabled);
 int cilqr_get_block_timeline(cilqr_handle* h, int64_t* out, int32_t B);
 

@@ -22,13 +22,23 @@ eng.set_timing(True)
 r = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
 kms = eng.last_kernel_ms()
 tl = eng.block_timeline(wl.B)
+eng_parked = eng.resume_stats()
 eng.close()
 t0 = tl[:, 0].min()
 st, en = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0  # microseconds
 span = en.max()
+sliced = bool((tl[:, 2] < 0).any())   # resumable solves: [2] = minus the busy time (ticks) instead of the block index
+busy = np.where(tl[:, 2] < 0, -tl[:, 2] / 100.0, en - st) if sliced else (en - st)
 out = {"workload": wl.name, "kernel_ms": kms, "span_ms_by_block_clock": span / 1e3,
-       "mean_resident_blocks": float((en - st).sum() / span),
-       "block_ms": {"mean": float((en - st).mean() / 1e3), "p50": float(np.median(en - st) / 1e3), "max": float((en - st).max() / 1e3)}}
+       "resumable_solves": sliced, "parked": eng_parked,
+       "mean_resident_blocks": float(busy.sum() / span),
+       "block_ms": {"mean": float(busy.mean() / 1e3), "p50": float(np.median(busy) / 1e3), "max": float(busy.max() / 1e3)},
+       "first_start_to_last_end_ms": {"mean": float((en - st).mean() / 1e3), "max": float((en - st).max() / 1e3)}}
+if sliced:  # (per-XCC placement and restart gaps describe one block per trajectory: not defined here)
+    if os.environ.get("TIMELINE_OUT"):
+        np.save(os.environ["TIMELINE_OUT"], tl)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 per = []
 for x in sorted(set(tl[:, 3].tolist())):
     m = tl[:, 3] == x

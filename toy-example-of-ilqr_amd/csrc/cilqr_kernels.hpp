@@ -577,7 +577,10 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
         }
         wave_sync();
         park_copy(pk, l.x, l.u, l.ridx, sc_, N, lane, 1);
-        if (a.timeline && lane == 0 && !resumed) a.timeline[4 * (size_t)b] = tl_start;
+        if (a.timeline && lane == 0) { // resumable solves: first start, and in [2] minus the busy time so far
+            if (!resumed) a.timeline[4 * (size_t)b] = tl_start;
+            a.timeline[4 * (size_t)b + 2] -= (long long)__builtin_amdgcn_s_memrealtime() - tl_start;
+        }
         rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
         return true;
     }
@@ -612,7 +615,8 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
         long long* tl_rec = a.timeline + 4 * (size_t)b;
         if (!(RES && resumed)) tl_rec[0] = tl_start;  // (a resumed solve keeps the start of its first slice)
         tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        tl_rec[2] = blockIdx.x;
+        if (RES && res_on) tl_rec[2] -= tl_rec[1] - tl_start; // (a sliced solve has no one block: minus its busy time instead)
+        else tl_rec[2] = blockIdx.x;
         tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
     }
     if ((SHARE && share) || (RES && res_on)) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
