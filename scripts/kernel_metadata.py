@@ -190,6 +190,8 @@ def describe(variant):
         tags.append("global-expansion")
     if kv.get("SHARE") == "true":
         tags.append("share")
+    if kv.get("RES") == "true":
+        tags.append("resumable")
     return " ".join(tags)
 
 
@@ -234,16 +236,17 @@ def main():
                     rec["innermost_loops"] = loop_report(ins)
             out["kernels"].append(rec)
     if a.markdown:
-        print("| kernel variant | VGPR | VGPR spills | SGPR spills | scratch B | backward step: instr / scratch / lane moves | rollout step: instr / scratch / lane moves |")
-        print("|---|---|---|---|---|---|---|")
+        print("| build of `k_solve` | VGPR | VGPR spills | SGPR spills | scratch B | instructions | backward step: instr / scratch / lane moves | rollout loops: count, scratch / lane moves inside |")
+        print("|---|---|---|---|---|---|---|---|")
         for r in out["kernels"]:
             if "variant" not in r:
                 continue
-            def cell(kind):
-                ls = [l for l in r.get("innermost_loops", []) if l["kind"] == kind]
-                return "; ".join(f'{l["instructions"]} / {l["scratch"]} / {l["readlane_writelane"]}' for l in ls) or "-"
-            print(f'| `{r["kernel"].split("k_solve")[1]}` {r["variant"]} | {r["vgpr"]} | {r["vgpr_spills"]} | {r["sgpr_spills"]} | '
-                  f'{r["scratch_bytes"]} | {cell("backward_step")} | {cell("rollout_step")} |')
+            bw = [l for l in r.get("innermost_loops", []) if l["kind"] == "backward_step"]
+            ro = [l for l in r.get("innermost_loops", []) if l["kind"] == "rollout_step"]
+            bcell = "; ".join(f'{l["instructions"]} / {l["scratch"]} / {l["readlane_writelane"]}' for l in bw[-1:]) or "-"
+            rcell = f'{len(ro)}, {sum(l["scratch"] for l in ro)} / {sum(l["readlane_writelane"] for l in ro)}' if ro else "-"
+            print(f'| {r["variant"]} | {r["vgpr"]} | {r["vgpr_spills"]} | {r["sgpr_spills"]} | {r["scratch_bytes"]} | '
+                  f'{r.get("instructions", "")} | {bcell} | {rcell} |')
         return
     txt = json.dumps(out, indent=1)
     if a.out:
