@@ -355,11 +355,32 @@ def closed_loop_run(pkg, torch, local_rank, rank, barrier, B=8192, ticks=40, N=5
     t0 = time.perf_counter()
     loop(False)
     barrier()
+    el_ticks = time.perf_counter() - t0
+    # the same loop in ONE launch (cilqr_closed_loop_batch_device): every ego's ticks back to back on the block that picked
+    # it up, no synchronisation between egos — the tick-by-tick loop ends every tick with its slowest solves on a mostly
+    # idle chip, this one ends once
+    d_states = torch.zeros((B, ticks, 4), dtype=torch.float64, device=dev)
+    d_fits = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+
+    def fused():
+        d_x0 = torch.from_numpy(x0).to(dev)
+        d_tick = torch.zeros(B, dtype=torch.int32, device=dev)
+        eng.closed_loop_batch_device(B, ticks, d_x0.data_ptr(), 0, 0, d_tick.data_ptr(), 0, d_u.data_ptr(), d_x.data_ptr(),
+                                     d_res.data_ptr(), d_states.data_ptr(), d_fits.data_ptr(), st.cuda_stream)
+
+    fused()
+    barrier()
+    t0 = time.perf_counter()
+    fused()
+    barrier()
     el = time.perf_counter() - t0
+    fused_same = bool((d_fits.cpu().numpy() == d_its.cpu().numpy()).all()) and bool(
+        np.array_equal(d_states[:check_egos].cpu().numpy()[:, :, :], np.stack([h[:, 1] for h in d_hist.cpu().numpy()], 1)))
     its = d_its.cpu().numpy()
     hist = d_hist.cpu().numpy()
     eng.close()
-    return {"elapsed": el, "iters_per_tick": its.sum(axis=1), "iters_total": float(its.sum()), "ticks": ticks, "B": B, "N": N,
+    return {"elapsed": el, "elapsed_tick_by_tick": el_ticks, "fused_equals_tick_by_tick": fused_same,
+            "iters_per_tick": its.sum(axis=1), "iters_total": float(its.sum()), "ticks": ticks, "B": B, "N": N,
             "params": p, "scenario": sc, "x0": x0, "hist": hist, "M": int(sc.obstacles.shape[0])}
 
 
@@ -569,6 +590,7 @@ def main():
         cl = closed_loop_run(pkg, torch, local_rank, rank, barrier)
         vec = np.array([cl["iters_total"], cl["B"] * cl["ticks"]], dtype=np.float64)
         red, tmax_c = st_mod.reduce_stats(vec, cl["elapsed"], dist, red_dev)
+        _, tmax_t = st_mod.reduce_stats(vec, cl["elapsed_tick_by_tick"], dist, red_dev)
         if rank != 0:
             return None
         ipt = cl["iters_per_tick"]
@@ -576,11 +598,15 @@ def main():
                  "ticks": cl["ticks"], "horizon": cl["N"], "obstacles": cl["M"],
                  "value": red[0] / tmax_c, "unit": "iLQR iterations/s", "ego_ticks_per_s": red[1] / tmax_c,
                  "ms_per_tick": tmax_c / cl["ticks"] * 1e3, "timed_region_s": tmax_c,
+                 "tick_by_tick": {"value": red[0] / tmax_t, "ego_ticks_per_s": red[1] / tmax_t, "ms_per_tick": tmax_t / cl["ticks"] * 1e3,
+                                  "what": "one cilqr_solve_batch_device + one cilqr_advance_batch_device per tick"},
+                 "one_launch_equals_tick_by_tick (iterations of every ego-tick, sampled states)": cl["fused_equals_tick_by_tick"],
                  "iterations_per_ego_tick_mean": float(cl["iters_total"] / (cl["B"] * cl["ticks"])),
                  "iterations_per_ego_first_tick_cold": float(ipt[0] / cl["B"]),
                  "iterations_per_ego_later_ticks_warm": float(ipt[1:].sum() / (cl["B"] * max(1, cl["ticks"] - 1))),
-                 "note": "cilqr_solve_batch_device warm-started from its own u buffer + cilqr_advance_batch_device per tick, "
-                         "no host round trip inside the timed region (mp:180-197, cs:163-180)"}
+                 "note": "value = cilqr_closed_loop_batch_device: the whole loop in one launch, every ego's ticks back to back "
+                         "(solve, ego <- x.row(1), tick + 1, warm start from the plan just made: mp:180-197, cs:163-180), no "
+                         "host round trip and no synchronisation between egos"}
         if not args.no_cpu_baseline:
             out_c["cpu_check"] = closed_loop_check(cl)
         return out_c

@@ -175,6 +175,20 @@ int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
 int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const double* d_x, double* d_x0, int32_t* d_tick,
                                void* stream);
 
+/* The whole closed planning loop of src/motion_planning.cpp:180-197 for B egos in ONE launch: every ego runs `ticks`
+ * ticks back to back on the block that picked it up — CILQRSolver::solve, ego_state = new_x.row(1), obstacle window one
+ * tick on, the next solve warm-started from the plan just made (cilqr_solver.cpp:163-180; the first tick from d_last_u,
+ * NULL = cold) — with no synchronisation between egos: a tick-by-tick loop of cilqr_solve_batch_device +
+ * cilqr_advance_batch_device ends every tick with the batch's slowest solves on a mostly idle chip, the fused loop ends
+ * once.  Same numbers as that loop, ego by ego.  d_x0[B][4] and d_tick[B] (required) are read AND advanced; d_u_out /
+ * d_x_out / d_res_out hold the LAST tick's plan; optional d_states[B][ticks][4] = the ego state after every tick,
+ * d_iters[ticks][B] = iterations of every tick's solve.  An ego whose obstacle routes run out (tick + N + 1 > T) stops there
+ * with CILQR_END_BAD_INPUT.  Resumable solves do not apply here (an ego's ticks are its slices). */
+int cilqr_closed_loop_batch_device(cilqr_handle* h, int32_t B, int32_t ticks, double* d_x0, const int32_t* d_scenario_id,
+                                   const int32_t* d_param_id, int32_t* d_tick, const double* d_last_u, double* d_u_out,
+                                   double* d_x_out, cilqr_result* d_res_out, double* d_states, int32_t* d_iters,
+                                   void* stream);
+
 /* Wall time of the most recent solve kernel measured with HIP events on its own stream (ms). */
 int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
 /* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Runs ON THE GPU BOX: hammer the work sharing between blocks.  Random horizons / batch sizes / scenario mixes,
-every launch repeated with sharing on and off (same handle) and compared bit for bit, counters checked.
+"""Runs ON THE GPU BOX: hammer the work sharing between blocks and (round 3) the resumable solves.  Random horizons /
+batch sizes / scenario mixes, every launch repeated with sharing on and off and with random slice lengths of the
+resumable solves (same handle) and compared bit for bit with the first, unsliced and unshared one; counters checked.
 usage: scripts/stress_work_sharing.py [seconds]"""
 import importlib
 import os
@@ -18,11 +19,11 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(20260928)
     t_end = time.time() + budget
-    launches = announced = helped = 0
+    launches = announced = helped = parked = sliced_launches = 0
     while time.time() < t_end:
         N = int(rng.choice([64, 70, 76, 88, 100, 112, 127]))
         mixed = bool(rng.integers(0, 2))
-        B = int(rng.choice([520, 700, 1100, 1600, 2300, 4100]))
+        B = int(rng.choice([520, 700, 1100, 1600, 2300, 4100, 6200]))
         if mixed:
             wl = pkg.workloads.config4(B=B, N=min(N, 100), first=int(rng.integers(0, 50000)))
         else:
@@ -37,15 +38,23 @@ def main():
         if alm:
             eng.set_helper_mode(0)  # lone wavefronts whatever the batch: the builds that share work
         ref = None
+        eng.set_resume_iters(0)
+        eng.set_work_sharing(0)
         for rep in range(3):
-            for mode in (1, 0, 1):
-                eng.set_work_sharing(mode)
+            for mode in (0, 1, 0, 1) if rep == 0 else (1, 0, 1):
+                if ref is not None:
+                    eng.set_work_sharing(mode)
+                    eng.set_resume_iters(int(rng.choice([0, 1, 3, 7, 16, 32, 90])))
                 out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
-                if mode == 1:
+                if mode == 1 and ref is not None:
                     st = eng.work_sharing_stats()
                     assert st["error"] == 0, (wl.name, st)
                     announced += st["announced"]
                     helped += st["helped"]
+                if ref is not None:
+                    n = eng.resume_stats()
+                    parked += n
+                    sliced_launches += int(n > 0)
                 if ref is None:
                     ref = out
                 else:
@@ -54,7 +63,8 @@ def main():
                     assert (ref["res"] == out["res"]).all(), (wl.name, mode, rep)
                 launches += 1
         eng.close()
-    print({"launches": launches, "searches_announced": announced, "trial_costs_delivered": helped, "mismatches": 0})
+    print({"launches": launches, "searches_announced": announced, "trial_costs_delivered": helped,
+           "launches_with_parked_solves": sliced_launches, "solves_parked": parked, "mismatches": 0})
 
 
 if __name__ == "__main__":

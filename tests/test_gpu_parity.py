@@ -1419,3 +1419,94 @@ def test_resumable_solves_are_transparent(pkg, orc_det):
     assert eng.resume_stats() == 0
     eq_bits(small["x"], whole["x"][:1800], "small batch")
     eng.close()
+
+
+_FUSED_LOOP_SCRIPT = r"""
+import sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+dev = torch.device("cuda", 0)
+cfg = pkg.GlobalConfig.get_instance("three_straight")
+sc = pkg.build_scenario(cfg, "three_straight")
+for N, B, ticks, alm in ((30, 300, 12, 0), (30, 3000, 12, 0), (50, 2600, 9, 0), (30, 200, 6, 1), (30, 2500, 5, 1), (70, 2200, 4, 0), (30, 64, 1, 0)):
+    p = pkg.params_from_config(cfg, N=N, use_last_solution=1, solve_type=alm)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 515151 + N)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    def buffers():
+        return (torch.from_numpy(x0).to(dev), torch.zeros(B, dtype=torch.int32, device=dev),
+                torch.zeros((B, N, 2), dtype=torch.float64, device=dev), torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev),
+                torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
+    # tick by tick: one launch + one advance per tick
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+    d_x0, d_tick, d_u, d_x, d_res = buffers()
+    states, iters = [], []
+    for t in range(ticks):
+        eng.solve_batch_device(B, d_x0.data_ptr(), 0, 0, d_tick.data_ptr(), d_u.data_ptr() if t else 0, d_u.data_ptr(), d_x.data_ptr(),
+                               d_res.data_ptr(), 0, 0, st)
+        eng.advance_batch_device(B, d_x.data_ptr(), d_x0.data_ptr(), d_tick.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        states.append(d_x0.cpu().numpy().copy())
+        iters.append(np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)["iters"].copy())
+    ref = (d_x0.cpu().numpy(), d_tick.cpu().numpy(), d_u.cpu().numpy(), d_x.cpu().numpy(), d_res.cpu().numpy())
+    eng.close()
+    # the same loop in one launch (a fresh handle: the ALM multipliers start from zero again)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+    f_x0, f_tick, f_u, f_x, f_res = buffers()
+    f_states = torch.zeros((B, ticks, 4), dtype=torch.float64, device=dev)
+    f_iters = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+    eng.closed_loop_batch_device(B, ticks, f_x0.data_ptr(), 0, 0, f_tick.data_ptr(), 0, f_u.data_ptr(), f_x.data_ptr(), f_res.data_ptr(),
+                                 f_states.data_ptr(), f_iters.data_ptr(), st)
+    torch.cuda.synchronize(dev)
+    got = (f_x0.cpu().numpy(), f_tick.cpu().numpy(), f_u.cpu().numpy(), f_x.cpu().numpy(), f_res.cpu().numpy())
+    for a_, b_, nm in zip(ref, got, ("x0", "tick", "u", "x", "res")):
+        assert np.array_equal(a_.view(np.uint8), b_.view(np.uint8)), (N, B, nm)
+    assert np.array_equal(np.stack(states, 1).view(np.uint64), f_states.cpu().numpy().view(np.uint64)), (N, B, "states")
+    assert np.array_equal(np.stack(iters, 0), f_iters.cpu().numpy()), (N, B, "iters")
+    assert got[1].tolist() == [ticks] * B
+    eng.close()
+    # ... and both equal a stateful oracle solver, ego by ego (a few egos)
+    orc = Oracle("det")
+    fs = f_states.cpu().numpy()
+    for b in range(4):
+        s_ = orc.solver(p); s_.reset()
+        xs = x0[b].copy()
+        for t in range(ticks):
+            r = s_.solve(xs, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t))
+            xs = r["x"][1].copy()
+            assert np.array_equal(xs, fs[b, t]), (N, B, b, t)
+# an ego whose routes run out stops there: T = 200 samples, N = 30: ticks 0 .. 169 are solvable
+p = pkg.params_from_config(cfg, N=30, use_last_solution=1)
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+B = 8
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 7)
+d_x0 = torch.from_numpy(x0).to(dev)
+d_tick = torch.tensor([0, 160, 165, 168, 169, 170, 100, 0], dtype=torch.int32, device=dev)
+d_u = torch.zeros((B, 30, 2), dtype=torch.float64, device=dev); d_x = torch.zeros((B, 31, 4), dtype=torch.float64, device=dev)
+d_res = torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+eng.closed_loop_batch_device(B, 5, d_x0.data_ptr(), 0, 0, d_tick.data_ptr(), 0, d_u.data_ptr(), d_x.data_ptr(), d_res.data_ptr(), 0, 0,
+                             torch.cuda.current_stream(dev).cuda_stream)
+torch.cuda.synchronize(dev)
+res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)
+assert d_tick.cpu().numpy().tolist() == [5, 165, 170, 170, 170, 170, 105, 5], d_tick.cpu().numpy().tolist()
+# (ego 2 starts at tick 165 and solves 165 .. 169: five good ticks; egos 3, 4 run into tick 170, ego 5 starts there)
+assert (res["end_reason"][[3, 4, 5]] == 3).all() and (res["end_reason"][[0, 1, 2, 6, 7]] != 3).all()
+print("FUSED-LOOP-OK")
+"""
+
+
+def test_closed_loop_in_one_launch_equals_the_tick_by_tick_loop():
+    """cilqr_closed_loop_batch_device: every ego's ticks back to back on one block (solve, ego <- x.row(1), tick + 1, warm
+    start from the plan just made: mp:180-197, cs:163-180) give, ego by ego, the numbers of the tick-by-tick loop of
+    cilqr_solve_batch_device + cilqr_advance_batch_device — final states, ticks, last plans, results, the state after every
+    tick and every tick's iteration count — for one block per ego (small batches, helper wavefronts), for persistent
+    blocks, for the augmented Lagrangian; and of stateful oracle solvers.  An ego whose obstacle routes run out stops."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FUSED_LOOP_SCRIPT, root], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FUSED-LOOP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -102,6 +102,7 @@ SIGNATURES = {
     "cilqr_solve_cache_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cilqr_solve_batch_device": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "cilqr_advance_batch_device": (C.c_int, [_P, _I, _P, _P, _P, _P]),
+    "cilqr_closed_loop_batch_device": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cilqr_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "cilqr_set_timing": (C.c_int, [_P, _I]),
     "cilqr_set_phase_profiling": (C.c_int, [_P, _I]),

@@ -17,8 +17,8 @@
 #include "cilqr_kernels.hpp"
 
 // every build of k_solve is instantiated in cilqr_solve_inst.hip (one compilation per group, run in parallel)
-#define CILQR_X_EXTERN(g, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES) \
-    extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES> CILQR_SOLVE_SIGNATURE;
+#define CILQR_X_EXTERN(g, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP) \
+    extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP> CILQR_SOLVE_SIGNATURE;
 CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
 #undef CILQR_X_EXTERN
 
@@ -346,6 +346,7 @@ struct cilqr_handle {
     DevBuf park, rq;
     int park_B = 0, park_N = 0;
     unsigned last_parked = 0;
+    bool looping = false;      // the call in progress is a closed loop in one launch: the plain builds (see the dispatch)
     DevBuf sh_ctl, sh_req, sh_hints;
     int sh_B = 0, sh_N = 0;
     int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
@@ -889,6 +890,7 @@ static bool wants_helper(const cilqr_handle* h, int B) {
 // lone wavefronts, two per SIMD (the builds with WPS = 2, NTP = 1)?
 static bool lone_two_per_simd(const cilqr_handle* h, int B) {
     if (wants_helper(h, B)) return false;
+    if (h->looping) return true; // (closed loop: helper wavefronts or lone wavefronts two per SIMD, nothing else)
     const bool alm = h->params[0].solve_type == 1;
     if (two_rows(h) && !alm && h->share) return true; // (the work-sharing builds, whatever the batch)
     return B > h->occ2_min_batch;
@@ -898,13 +900,13 @@ static bool lone_two_per_simd(const cilqr_handle* h, int B) {
 // Mirrors the dispatch in cilqr_solve_batch_device, which checks the two against each other.
 static bool single_slot(const cilqr_handle* h, int B) {
     const bool alm = h->params[0].solve_type == 1;
-    if (!alm && (h->debug_flags != 0 || h->profiling)) return false;
+    if (!alm && !h->looping && (h->debug_flags != 0 || h->profiling)) return false;
     return lone_two_per_simd(h, B);
 }
 
 // does this batch run a build that keeps the cost expansion in global memory (k_solve's LG)?
 static bool global_expansion(const cilqr_handle* h, int B) {
-    if (!single_slot(h, B) || h->global_expansion == 0) return false;
+    if (!single_slot(h, B) || h->global_expansion == 0 || h->looping) return false;
     const int N = h->params[0].N;
     const int alm = h->params[0].solve_type == 1 ? 1 : 0;
     if (N + 1 <= CILQR_WAVE) return false; // (builds exist for two rows per lane only; shorter horizons fit anyway)
@@ -950,6 +952,11 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.ctl = static_cast<unsigned*>(h->sh_ctl.p);
     a.rq_cap = 0;
     a.res_iters = 0;
+    a.loop_ticks = 0;
+    a.loop_x0 = nullptr;
+    a.loop_tick = nullptr;
+    a.loop_states = nullptr;
+    a.loop_iters = nullptr;
     return a;
 }
 
@@ -1039,21 +1046,41 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
 #define DL(slot, ptr, bytes) \
     HIP_TRY(hipMemcpyAsync((ptr), h->st[slot].p, (bytes), hipMemcpyDeviceToHost, h->stream))
 
-extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
-                                        const int32_t* d_scenario_id, const int32_t* d_param_id,
-                                        const int32_t* d_tick, const double* d_last_u,
-                                        double* d_u_out, double* d_x_out, cilqr_result* d_res_out,
-                                        cilqr_trace_rec* d_trace_out, int32_t trace_cap, void* stream) {
+struct LoopArgs {
+    int ticks = 0;
+    double* x0 = nullptr;
+    int32_t* tick = nullptr;
+    double* states = nullptr;
+    int32_t* iters = nullptr;
+};
+
+static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x0,
+                                   const int32_t* d_scenario_id, const int32_t* d_param_id,
+                                   const int32_t* d_tick, const double* d_last_u,
+                                   double* d_u_out, double* d_x_out, cilqr_result* d_res_out,
+                                   cilqr_trace_rec* d_trace_out, int32_t trace_cap, void* stream, const LoopArgs& loop) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (B < 1 || !d_x0 || !d_u_out || !d_x_out) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
     if (trace_cap < 0) return fail(CILQR_ERR_BAD_ARG, "trace_cap < 0");
     HIP_TRY(hipSetDevice(h->device));
+    struct LoopScope { // (the launch-shape helpers below look at the handle)
+        cilqr_handle* h;
+        LoopScope(cilqr_handle* hh, bool on) : h(hh) { h->looping = on; }
+        ~LoopScope() { h->looping = false; }
+    } loop_scope(h, loop.ticks >= 1);
+    if (loop.ticks >= 1 && (h->debug_flags != 0 || h->profiling))
+        return fail(CILQR_ERR_UNSUPPORTED, "the closed loop has no testing-aid / cycle-accounting builds");
     rc = ensure_scratch(h, B, true);
     if (rc) return rc;
     Staged ids;
     ids.sid = d_scenario_id; ids.pid = d_param_id; ids.tick = d_tick;
     BatchArgs a = make_args(h, B, ids);
+    a.loop_ticks = loop.ticks;
+    a.loop_x0 = loop.x0;
+    a.loop_tick = loop.tick;
+    a.loop_states = loop.states;
+    a.loop_iters = loop.iters;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h->profiling) {
         if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
@@ -1076,7 +1103,22 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         auto kern = k_solve<false, 1, false, false, false>;
         bool one = false, lg = false, persistent = false;
         h->last_launch_shared = false;
-        if (a.alm) {
+        if (loop.ticks >= 1) {
+            // closed loop in one launch: the plain builds carry it
+            if (a.alm) {
+                if (help) kern = two ? k_solve<CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, true>
+                                     : k_solve<CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, true>;
+                else kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, true>
+                                : k_solve<CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, true>;
+            } else {
+                if (help) kern = two ? k_solve<false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, true>
+                                     : k_solve<false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true>;
+                else kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, false, false, true>
+                                : k_solve<false, 1, false, false, false, 2, 1, 0, false, false, false, true>;
+            }
+            one = !help;
+            persistent = !help;
+        } else if (a.alm) {
             if (help) kern = two ? k_solve<CILQR_ALM_DBG, 2, true, true, false> : k_solve<CILQR_ALM_DBG, 1, true, true, false>;
             else if (lone_two_per_simd(h, B)) {
                 kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1> : k_solve<CILQR_ALM_DBG, 1, true, false, false, 2, 1>;
@@ -1125,7 +1167,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
         } else {
             kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
         }
-        const bool helped = help && (a.alm || a.flags == 0);
+        const bool helped = help && (a.alm || a.flags == 0 || loop.ticks >= 1);
         if (one != single_slot(h, B)) return fail(CILQR_ERR_DEVICE, "internal: kernel variant / LDS layout mismatch");
         const size_t shm = lds_bytes(a.N, a.W, a.alm, one ? 1 : 2, lg ? 1 : 0);
         int grid = B;
@@ -1140,7 +1182,7 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
             HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
             // resumable solves: the builds that carry them (two rows per lane, persistent), batches that take more than
             // one round of the resident blocks
-            if (two && !a.alm && h->resume_iters > 0 && B > grid && h->park.p && h->park_B >= B && h->park_N == a.N) {
+            if (two && !a.alm && loop.ticks < 1 && h->resume_iters > 0 && B > grid && h->park.p && h->park_B >= B && h->park_N == a.N) {
                 a.park = static_cast<double*>(h->park.p);
                 a.rq = static_cast<unsigned long long*>(h->rq.p);
                 HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
@@ -1167,6 +1209,31 @@ extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double
     h->last_stream = s;
     h->launched = true;
     return CILQR_OK;
+}
+
+extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
+                                        const int32_t* d_scenario_id, const int32_t* d_param_id,
+                                        const int32_t* d_tick, const double* d_last_u,
+                                        double* d_u_out, double* d_x_out, cilqr_result* d_res_out,
+                                        cilqr_trace_rec* d_trace_out, int32_t trace_cap, void* stream) {
+    return solve_batch_device_impl(h, B, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u_out, d_x_out, d_res_out,
+                                   d_trace_out, trace_cap, stream, LoopArgs());
+}
+
+extern "C" int cilqr_closed_loop_batch_device(cilqr_handle* h, int32_t B, int32_t ticks, double* d_x0,
+                                              const int32_t* d_scenario_id, const int32_t* d_param_id, int32_t* d_tick,
+                                              const double* d_last_u, double* d_u_out, double* d_x_out,
+                                              cilqr_result* d_res_out, double* d_states, int32_t* d_iters, void* stream) {
+    if (ticks < 1) return fail(CILQR_ERR_BAD_ARG, "ticks < 1");
+    if (!d_tick) return fail(CILQR_ERR_BAD_ARG, "the closed loop needs the tick array (it is advanced on the device)");
+    LoopArgs loop;
+    loop.ticks = ticks;
+    loop.x0 = d_x0;
+    loop.tick = d_tick;
+    loop.states = d_states;
+    loop.iters = d_iters;
+    return solve_batch_device_impl(h, B, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u_out, d_x_out, d_res_out,
+                                   nullptr, 0, stream, loop);
 }
 
 extern "C" int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const double* d_x, double* d_x0, int32_t* d_tick,

@@ -53,6 +53,13 @@ struct BatchArgs {
     unsigned* ctl;              // the launch's control words
     int rq_cap;
     int res_iters;              // iterations per slice
+    // closed planning loop on the device (cilqr_closed_loop_batch_device): every ego runs `loop_ticks` ticks back to back —
+    // solve, ego <- x.row(1), obstacle window one tick on, warm start from the plan just made (mp:180-197, cs:163-180)
+    int loop_ticks;             // 0 / 1 = one solve per trajectory
+    double* loop_x0;            // [B][4] in / out: the ego states (the solve reads them through its x0 argument)
+    int32_t* loop_tick;         // [B] in / out
+    double* loop_states;        // optional [B][loop_ticks][4]: the ego state after every tick
+    int32_t* loop_iters;        // optional [loop_ticks][B]: iterations of every tick's solve
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -76,20 +83,24 @@ enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST
         }                                                             \
     } while (0)
 
+template <bool LOOP = false>
 __device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l, int lane) {
     int pid = a.param_id ? a.param_id[b] : 0;
     int sid = a.scenario_id ? a.scenario_id[b] : 0;
     int tk = a.tick ? a.tick[b] : 0;
+    if (LOOP) tk = uniform_int((int)sh_ld(reinterpret_cast<const unsigned*>(a.loop_tick + b))); // (advanced inside this launch)
     make_cst(c, a.params[pid], a.scenes[sid], tk, l.ck, lane);
 }
 
 // The device-pointer entry point cannot check its index arrays on the host.  A trajectory whose ids point
 // outside the tables, or whose obstacle routes end before tick + N + 1 (upstream: RoutingLine::operator[]
 // throws std::out_of_range, ut:52-58), is not solved: NaN outputs, end_reason CILQR_END_BAD_INPUT.
+template <bool LOOP = false>
 __device__ inline bool ids_valid(const BatchArgs& a, int b) {
     const int pid = a.param_id ? a.param_id[b] : 0;
     const int sid = a.scenario_id ? a.scenario_id[b] : 0;
-    const int tk = a.tick ? a.tick[b] : 0;
+    int tk = a.tick ? a.tick[b] : 0;
+    if (LOOP) tk = uniform_int((int)sh_ld(reinterpret_cast<const unsigned*>(a.loop_tick + b)));
     if ((unsigned)pid >= (unsigned)a.n_params || (unsigned)sid >= (unsigned)a.n_scenes || tk < 0) return false;
     const DevScene& s = a.scenes[sid];
     return !(s.M > 0 && (long long)tk + a.N + 1 > (long long)s.T);
@@ -232,10 +243,14 @@ __device__ __attribute__((noinline)) void park_copy(double* pk, double* lx, doub
     wave_sync();
 }
 
+// what solve_one returns besides a finished solve's iteration count
+enum { SOLVE_PARKED = -1 /* parked again: its number has been queued */, SOLVE_BAD_INPUT = -2 };
+
 // RES = resumable: the solve runs a.res_iters iterations at a time and is parked in between (see rq_push); `resumed` = this
-// call continues a parked solve.  Returns true when the solve was parked again (its number has been queued).
-template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE, bool RES>
-__device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const int slot, const bool resumed,
+// call continues a parked solve.
+// LOOP = the launch runs a closed planning loop (cilqr_closed_loop_batch_device): x0 and tick are advanced inside it
+template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE, bool RES, bool LOOP>
+__device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const int slot, const bool resumed,
                                           const double* __restrict__ x0,
                                           const double* __restrict__ last_u, double* __restrict__ u_out,
                                           double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -246,10 +261,11 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
     static_assert(!SHARE || (!HELP && !PROF && NTP == 1), "work sharing: lone wavefronts costing one trial per pass");
     static_assert(!RES || (!HELP && !PROF && !ALM), "resumable solves: lone wavefronts, barrier mode (the multipliers of the "
                                                       "augmented Lagrangian are large arrays written with plain stores)");
+    static_assert(!LOOP || (!RES && !SHARE && !PROF), "closed loop: plain builds");
     const bool res_on = RES && a.park != nullptr;
     const bool share = SHARE && a.sh_ctl != nullptr;
     const int N = NC ? NC : a.N; // one horizon per handle
-    if (!ids_valid(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
+    if (!ids_valid<LOOP>(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
         if (share || res_on) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
         if (wave == 0) {
             const double qnan = dm_from_bits(0x7ff8000000000000ULL);
@@ -262,13 +278,13 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
                 res_out[b] = r;
             }
         }
-        return false;
+        return SOLVE_BAD_INPUT;
     }
     Lds l;
     constexpr int SLOTS = (HELP || NTP == 2) ? 2 : 1; // trials costed concurrently (the host sizes the LDS block alike)
     carve(l, g_lds, N, a.W, ALM ? 1 : 0, SLOTS, LG ? 1 : 0);
     Cst c;
-    load_cst(c, a, b, l, lane);
+    load_cst<LOOP>(c, a, b, l, lane);
     if (NC) c.N = NC;
     double* scr = a.scratch + (size_t)slot * scratch_doubles(N);
     if (LG) l.gl = scr + scratch_gl_offset(N);
@@ -315,7 +331,7 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
             __syncthreads(); // B4
             if (l.ctli[CTL_EXIT]) break;
         }
-        return false;
+        return 0;
     }
     // the main wavefront carries the serial chain of the solve: it wins issue arbitration against the helper
     // wavefront (of another block) it shares its SIMD with
@@ -354,7 +370,14 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
         r_tl = (int)sc_[7]; r_flag = (int)sc_[8]; r_deep = (int)sc_[9]; r_seq = (int)sc_[11];
         wave_sync();
     } else {
-        const double xs[4] = {x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3]};
+        double xs[4];
+        if (LOOP) { // closed loop on the device: the ego state is advanced inside this launch — not through the
+                                // read-only kernel argument, whose loads the compiler may hoist out of the tick loop
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[e] = park_ld(a.loop_x0 + 4 * (size_t)b + e);
+        } else {
+            xs[0] = x0[4 * b]; xs[1] = x0[4 * b + 1]; xs[2] = x0[4 * b + 2]; xs[3] = x0[4 * b + 3];
+        }
         init_trajectory(c, l, xs, last_u ? last_u + (size_t)b * N * 2 : nullptr, lane, idx0, a.W);
         seed_trial_indices(l, N, SLOTS, lane);
         J_cur = total_cost_lds<ALM>(c, l, al, lane);
@@ -582,7 +605,7 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
             a.timeline[4 * (size_t)b + 2] -= (long long)__builtin_amdgcn_s_memrealtime() - tl_start;
         }
         rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
-        return true;
+        return SOLVE_PARKED;
     }
     if (ALM) {
         J_cur = total_cost_lds<ALM>(c, l, al, lane); // J_final := get_total_cost(u_ret, x_ret) with the final multipliers
@@ -620,7 +643,7 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
         tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
     }
     if ((SHARE && share) || (RES && res_on)) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
-    return false;
+    return iters;
 }
 
 // The solve kernel.  Small batches: one block per trajectory (in the XCD-aware order above).  Large batches (a.next
@@ -632,7 +655,7 @@ __device__ __forceinline__ bool solve_one(const BatchArgs& a, const int b, const
 // and a launch touches one scratch area per resident block instead of one per trajectory.  A block that finds no
 // trajectory left turns to the line searches of the blocks still running (SHARE builds).
 template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
-          bool SHARE = false, bool RES = false>
+          bool SHARE = false, bool RES = false, bool LOOP = false>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
 k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
         double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
@@ -642,11 +665,15 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     if (!persistent && (int)blockIdx.x >= a.B) return;
     const bool res_on = RES && persistent && a.park != nullptr;
     bool fresh_left = true;
+    const int T = LOOP ? a.loop_ticks : 1; // closed loop on the device: ticks per ego
+    int t_done = 0;                                    // ... ticks of the current ego that are done
+    unsigned b_cur = 0;
     for (;;) { // (one call site: a second inlined copy of the solve costs the loop ~70 spilled vector registers; out of
                //  line, with the arguments on the stack, a solve takes 7 % longer)
         unsigned b = (unsigned)a.B;
         bool resumed = false;
-        if (!persistent) b = (unsigned)trajectory_of_block(blockIdx.x, a.B);
+        if (LOOP && t_done > 0) b = b_cur; // the next tick of the ego this block is driving
+        else if (!persistent) b = (unsigned)trajectory_of_block(blockIdx.x, a.B);
         else if (fresh_left) b = sh_add_u(a.next, 1u, lane);
         if (b >= (unsigned)a.B) {
             if (!res_on) break;
@@ -659,9 +686,39 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             b = (unsigned)pb;
             resumed = true;
         }
-        (void)solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES>(a, (int)b, persistent ? (int)blockIdx.x : (int)b,
-                                                                                 resumed, x0, last_u, u_out, x_out, res_out,
-                                                                                 trace_out, trace_cap);
+        const int it = solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP>(
+            a, (int)b, persistent ? (int)blockIdx.x : (int)b, resumed, x0, (LOOP && t_done > 0) ? u_out : last_u, u_out, x_out,
+            res_out, trace_out, trace_cap);
+        if (LOOP) {
+            // the step after the path (mp:181,197), for this ego: ego_state = new_x.row(1), the obstacle window one tick on;
+            // the next solve starts warm from the plan just stored (cs:163-180: d_last_u = d_u_out)
+            if (HELP) __syncthreads();
+            const int N = NC ? NC : a.N;
+            if ((!HELP || threadIdx.x < CILQR_WAVE) && it >= 0) {
+                Lds l;
+                carve(l, g_lds, N, a.W, ALM ? 1 : 0, (HELP || NTP == 2) ? 2 : 1, LG ? 1 : 0);
+                if (lane < 4) {
+                    const double v = l.x[4 + lane]; // row 1 of the plan, still in LDS
+                    a.loop_x0[4 * (size_t)b + lane] = v;
+                    if (a.loop_states) a.loop_states[((size_t)b * T + t_done) * 4 + lane] = v;
+                }
+                if (lane == 0) {
+                    a.loop_tick[b] += 1;
+                    if (a.loop_iters) a.loop_iters[(size_t)t_done * a.B + b] = it;
+                }
+            }
+            // This block's own stores are in L2 before it reads x0 / tick / u again, and not shadowed by its CU's L1: stores
+            // complete, THEN (helper mode: both wavefronts past this point, THEN) the L1 is invalidated.  In that order: a
+            // neighbouring ego's block on the same CU may re-fill the shared line of tick[] / x0[] at any time, and a fill
+            // that predates the store must not survive the invalidate.
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (HELP) __syncthreads();
+            sh_acquire();
+            __builtin_amdgcn_s_dcache_inv(); // (tick[b] is wave-uniform: the scalar cache may hold it)
+            t_done = (it >= 0 && t_done + 1 < T) ? t_done + 1 : 0; // (an ego whose routes have run out stops there)
+            b_cur = b;
+            if (t_done > 0) continue;
+        }
         if (!persistent) break;
     }
     if (SHARE && persistent && a.sh_ctl != nullptr) {
@@ -673,7 +730,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------------
-// The builds of k_solve the library carries: X(group, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES).
+// The builds of k_solve the library carries: X(group, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP).
 // `group` = which compilation of cilqr_solve_inst.hip instantiates it (toy-example-of-ilqr_amd/build.py runs the
 // groups in parallel).  The production library carries neither the testing-aid builds (DBG: cilqr_set_debug_flags)
 // nor the cycle-accounting builds (PROF: cilqr_set_phase_profiling); the development library, libcilqr_amd_dev.so
@@ -685,33 +742,42 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
 #define CILQR_ALM_DBG false
 #endif
 #define CILQR_SOLVE_VARIANTS_PROD(X)                                            \
-    X(0, false, 1, false, false, false, 1, CILQR_NT, 0, false, false, false)           \
-    X(0, false, 2, false, false, false, 1, CILQR_NT, 0, false, false, false)           \
-    X(1, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false)            \
-    X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false)            \
-    X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false, false)           \
-    X(2, false, 2, false, true, false, 1, CILQR_NT, 100, false, false, false)          \
-    X(3, false, 1, false, false, false, 2, 1, 0, false, false, false)                  \
-    X(3, false, 2, false, false, false, 2, 1, 0, false, true, true)                   \
-    X(4, false, 1, false, false, false, 2, 1, 50, false, false, false)                 \
-    X(4, false, 2, false, false, false, 2, 1, 100, false, true, true)                 \
-    X(5, false, 2, false, false, false, 2, 1, 0, true, true, true)                    \
-    X(5, false, 2, false, false, false, 2, 1, 100, true, true, true)                  \
-    X(6, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false)     \
-    X(6, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false)     \
-    X(7, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false)           \
-    X(7, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false)           \
-    X(0, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false)             \
-    X(1, CILQR_ALM_DBG, 1, true, false, false, 1, CILQR_NT, 0, false, false, false)    \
-    X(2, CILQR_ALM_DBG, 2, true, false, false, 1, CILQR_NT, 0, false, false, false)
+    X(0, false, 1, false, false, false, 1, CILQR_NT, 0, false, false, false, false)           \
+    X(0, false, 2, false, false, false, 1, CILQR_NT, 0, false, false, false, false)           \
+    X(1, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
+    X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
+    X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false, false, false)           \
+    X(2, false, 2, false, true, false, 1, CILQR_NT, 100, false, false, false, false)          \
+    X(3, false, 1, false, false, false, 2, 1, 0, false, false, false, false)                  \
+    X(3, false, 2, false, false, false, 2, 1, 0, false, true, true, false)                   \
+    X(4, false, 1, false, false, false, 2, 1, 50, false, false, false, false)                 \
+    X(4, false, 2, false, false, false, 2, 1, 100, false, true, true, false)                 \
+    X(5, false, 2, false, false, false, 2, 1, 0, true, true, true, false)                    \
+    X(5, false, 2, false, false, false, 2, 1, 100, true, true, true, false)                  \
+    X(6, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
+    X(6, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
+    X(7, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, false)           \
+    X(7, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, false)           \
+    X(0, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false, false)             \
+    X(1, CILQR_ALM_DBG, 1, true, false, false, 1, CILQR_NT, 0, false, false, false, false)    \
+    X(2, CILQR_ALM_DBG, 2, true, false, false, 1, CILQR_NT, 0, false, false, false, false)    \
+    /* closed planning loop in one launch: the plain builds (helper wavefront / lone, two per SIMD), both solve types */ \
+    X(3, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
+    X(4, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
+    X(5, false, 1, false, false, false, 2, 1, 0, false, false, false, true)                   \
+    X(6, false, 2, false, false, false, 2, 1, 0, false, false, false, true)                   \
+    X(7, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
+    X(0, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
+    X(1, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, true)            \
+    X(2, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, true)
 #ifdef CILQR_DEV_BUILD
 #define CILQR_SOLVE_VARIANTS_DEV(X)                                             \
-    X(3, true, 1, false, false, false, 1, CILQR_NT, 0, false, false, false)            \
-    X(4, true, 2, false, false, false, 1, CILQR_NT, 0, false, false, false)            \
-    X(5, false, 1, false, true, true, 1, CILQR_NT, 0, false, false, false)             \
-    X(6, false, 2, false, true, true, 1, CILQR_NT, 0, false, false, false)             \
-    X(7, false, 1, false, false, true, 1, CILQR_NT, 0, false, false, false)            \
-    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false, false)
+    X(3, true, 1, false, false, false, 1, CILQR_NT, 0, false, false, false, false)            \
+    X(4, true, 2, false, false, false, 1, CILQR_NT, 0, false, false, false, false)            \
+    X(5, false, 1, false, true, true, 1, CILQR_NT, 0, false, false, false, false)             \
+    X(6, false, 2, false, true, true, 1, CILQR_NT, 0, false, false, false, false)             \
+    X(7, false, 1, false, false, true, 1, CILQR_NT, 0, false, false, false, false)            \
+    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false, false, false)
 #else
 #define CILQR_SOLVE_VARIANTS_DEV(X)
 #endif

@@ -154,6 +154,15 @@ class BatchedCILQR:
         self._check(self._lib.cilqr_advance_batch_device(self._h, int(B), d_x, d_x0, d_tick or None, stream or None),
               "cilqr_advance_batch_device")
 
+    def closed_loop_batch_device(self, B, ticks, d_x0, d_scenario_id, d_param_id, d_tick, d_last_u, d_u, d_x, d_res,
+                                 d_states=0, d_iters=0, stream=0):
+        """`ticks` ticks of the planning loop for every ego in one launch (raw device pointers as ints): solve, ego <-
+        x.row(1), tick += 1, warm start from the plan just made; d_x0 / d_tick are advanced in place."""
+        self._check(self._lib.cilqr_closed_loop_batch_device(self._h, int(B), int(ticks), d_x0, d_scenario_id or None,
+                                                             d_param_id or None, d_tick, d_last_u or None, d_u, d_x,
+                                                             d_res or None, d_states or None, d_iters or None, stream or None),
+                    "cilqr_closed_loop_batch_device")
+
     def set_timing(self, on=True):
         self._check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
 
