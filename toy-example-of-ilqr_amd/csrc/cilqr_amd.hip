@@ -1115,6 +1115,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
                                      : k_solve<false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true>;
                 else kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, false, false, true>
                                 : k_solve<false, 1, false, false, false, 2, 1, 0, false, false, false, true>;
+                if (!help && a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50, false, false, false, true>;
             }
             one = !help;
             persistent = !help;

@@ -765,6 +765,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
     X(3, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
     X(4, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
     X(5, false, 1, false, false, false, 2, 1, 0, false, false, false, true)                   \
+    X(3, false, 1, false, false, false, 2, 1, 50, false, false, false, true)                  \
     X(6, false, 2, false, false, false, 2, 1, 0, false, false, false, true)                   \
     X(7, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
     X(0, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
