@@ -168,7 +168,7 @@ def variant_of(dem):
     return m.group(1) if m else None
 
 
-TPL = ("DBG", "NCH", "ALM", "HELP", "PROF", "WPS", "NTP", "NC", "LG", "SHARE", "RES")
+TPL = ("DBG", "NCH", "ALM", "HELP", "PROF", "WPS", "NTP", "NC", "LG", "SHARE", "RES", "LOOP")
 
 
 def describe(variant):
@@ -192,6 +192,8 @@ def describe(variant):
         tags.append("share")
     if kv.get("RES") == "true":
         tags.append("resumable")
+    if kv.get("LOOP") == "true":
+        tags.append("closed-loop")
     return " ".join(tags)
 
 
