@@ -177,10 +177,11 @@ int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const double* d_x, do
 
 /* The whole closed planning loop of src/motion_planning.cpp:180-197 for B egos in ONE launch: every ego runs `ticks`
  * ticks back to back on the block that picked it up — CILQRSolver::solve, ego_state = new_x.row(1), obstacle window one
- * tick on, the next solve warm-started from the plan just made (cilqr_solver.cpp:163-180; the first tick from d_last_u,
- * NULL = cold) — with no synchronisation between egos: a tick-by-tick loop of cilqr_solve_batch_device +
+ * tick on, the next solve warm-started from the plan just made where the ego's parameter set has use_last_solution
+ * (cilqr_solver.cpp:95-101, 163-180), cold otherwise as in the reference (under "alm" with fresh multipliers: cs:88-93);
+ * the first tick starts from d_last_u, NULL = cold — with no synchronisation between egos: a tick-by-tick loop of cilqr_solve_batch_device +
  * cilqr_advance_batch_device ends every tick with the batch's slowest solves on a mostly idle chip, the fused loop ends
- * once.  Same numbers as that loop, ego by ego.  d_x0[B][4] and d_tick[B] (required) are read AND advanced; d_u_out /
+ * once.  Same numbers as that loop (d_last_u = the previous d_u_out where use_last_solution, else NULL), ego by ego.  d_x0[B][4] and d_tick[B] (required) are read AND advanced; d_u_out /
  * d_x_out / d_res_out hold the LAST tick's plan; optional d_states[B][ticks][4] = the ego state after every tick,
  * d_iters[ticks][B] = iterations of every tick's solve.  An ego whose obstacle routes run out (tick + N + 1 > T) stops there
  * with CILQR_END_BAD_INPUT.  Resumable solves do not apply here (an ego's ticks are its slices). */

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Soak run of cilqr_closed_loop_batch_device ON THE GPU BOX: random shapes — horizon, batch (one block per ego with
+helper wavefronts up to persistent blocks), ticks, solve type, vehicle model, warm start on / off, egos of all four
+scenarios mixed in one launch, every ego starting at its own tick — compared bit for bit with the tick-by-tick loop
+(cilqr_solve_batch_device + cilqr_advance_batch_device) in every output, and, for a few egos per case, with stateful
+solvers of the CPU oracle's detmath build (TEST INFRASTRUCTURE: the oracle is the checker).
+
+    python scripts/soak_closed_loop.py [--cases 40] [--seed 1] [--out gpurun_out/soak/closed_loop.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import cilqr_amd as pkg  # noqa: E402
+from oracle import Oracle, Scene  # noqa: E402
+
+NAMES = ("two_straight", "three_bend", "two_borrow", "three_straight")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    scen = {}
+    for n in NAMES:
+        cfg = pkg.GlobalConfig.get_instance(n)
+        scen[n] = (cfg, pkg.build_scenario(cfg, n))
+    orc = Oracle("det")
+    rep = {"seed": a.seed, "cases": [], "ego_ticks": 0, "iterations": 0, "mismatches": 0, "oracle_ego_ticks_checked": 0}
+    t_start = time.time()
+    for case in range(a.cases):
+        N = int(rng.choice([12, 30, 30, 50, 50, 63, 64, 80, 100]))
+        alm = int(rng.random() < 0.25)
+        warm = int(rng.random() < 0.7)
+        rp = int(rng.integers(0, 2))
+        ticks = int(rng.integers(1, 9))
+        B = int(rng.choice([1, 7, 64, 300, 1100, 2300, 2600, 5000]))
+        if N >= 80:
+            B = min(B, 2300)
+        names = list(rng.choice(NAMES, size=int(rng.integers(1, 5)), replace=False))
+        params = [pkg.params_from_config(scen[n][0], N=N, use_last_solution=warm, solve_type=alm, reference_point=rp,
+                                         max_iter=int(rng.choice([20, 100]))) for n in names]
+        tabs = [pkg.SceneTable.from_scenario(scen[n][1]) for n in names]
+        sid = rng.integers(0, len(names), size=B).astype(np.int32)
+        x0 = np.zeros((B, 4))
+        tick0 = np.zeros(B, np.int32)
+        for s, n in enumerate(names):
+            m = sid == s
+            if m.any():
+                x0[m] = pkg.workloads.perturbed_starts(scen[n][1].ego_state, int(m.sum()), 9000 + case * 7 + s)
+                T = scen[n][1].routes.shape[1]
+                tick0[m] = rng.integers(0, max(1, T - N - ticks - 1), size=int(m.sum()))
+
+        def buffers():
+            return (torch.from_numpy(x0).to(dev), torch.from_numpy(tick0).to(dev), torch.from_numpy(sid).to(dev),
+                    torch.zeros((B, N, 2), dtype=torch.float64, device=dev), torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev),
+                    torch.zeros((B, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
+
+        eng = pkg.BatchedCILQR(params, tabs)
+        d_x0, d_tick, d_sid, d_u, d_x, d_res = buffers()
+        states, iters = [], []
+        for t in range(ticks):
+            eng.solve_batch_device(B, d_x0.data_ptr(), d_sid.data_ptr(), d_sid.data_ptr(), d_tick.data_ptr(),
+                                   d_u.data_ptr() if (t and warm) else 0, d_u.data_ptr(), d_x.data_ptr(), d_res.data_ptr(), 0, 0, st)
+            eng.advance_batch_device(B, d_x.data_ptr(), d_x0.data_ptr(), d_tick.data_ptr(), st)
+            torch.cuda.synchronize(dev)
+            states.append(d_x0.cpu().numpy().copy())
+            iters.append(np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=pkg.RESULT_DTYPE)["iters"].copy())
+        ref = (d_x0.cpu().numpy(), d_tick.cpu().numpy(), d_u.cpu().numpy(), d_x.cpu().numpy(), d_res.cpu().numpy())
+        eng.close()
+        eng = pkg.BatchedCILQR(params, tabs)
+        f_x0, f_tick, f_sid, f_u, f_x, f_res = buffers()
+        f_states = torch.zeros((B, ticks, 4), dtype=torch.float64, device=dev)
+        f_iters = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+        eng.closed_loop_batch_device(B, ticks, f_x0.data_ptr(), f_sid.data_ptr(), f_sid.data_ptr(), f_tick.data_ptr(), 0,
+                                     f_u.data_ptr(), f_x.data_ptr(), f_res.data_ptr(), f_states.data_ptr(), f_iters.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        eng.close()
+        got = (f_x0.cpu().numpy(), f_tick.cpu().numpy(), f_u.cpu().numpy(), f_x.cpu().numpy(), f_res.cpu().numpy())
+        bad = [nm for a_, b_, nm in zip(ref, got, ("x0", "tick", "u", "x", "res")) if not np.array_equal(a_.view(np.uint8), b_.view(np.uint8))]
+        fs = f_states.cpu().numpy()
+        if not np.array_equal(np.stack(states, 1).view(np.uint64), fs.view(np.uint64)):
+            bad.append("states")
+        if not np.array_equal(np.stack(iters, 0), f_iters.cpu().numpy()):
+            bad.append("iters")
+        # stateful oracle solvers, a few egos
+        n_orc = 0
+        for b in rng.choice(B, size=min(B, 3), replace=False):
+            n = names[sid[b]]
+            sc = scen[n][1]
+            s_ = orc.solver(params[sid[b]])
+            s_.reset()
+            xs = x0[b].copy()
+            for t in range(ticks):
+                r = s_.solve(xs, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, int(tick0[b]) + t))
+                xs = r["x"][1].copy()
+                if not np.array_equal(xs, fs[b, t]):
+                    bad.append(f"oracle ego {int(b)} tick {t}")
+                    break
+                n_orc += 1
+        it_sum = int(np.stack(iters, 0).sum())
+        rep["cases"].append({"N": N, "B": B, "ticks": ticks, "alm": alm, "warm_start": warm, "reference_point": rp,
+                             "scenarios": names, "iterations": it_sum, "mismatch": bad})
+        rep["ego_ticks"] += B * ticks
+        rep["iterations"] += it_sum
+        rep["mismatches"] += 1 if bad else 0
+        rep["oracle_ego_ticks_checked"] += n_orc
+        print(case, N, B, ticks, alm, warm, names, "MISMATCH " + str(bad) if bad else "ok", flush=True)
+    rep["seconds"] = time.time() - t_start
+    txt = json.dumps(rep, indent=1)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        open(a.out, "w").write(txt + "\n")
+    print("SOAK-CLOSED-LOOP", "OK" if rep["mismatches"] == 0 else "FAILED", rep["ego_ticks"], "ego-ticks", rep["iterations"], "iterations")
+    return 0 if rep["mismatches"] == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1510,3 +1510,21 @@ def test_closed_loop_in_one_launch_equals_the_tick_by_tick_loop():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _FUSED_LOOP_SCRIPT, root], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "FUSED-LOOP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_closed_loop_in_one_launch_follows_use_last_solution():
+    """Found by scripts/soak_closed_loop.py: later ticks of the fused loop start warm only for egos whose parameter set has
+    use_last_solution (cs:95-101); the others start cold every tick (fresh multipliers under "alm", cs:88-93), as the
+    tick-by-tick loop with d_last_u = NULL and the oracle's stateful solver do.  A short seeded run of the soak script:
+    random shapes, egos of several scenarios mixed in one launch, each from its own tick, warm start on and off."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_closed_loop.py"), "--cases", "24", "--seed", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SOAK-CLOSED-LOOP OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    cold = [l for l in r.stdout.splitlines() if l.endswith("ok") and l.split()[5] == "0"]
+    assert len(cold) >= 3, "the seeded run no longer holds cold-start cases"
+

@@ -686,12 +686,18 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
             b = (unsigned)pb;
             resumed = true;
         }
+        const double* lu = last_u;
+        if (LOOP && t_done > 0) {
+            // a later tick of the loop: warm from the plan just stored if the ego's configuration says so, cold (and, under
+            // the augmented Lagrangian, with fresh multipliers) otherwise — cs:88-101.  (The ids were valid a tick ago.)
+            const int pid = a.param_id ? a.param_id[b] : 0;
+            lu = a.params[pid].use_last_solution ? u_out : nullptr;
+        }
         const int it = solve_one<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP>(
-            a, (int)b, persistent ? (int)blockIdx.x : (int)b, resumed, x0, (LOOP && t_done > 0) ? u_out : last_u, u_out, x_out,
-            res_out, trace_out, trace_cap);
+            a, (int)b, persistent ? (int)blockIdx.x : (int)b, resumed, x0, lu, u_out, x_out, res_out, trace_out, trace_cap);
         if (LOOP) {
             // the step after the path (mp:181,197), for this ego: ego_state = new_x.row(1), the obstacle window one tick on;
-            // the next solve starts warm from the plan just stored (cs:163-180: d_last_u = d_u_out)
+            // the next solve starts warm from the plan just stored (cs:163-180: d_last_u = d_u_out) if use_last_solution
             if (HELP) __syncthreads();
             const int N = NC ? NC : a.N;
             if ((!HELP || threadIdx.x < CILQR_WAVE) && it >= 0) {
