@@ -1528,3 +1528,51 @@ def test_closed_loop_in_one_launch_follows_use_last_solution():
     cold = [l for l in r.stdout.splitlines() if l.endswith("ok") and l.split()[5] == "0"]
     assert len(cold) >= 3, "the seeded run no longer holds cold-start cases"
 
+
+
+def test_single_ego_cache_under_random_scene_changes(pkg, orc_det, scenarios):
+    """cilqr_solve keeps the tables of the previous call in HBM and re-uses them when the new arguments are the same or
+    the obstacle predictions are a later window of the routes uploaded before.  A random walk over what a caller may do
+    between two ticks — window one tick on, same window again, a jump back or ahead, routes cut to N + 1 samples, an
+    obstacle moved, another lane, other borders or target speed, the other scenario — must give the oracle's numbers on
+    every call, whatever the cache did."""
+    from oracle import Scene
+    rng = np.random.default_rng(31337)
+    N = 30
+    hits = 0
+    for name in ("three_straight", "two_borrow"):
+        cfg, sc = scenarios[name]
+        other = scenarios["three_bend" if name == "three_straight" else "two_straight"][1]
+        p = pkg.params_from_config(cfg, N=N, use_last_solution=0)
+        eng = pkg.BatchedCILQR(p, None)
+        T = sc.routes.shape[1]
+        lane, obs_all, borders, velo, tick = sc.lane, sc.obstacles.copy(), np.array(sc.road_borders, float), float(sc.target_velocity), 0
+        x0 = sc.ego_state.copy()
+        for step in range(70):
+            op = int(rng.integers(0, 10))
+            if op <= 3:
+                tick = min(tick + 1, T - N - 1)                       # the usual case: the window one tick on
+            elif op == 4:
+                pass                                                  # the very same arguments again
+            elif op == 5:
+                tick = int(rng.integers(0, T - N - 1))                # a jump
+            elif op == 6:
+                obs_all = obs_all.copy(); obs_all[int(rng.integers(0, len(obs_all))), :, 1] += 0.25   # an obstacle moved
+            elif op == 7:
+                lane = other.lane if lane is sc.lane else sc.lane     # another reference line
+            elif op == 8:
+                borders = borders + np.array([0.1, -0.1]); velo += 0.5
+            cut = rng.random() < 0.3                                  # predictions cut to exactly N + 1 samples
+            obs = obs_all[:, tick:tick + N + 1] if cut else obs_all[:, tick:]
+            tab = pkg.SceneTable(lane.x, lane.y, lane.yaw, np.ascontiguousarray(obs), borders, velo)
+            x = x0 + np.array([0.3 * rng.standard_normal(), 0.2 * rng.standard_normal(), 0.3 * rng.standard_normal(), 0.0])
+            u, xx, res = eng.solve_one(x, tab)
+            ref = orc_det.solver(p).solve(x, Scene(tab.lane_x, tab.lane_y, tab.lane_yaw, tab.obs, tab.road_borders, tab.ref_velo, 0))
+            eq_bits(ref["u"], u, f"{name} step {step} op {op} cut {cut}: u")
+            eq_bits(ref["x"], xx, f"{name} step {step} op {op} cut {cut}: x")
+            assert int(res["iters"]) == int(ref["res"]["iters"]), (name, step, op)
+        up, re = eng.solve_cache_stats()
+        assert up + re == 70 and re >= 20 and up >= 10, (up, re)   # both paths taken
+        hits += re
+        eng.close()
+    assert hits > 0
