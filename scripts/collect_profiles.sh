@@ -41,6 +41,10 @@ for b in 512 2048 4096 16384; do
 done
 # 4b. four batches in flight (extra.pipelined), config 2
 $BENCH --config 2 --streams 4 --steps 40 --warmup 3 $ONLY > "$OUT/bench_pipelined.json" 2>/dev/null
+# 4c. three batches in flight on the large launches: the next batch fills the tail of the one before
+for c in 5 3 4; do
+    $BENCH --config $c --streams 3 --steps 24 --warmup 2 $ONLY > "$OUT/bench_pipelined_c$c.json" 2>/dev/null
+done
 fi
 
 # 5. in-kernel phase accounting

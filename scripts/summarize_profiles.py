@@ -124,9 +124,16 @@ json.dump(other, open(os.path.join(dst, f"{tag}_other_configs.json"), "w"), inde
 
 b = last_json(os.path.join(src, "bench_pipelined.json"))
 if b:
-    json.dump({"command": "python bench.py --config 2 --streams 4 --steps 40 --warmup 3 --no-cpu-baseline --no-extras",
-               "sequential_value": b["value"], "pipelined": b["extra"]["pipelined"]},
-              open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
+    pl = {"command": "python bench.py --config 2 --streams 4 --steps 40 --warmup 3 --no-cpu-baseline --no-extras",
+          "sequential_value": b["value"], "pipelined": b["extra"]["pipelined"], "large_launches": {}}
+    for c in (5, 3, 4):
+        bc = last_json(os.path.join(src, f"bench_pipelined_c{c}.json"))
+        if bc:
+            pl["large_launches"][bc["config"]["workload"]] = {
+                "command": f"python bench.py --config {c} --streams 3 --steps 24 --warmup 2 --no-cpu-baseline --no-extras",
+                "one_batch_at_a_time": {"value": bc["value"], "ms_per_step": bc["ms_per_step"]},
+                "three_batches_in_flight": bc["extra"]["pipelined"]}
+    json.dump(pl, open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
 
 for c in (2, 3, 5, 4):
     p = os.path.join(src, f"phase_config{c}.json")
