@@ -29,7 +29,6 @@
 #include "detmath.h"
 
 #define CILQR_WAVE 64
-#define CILQR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define CILQR_DBG_SERIAL_REF_SCAN 1 /* cilqr_set_debug_flags: always take the serial reference-point chain */
 #define CILQR_DBG_UNIFORM_BACKWARD 2 /* use the wave-uniform backward sweep instead of the lane-parallel one */
 
@@ -674,19 +673,12 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
             j = j + alm_item(pos_lo, al.rho, mu[7]);
         } else {
             j = c.k->sq1 * dm_exp(c.k->sq2 * acc_up) + c.k->sq1 * dm_exp(c.k->sq2 * acc_lo);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * stl_up);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * stl_lo);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * vel_up);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * vel_lo);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * pos_up);
-            CILQR_SCHED_FENCE();
             j = j + c.k->sq1 * dm_exp(c.k->sq2 * pos_lo);
-            CILQR_SCHED_FENCE();
         }
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
@@ -1666,13 +1658,9 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             // (the scheduling fences keep the eight independent exp chains from being interleaved: that
             //  would only raise the register count — the wave is issue-bound, not latency-bound, here)
             double b_au = c.k->sq1 * dm_exp(c.k->sq2 * (um0 - c.k->acc_max));
-            CILQR_SCHED_FENCE();
             double b_al = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->acc_min - um0));
-            CILQR_SCHED_FENCE();
             double b_su = c.k->sq1 * dm_exp(c.k->sq2 * (um1 - c.k->stl_lim));
-            CILQR_SCHED_FENCE();
             double b_sl = c.k->sq1 * dm_exp(c.k->sq2 * (-c.k->stl_lim - um1));
-            CILQR_SCHED_FENCE();
             double q22 = c.k->sq2 * c.k->sq2;
             double lub0 = (c.k->sq2 * b_au) - (c.k->sq2 * b_al);
             double lub1 = (c.k->sq2 * b_su) - (c.k->sq2 * b_sl);
@@ -1693,16 +1681,12 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             }
             // velocity bounds and road borders (cs:507-533, 560-580)
             double b_vu = c.k->sq1 * dm_exp(c.k->sq2 * (xk[2] - c.k->velo_max));
-            CILQR_SCHED_FENCE();
             double b_vl = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->velo_min - xk[2]));
-            CILQR_SCHED_FENCE();
             double d_sign = e1 * cr - e0 * sr;
             double hyp = dm_hypot(e0, e1);
             double cur_d = (d_sign < 0) ? -hyp : hyp;
             double b_pu = c.k->sq1 * dm_exp(c.k->sq2 * (cur_d - c.k->pos_up_b));
-            CILQR_SCHED_FENCE();
             double b_pl = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->pos_lo_b - cur_d));
-            CILQR_SCHED_FENCE();
             double px = e0 / hyp, py = e1 / hyp;
             if (d_sign < 0) { px = -px; py = -py; }
             double nx = -px, ny = -py; // pos_lo_constr_over_x = -1 * pos_up_constr_over_x
@@ -1722,9 +1706,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
                 ObsOut t;
                 obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
                 double bf = c.k->oq1 * dm_exp(c.k->oq2 * t.mf);
-                CILQR_SCHED_FENCE();
                 double br = c.k->oq1 * dm_exp(c.k->oq2 * t.mr);
-                CILQR_SCHED_FENCE();
                 double df = c.k->oq2 * bf, dr = c.k->oq2 * br;
                 double sf = oq22 * bf, srr = oq22 * br;
                 b0 = b0 + (df * t.gf[0] + dr * t.gr[0]);
