@@ -1655,8 +1655,8 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
         if (!ALM && k >= 1) {
             double um0 = l.u[2 * k - 2], um1 = l.u[2 * k - 1];
             // control bounds (cs:510-513, 537-558)
-            // (the scheduling fences keep the eight independent exp chains from being interleaved: that
-            //  would only raise the register count — the wave is issue-bound, not latency-bound, here)
+            // (no scheduling fences between the exponentials any more: round 1 had them to hold the register count
+            //  down at one wavefront per SIMD; with two per SIMD leaving the order to the compiler is 2 % faster)
             double b_au = c.k->sq1 * dm_exp(c.k->sq2 * (um0 - c.k->acc_max));
             double b_al = c.k->sq1 * dm_exp(c.k->sq2 * (c.k->acc_min - um0));
             double b_su = c.k->sq1 * dm_exp(c.k->sq2 * (um1 - c.k->stl_lim));
