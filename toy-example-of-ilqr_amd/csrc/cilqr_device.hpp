@@ -311,10 +311,10 @@ __device__ inline void propagate(const Cst& c, const double x[4], const double u
 // |yaw| < 0.785 and |steer| < 0.7 (so |tan(steer)| / 2 < 0.4375 and |beta| < 0.42); for the CoG model the
 // angle beta + yaw is only known here: returns false, with xn untouched, when it is not small on
 // some lane — the caller then redoes the step the general way.  pk: the pinned coefficients (dm_pin_load).
-template <int RP>
+template <int RP, int PIN = DM_PIN>
 __device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4],
                                        const DmPinned* pk) {
-    constexpr int T = DM_PIN | DM_SMALL;
+    constexpr int T = PIN | DM_SMALL;
     if (RP == 0) {
         double sn, cs;
         dm_sincos<T>(x[3], &sn, &cs, pk);
@@ -1120,7 +1120,7 @@ struct RollOut {
     int csb, rowb;    // component / row stride in bytes
     unsigned lane_off;
 };
-template <int RP, bool SMALL>
+template <int RP, bool SMALL, int PIN = DM_PIN>
 __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], RollOut& o) {
     const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
     const double k0 = ((g.k[0] * dx0 + g.k[1] * dx1) + g.k[2] * dx2) + g.k[3] * dx3;
@@ -1131,9 +1131,9 @@ __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn&
     double xn[4];
     if (SMALL) {
         if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) return false;
-        if (!propagate_small<RP>(c, xc, un, xn, &pk)) return false;
+        if (!propagate_small<RP, PIN>(c, xc, un, xn, &pk)) return false;
     } else {
-        propagate<RP, DM_PIN | DM_NOSHORT>(c, xc, un, xn, &pk);
+        propagate<RP, PIN | DM_NOSHORT>(c, xc, un, xn, &pk);
     }
 #define CILQR_SLAB_ST(base, comp, val) \
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (val)), o.rsrc, o.lane_off, (base) + (comp) * o.csb, 0)
@@ -1160,7 +1160,7 @@ __device__ inline gdouble_w* uniform_ptr(double* p) {
     return (gdouble_w*)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 
-template <int RP>
+template <int RP, int PIN = DM_PIN>
 __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr_in, int lane, int n_alpha, int as_in) {
     const int N = c.N;
     const int R = N + 1;
@@ -1188,7 +1188,7 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
         // the loops are unrolled by two over two register sets, so nothing is copied between steps.  The
         // polynomial coefficients of sin / cos / tan sit in vector registers for the whole pass (dm_pin_load).
         DmPinned pk;
-        dm_pin_load(pk);
+        if (PIN) dm_pin_load(pk);
         int i = 0;
         {
             RollIn ga, gb;
@@ -1196,11 +1196,11 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             for (;;) {
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(gb, l, i + 1);
-                if (!roll_step<RP, true>(c, pk, ga, alpha, xc, o)) break;
+                if (!roll_step<RP, true, PIN>(c, pk, ga, alpha, xc, o)) break;
                 ++i;
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(ga, l, i + 1);
-                if (!roll_step<RP, true>(c, pk, gb, alpha, xc, o)) break;
+                if (!roll_step<RP, true, PIN>(c, pk, gb, alpha, xc, o)) break;
                 ++i;
             }
         }
@@ -1209,11 +1209,11 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             roll_fetch(ga, l, i);
             for (;;) {
                 if (i + 1 < N) roll_fetch(gb, l, i + 1);
-                roll_step<RP, false>(c, pk, ga, alpha, xc, o);
+                roll_step<RP, false, PIN>(c, pk, ga, alpha, xc, o);
                 ++i;
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(ga, l, i + 1);
-                roll_step<RP, false>(c, pk, gb, alpha, xc, o);
+                roll_step<RP, false, PIN>(c, pk, gb, alpha, xc, o);
                 ++i;
                 if (i >= N) break;
             }
@@ -1222,11 +1222,16 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
     wave_sync();
 }
 
+// PIN = DM_PIN: the polynomial coefficients of sin / cos and of the range reduction sit in vector registers for the whole
+// pass (36 VGPRs; what the one-wavefront-per-SIMD builds and the two-rows-per-lane builds do best with); 0: they are
+// scalar-register literals rebuilt where they are used (the scalar unit's issue slots) — the lone wavefronts that share a
+// SIMD in the large-batch builds are faster that way, and spill 12 vector registers instead of 74.
+template <int PIN = DM_PIN>
 __device__ inline void rollout_trials(const Cst& c, const Lds& l, double* scr, int lane, int n_alpha,
                                       int as = CILQR_MAX_ALPHA_TRIALS) {
     // one loop per vehicle model: only that model's polynomial constants are live inside it
-    if (c.rp == 0) rollout_trials_rp<0>(c, l, scr, lane, n_alpha, as);
-    else rollout_trials_rp<1>(c, l, scr, lane, n_alpha, as);
+    if (c.rp == 0) rollout_trials_rp<0, PIN>(c, l, scr, lane, n_alpha, as);
+    else rollout_trials_rp<1, PIN>(c, l, scr, lane, n_alpha, as);
 }
 
 // the rows of l.tidx start out as the current trajectory's indices (see the guesses of total_cost_trials)

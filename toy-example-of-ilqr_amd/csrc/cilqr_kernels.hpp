@@ -467,7 +467,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
                     // was rejected, now the other step sizes (lane 0 repeats the first trial: the same bits)
                     const bool all = deep || t0 == 1;
                     if (t0 == 1) restore_gains_head(l, first, N, lane);
-                    rollout_trials(c, l, all ? scr : first, lane, all ? CILQR_MAX_ALPHA_TRIALS : 1, all ? CILQR_MAX_ALPHA_TRIALS : 1);
+                    rollout_trials<(!HELP && WPS == 2 && NCH == 1) ? 0 : DM_PIN>(c, l, all ? scr : first, lane, all ? CILQR_MAX_ALPHA_TRIALS : 1,
+                                                                                      all ? CILQR_MAX_ALPHA_TRIALS : 1);
                     have_all = all;
                     PROF_ADD(PH_ROLLOUT);
                     if (PROF && a.prof && lane == 0) ph_acc[t0 == 1 ? PH_ROLL_SECOND : (all ? PH_ROLL_ALL : PH_ROLL_FIRST)] += 1;
