@@ -583,9 +583,18 @@ struct ObsOut {
     double gf[3], gr[3];  // gradient components (x, y, yaw); the v component is structurally 0
 };
 
+// What a row needs of an obstacle's record (x, y, sin yaw, cos yaw).  The rows fetch the record of obstacle o + 1 while they
+// work on obstacle o, and the first one before the barrier terms of the row: a record is the same for every trial and
+// every iteration of a solve and sits in L1 / L2, but its latency was paid once per obstacle and row.
+struct ObsRec {
+    double x, y, s, c;
+};
+__device__ inline void obs_fetch(ObsRec& r, gdouble* ob) {
+    r.x = ob[0]; r.y = ob[1]; r.s = ob[3]; r.c = ob[4]; // (ob[3], ob[4]: dm_sincos(ob[2]) precomputed on the device at upload)
+}
 template <bool GRAD>
 __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double sn_yaw, double cs_yaw,
-                                      gdouble* ob, ObsOut& o) {
+                                      const ObsRec& ob, ObsOut& o) {
     double wv0 = c.wb * cs_yaw, wv1 = c.wb * sn_yaw;
     double fx, fy, rx, ry;
     if (c.rp == 0) {
@@ -594,9 +603,9 @@ __device__ inline void obstacle_terms(const Cst& c, const double xk[4], double s
         fx = xk[0] + 0.5 * wv0; fy = xk[1] + 0.5 * wv1;
         rx = xk[0] - 0.5 * wv0; ry = xk[1] - 0.5 * wv1;
     }
-    const double so = ob[3], co = ob[4]; // dm_sincos(ob[2]) precomputed on the device at upload
-    double dfx = fx - ob[0], dfy = fy - ob[1];
-    double drx = rx - ob[0], dry = ry - ob[1];
+    const double so = ob.s, co = ob.c;
+    double dfx = fx - ob.x, dfy = fy - ob.y;
+    double drx = rx - ob.x, dry = ry - ob.y;
     double fX = co * dfx + so * dfy, fY = (-so) * dfx + co * dfy;
     double rX = co * drx + so * dry, rY = (-so) * drx + co * dry;
     o.mf = 1 - ((fX * fX) / c.k->ell_a2 + (fY * fY) / c.k->ell_b2);
@@ -662,6 +671,10 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
         double cur_d = (d_sign < 0) ? -hyp : hyp;
         double pos_up = cur_d - c.k->pos_up_b, pos_lo = c.k->pos_lo_b - cur_d;
         const double* mu = ALM ? (al.mu + (size_t)(k - 1) * al.C) : nullptr;
+        ObsRec rec = {0.0, 0.0, 0.0, 0.0};
+        gdouble* po = obs_at(c, 0, k);
+        const size_t po_step = (size_t)c.T * CILQR_OBS_STRIDE;
+        if (c.M > 0) obs_fetch(rec, po);
         double j;
         if (ALM) {
             j = alm_item(acc_up, al.rho, mu[0]) + alm_item(acc_lo, al.rho, mu[1]);
@@ -683,8 +696,11 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
         for (int o = 0; o < c.M; ++o) {
+            ObsRec nxt = rec;
+            po += po_step;
+            if (o + 1 < c.M) obs_fetch(nxt, po);
             ObsOut t;
-            obstacle_terms<false>(c, xk, sy, cy, obs_at(c, o, k), t);
+            obstacle_terms<false>(c, xk, sy, cy, rec, t);
             if (ALM) {
                 j = j + alm_item(t.mf, al.rho, mu[8 + 2 * o]);
                 j = j + alm_item(t.mr, al.rho, mu[9 + 2 * o]);
@@ -692,6 +708,7 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
                 j = j + c.k->oq1 * dm_exp(c.k->oq2 * t.mf);
                 j = j + c.k->oq1 * dm_exp(c.k->oq2 * t.mr);
             }
+            rec = nxt;
         }
         jb = j;
     }
@@ -1592,6 +1609,10 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
         double b0 = 0, b1 = 0, b2 = 0, b3 = 0;                                 // barrier gradient
         double sy, cy;
         dm_sincos(xk[3], &sy, &cy);
+        ObsRec rec = {0.0, 0.0, 0.0, 0.0};
+        gdouble* po = obs_at(c, 0, k);
+        const size_t po_step = (size_t)c.T * CILQR_OBS_STRIDE;
+        if (k >= 1 && c.M > 0) obs_fetch(rec, po);
         double g10 = 0, g30 = 0, g31 = 0; // ALM only: the other halves of the non-symmetric Hessian
         if (ALM && k >= 1) {
             const double um0 = l.u[2 * k - 2], um1 = l.u[2 * k - 1];
@@ -1635,8 +1656,12 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             h11 = uy * py + vy * ny;
             h22 = sl[4] + sl[5];
             for (int o = 0; o < c.M; ++o) {
+                ObsRec nxt = rec;
+                po += po_step;
+                if (o + 1 < c.M) obs_fetch(nxt, po);
                 ObsOut t;
-                obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
+                obstacle_terms<true>(c, xk, sy, cy, rec, t);
+                rec = nxt;
                 const double sf = alm_slope(t.mf, rho, mu[8 + 2 * o]);
                 const double sr2 = alm_slope(t.mr, rho, mu[9 + 2 * o]);
                 mun[8 + 2 * o] = alm_next_mu(c, mu[8 + 2 * o], rho, t.mf);
@@ -1708,8 +1733,12 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             // obstacles (cs:647-683)
             double oq22 = c.k->oq2 * c.k->oq2;
             for (int o = 0; o < c.M; ++o) {
+                ObsRec nxt = rec;
+                po += po_step;
+                if (o + 1 < c.M) obs_fetch(nxt, po);
                 ObsOut t;
-                obstacle_terms<true>(c, xk, sy, cy, obs_at(c, o, k), t);
+                obstacle_terms<true>(c, xk, sy, cy, rec, t);
+                rec = nxt;
                 double bf = c.k->oq1 * dm_exp(c.k->oq2 * t.mf);
                 double br = c.k->oq1 * dm_exp(c.k->oq2 * t.mr);
                 double df = c.k->oq2 * bf, dr = c.k->oq2 * br;
