@@ -100,7 +100,7 @@ k_forward_pass(BatchArgs a, const double* __restrict__ u, const double* __restri
     AlmSt al = load_alm(a, b, N);
     rollout_trials(c, l, scr, lane, n_alpha);
     for (int t = 0; t < n_alpha; ++t) {
-        const double* tr = scr + t;
+        const double* tr = TRIAL_AT(scr, t);
         for (int k = lane; k <= N; k += CILQR_WAVE) {
             double* xo = new_x + (((size_t)b * n_alpha + t) * R + k) * 4;
             xo[0] = TR(tr, 0, k); xo[1] = TR(tr, 1, k); xo[2] = TR(tr, 2, k); xo[3] = TR(tr, 3, k);

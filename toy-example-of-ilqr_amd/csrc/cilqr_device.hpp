@@ -259,15 +259,16 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
     wave_sync();
 }
 
-// scratch slab of the trial trajectories: [6][(N+1)][20 alphas] doubles, alpha fastest, so that the
-// 20 rollout lanes of one store instruction write 160 contiguous bytes.
-// rows 0-3 = x' components, 4-5 = u' components.  TR(t, c, k) with t = slab + alpha.
+// scratch slab of the trial trajectories: [3 pairs][(N+1)][20 alphas][2] doubles — components in pairs (x0 x1 | x2 x3 |
+// u0 u1), alpha next, so that the 20 rollout lanes of one 16-byte store instruction write 320 contiguous bytes and a
+// row is three stores, three loads.  Components 0-3 = x', 4-5 = u'.  TR(t, c, k) with t = TRIAL_AT(slab, alpha).
 // Behind the slab, [6][(N+1)] doubles for the alpha = 1 trial alone (the "first-trial buffer"): most iterations
 // accept that trial, so they roll out, cost and accept only it — 2.4 KB written and read back contiguously,
 // L2-resident — and the slab is written only in iterations expected (or found) to search deeper.  Both are
-// addressed as TRS(t, c, k, as): as = 20 inside the slab (t = slab + alpha), as = 1 in the first-trial buffer.
+// addressed as TRS(t, c, k, as): as = 20 inside the slab (t = TRIAL_AT(slab, alpha)), as = 1 in the first-trial buffer.
 #define CILQR_TRIAL_ROWS 6
-#define TRS(t, c, k, as) (t)[((size_t)(c) * R + (size_t)(k)) * (size_t)(as)]
+#define TRS(t, c, k, as) (t)[(((size_t)((c) >> 1) * R + (size_t)(k)) * (size_t)(as)) * 2 + (size_t)((c) & 1)]
+#define TRIAL_AT(base, alpha) ((base) + 2 * (alpha))
 #define TR(t, c, k) TRS(t, c, k, CILQR_MAX_ALPHA_TRIALS)
 __host__ __device__ inline size_t slab_doubles(int N) {
     return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
@@ -825,7 +826,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
     }
 #pragma unroll
     for (int tt = 0; tt < NTR; ++tt) {
-        const double* t = scr + a0 + tt;
+        const double* t = TRIAL_AT(scr, a0 + tt);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int k = lane + CILQR_WAVE * ch;
@@ -952,7 +953,7 @@ __device__ inline void total_cost_trials(const Cst& c, const Lds& l, const AlmSt
         if (proven[tt]) continue;
         wave_sync();
         *n_fallback += 1;
-        const double* t = scr + a0 + tt;
+        const double* t = TRIAL_AT(scr, a0 + tt);
         int* tix = l.tidx + (slot0 + tt) * (N + 2);
         int s = idx0;
         if (lane == 0) tix[0] = s;
@@ -1127,6 +1128,7 @@ __device__ inline void roll_fetch(RollIn& g, const Lds& l, int i) {
     g.u[1] = l.u[2 * i + 1];
 }
 typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 // Where the rollout lanes store: a buffer descriptor of the destination (four scalar registers), wave-uniform byte
 // offsets of the current rows (scalar registers, advanced by the scalar unit) and this lane's byte offset — one
 // buffer_store per value, no address arithmetic in vector registers.
@@ -1134,7 +1136,7 @@ struct RollOut {
     __amdgpu_buffer_rsrc_t rsrc;
     int ox;           // byte offset of row i + 1 of component 0
     int ou;           // byte offset of row i of component 4
-    int csb, rowb;    // component / row stride in bytes
+    int csb, rowb;    // pair / row stride in bytes
     unsigned lane_off;
 };
 template <int RP, bool SMALL, int PIN = DM_PIN>
@@ -1152,15 +1154,17 @@ __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn&
     } else {
         propagate<RP, PIN | DM_NOSHORT>(c, xc, un, xn, &pk);
     }
-#define CILQR_SLAB_ST(base, comp, val) \
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (val)), o.rsrc, o.lane_off, (base) + (comp) * o.csb, 0)
-    CILQR_SLAB_ST(o.ou, 0, un[0]);
-    CILQR_SLAB_ST(o.ou, 1, un[1]);
-    CILQR_SLAB_ST(o.ox, 0, xn[0]);
-    CILQR_SLAB_ST(o.ox, 1, xn[1]);
-    CILQR_SLAB_ST(o.ox, 2, xn[2]);
-    CILQR_SLAB_ST(o.ox, 3, xn[3]);
-#undef CILQR_SLAB_ST
+#define CILQR_SLAB_ST2(base, pair, v0, v1)                                                                           \
+    {                                                                                                                \
+        const u32x2 lo_ = __builtin_bit_cast(u32x2, (v0)), hi_ = __builtin_bit_cast(u32x2, (v1));                    \
+        u32x4 q_;                                                                                                    \
+        q_.x = lo_.x; q_.y = lo_.y; q_.z = hi_.x; q_.w = hi_.y;                                                      \
+        __builtin_amdgcn_raw_buffer_store_b128(q_, o.rsrc, o.lane_off, (base) + (pair) * o.csb, 0);                  \
+    }
+    CILQR_SLAB_ST2(o.ou, 0, un[0], un[1]);
+    CILQR_SLAB_ST2(o.ox, 0, xn[0], xn[1]);
+    CILQR_SLAB_ST2(o.ox, 1, xn[2], xn[3]);
+#undef CILQR_SLAB_ST2
     xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
     o.ox += o.rowb;
     o.ou += o.rowb;
@@ -1186,17 +1190,17 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
     double* scr_in_uniform = (double*)(size_t)scr; // the same address as a generic pointer, for the descriptor
     if (lane < n_alpha) {
         const double alpha = dm_pow2i(-lane);
-        gdouble_w* t = scr + lane;
+        gdouble_w* t = TRIAL_AT(scr, lane);
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         TRS(t, 0, 0, as) = xc[0]; TRS(t, 1, 0, as) = xc[1]; TRS(t, 2, 0, as) = xc[2]; TRS(t, 3, 0, as) = xc[3];
         const int CS = R * as; // component stride (doubles)
         RollOut o;
         o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)scr_in_uniform, 0, (int)(CILQR_TRIAL_ROWS * CS * sizeof(double)), 0x00020000);
-        o.ox = as * (int)sizeof(double);        // row 1 of component 0
-        o.ou = 4 * CS * (int)sizeof(double);    // row 0 of component 4
-        o.lane_off = 8u * (unsigned)lane;
-        o.csb = CS * (int)sizeof(double);
-        o.rowb = as * (int)sizeof(double);
+        o.ox = 2 * as * (int)sizeof(double);        // row 1 of the pair (x0, x1)
+        o.ou = 2 * 2 * CS * (int)sizeof(double);    // row 0 of the pair (u0, u1)
+        o.lane_off = 16u * (unsigned)lane;
+        o.csb = 2 * CS * (int)sizeof(double);       // pair stride
+        o.rowb = 2 * as * (int)sizeof(double);
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
         // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
@@ -1263,7 +1267,7 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
                                     int as = CILQR_MAX_ALPHA_TRIALS) {
     const int N = c.N;
     const int R = N + 1;
-    const double* t = scr + a;
+    const double* t = TRIAL_AT(scr, a);
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         l.x[4 * k] = TRS(t, 0, k, as);
         l.x[4 * k + 1] = TRS(t, 1, k, as);
