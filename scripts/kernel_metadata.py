@@ -10,7 +10,7 @@ LLVM tools are: no GPU needed).
 3. disassembles each k_solve variant and, for every INNERMOST loop of its body (a backward branch whose span holds
    no other backward branch), counts instructions, FP64 vector ops, scratch accesses and v_readlane / v_writelane
    (how the compiler reloads spilled scalars) and names the loop by what it contains: `backward_step` (ds_bpermute +
-   v_rcp_f64: the Riccati step), `rollout_step` (buffer_store_dwordx2 into the slab), `cost_rows`, ...
+   v_rcp_f64: the Riccati step), `rollout_step` (buffer_store_dwordx4 into the slab), `cost_rows`, ...
 
 The table in DESIGN.md section 4 ("Register allocation") is generated from this file's output:
   scripts/kernel_metadata.py --markdown
@@ -114,7 +114,7 @@ def classify(ops):
     n_dsr = c(lambda o: o.startswith("ds_read") or o.startswith("ds_load"))
     if n_bperm >= 8 and n_rcp >= 1:
         return "backward_step"
-    if n_bst >= 6:
+    if n_bst >= 3:
         return "rollout_step"
     if n_exp >= 4:
         return "cost_rows"
