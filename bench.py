@@ -298,6 +298,21 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
                 # large-batch build, two per SIMD): SIMD VALU busy = share x resident waves / 1024
                 valu["valu_active_share_of_wave_cycles"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"]
                 valu["mean_resident_waves"] = pmc["SQ_WAVE_CYCLES"] * 4.0 / (2.36e9 * kernel_ms * 1e-3)
+            if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+                # how many of the 64 lanes of an issued vector instruction are live, averaged over the instructions'
+                # cycles (both counters in quad-cycles: thread-cycles / (instruction-cycles x 64)).  The serial phases
+                # pull it down: the lone first-trial rollout runs one (with trajectories in pairs: two) lanes of 64
+                valu["valu_lane_occupancy"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+    # how much of the FP64 vector peak does the ALGORITHM's arithmetic amount to: SURVEY 8(d)'s dense count
+    # N (965 + 168 M + T (106 + 34 M)) flops per iteration, T = line-search trials per iteration of THIS run
+    iters_sum = float(res["iters"].sum())
+    trials_per_iter = float(res["ls_trials"].sum()) / iters_sum if iters_sum else 0.0
+    flops_launch = float((res["iters"] * N * (965.0 + 168.0 * M_of)).sum() + (res["ls_trials"] * N * (106.0 + 34.0 * M_of)).sum())
+    useful = {"flops_per_launch": flops_launch, "trials_per_iteration": trials_per_iter,
+              "fp64_useful_frac": flops_launch / (kernel_ms * 1e-3) / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
+              "definition": "SURVEY.md 8(d): N (965 + 168 M + T (106 + 34 M)) FP64 flops per iteration as the reference "
+                            "computes them (dense 4x4 products, transcendentals NOT weighted), T from this run, over "
+                            "the 78.6 TFLOP/s FP64 vector peak"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "traffic_is": "bytes crossing the L2 <-> fabric boundary per launch (Infinity Cache + HBM; the counters cannot "
@@ -307,6 +322,7 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",
             "valu_issue": valu,
+            "fp64_useful": useful,
             "note": "the fused solve is FP64-VALU/latency bound, not HBM bound (DESIGN.md)"}
 
 

@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config2" -- 
 # 3. HBM traffic and SQ counters per workload, one small counter group per pass
 wl_args() { case $1 in c5) echo "--config 5";; c3) echo "--config 3";; c2) echo "--config 2";; c2b16k) echo "--config 2 --batch 16384";; c4) echo "--config 4";; esac; }
 for wl in c5 c3 c2 c2b16k c4; do
-    for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" \
+    for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
                "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
         name=$(echo $grp | tr ' ' '+')
         rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_${wl}_$name" -- \

@@ -6,7 +6,8 @@ leaf functions, formula-identical to the CoG branches of src/utils.cpp:262-439 a
 src/cilqr_solver.cpp:316-324,692-699 — evaluates them on seeded random inputs and
 stores inputs + outputs in tests/golden/leaf_vectors.npz.  Also runs the reference's Python
 *variant* solver (scripts/2-cilqr-motionplanning.py main scenario) headless and stores its end state
-(tests/golden/variant_end_to_end.npz) and samples the Python cubic spline on the four scenario
+(tests/golden/variant_vectors.npz), the rear-axle step of scripts/1-lqr-pathtracking.py
+(tests/golden/rear_axle_vectors.npz) and samples the Python cubic spline on the four scenario
 way-point sets (tests/golden/spline_vectors.npz).  Only data is written; no reference source is
 copied.  Nothing here runs on the GPU box.
 """
@@ -182,7 +183,38 @@ def variant_vectors():
     return out
 
 
+def rear_axle_vectors():
+    """The rear-axle step of the reference's path-tracking demo (scripts/1-lqr-pathtracking.py:134-140, `update`):
+    the same model as the RearCenter branch of utils::kinematic_propagate (src/utils.cpp:266-272) — x, y, v identical
+    expressions, yaw as `v / WB * tan(delta) * dt` there against `v * tan(delta) * dt / wb` in the C++ (<= 2 ulp apart).
+    State order there is (x, y, yaw, v); stored here in the solver's order (x, y, v, yaw)."""
+    spec = importlib.util.spec_from_file_location("lqr_pathtracking", str(REF / "scripts" / "1-lqr-pathtracking.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, str(REF / "scripts"))
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(20250830)  # its own stream: the other fixtures regenerate unchanged
+    n = 200
+    x = np.column_stack([rng.uniform(-50, 50, n), rng.uniform(-10, 10, n), rng.uniform(0, 15, n), rng.uniform(-3.2, 3.2, n)])
+    u = np.column_stack([rng.uniform(-4, 4, n), rng.uniform(-0.6, 0.6, n)])
+    out = np.empty_like(x)
+    for i in range(n):
+        st = mod.VehicleState(x=float(x[i, 0]), y=float(x[i, 1]), yaw=float(x[i, 3]), v=float(x[i, 2]))
+        st = mod.update(st, float(u[i, 0]), float(u[i, 1]))
+        out[i] = (st.x, st.y, st.v, st.yaw)
+    # a 60-step open-loop rollout through the same function (chained, as const_velo_prediction chains the C++ step)
+    st = mod.VehicleState(x=1.0, y=-2.0, yaw=0.3, v=6.5)
+    ctl = np.column_stack([rng.uniform(-2, 2, 60), rng.uniform(-0.3, 0.3, 60)])
+    chain = []
+    for a, d in ctl:
+        st = mod.update(st, float(a), float(d))
+        chain.append((st.x, st.y, st.v, st.yaw))
+    return {"x": x, "u": u, "out": out, "dt": np.array(mod.dt), "wb": np.array(mod.WB),
+            "chain_x0": np.array([1.0, -2.0, 6.5, 0.3]), "chain_u": ctl, "chain_out": np.array(chain)}
+
+
 def main():
+    np.savez_compressed(OUT / "rear_axle_vectors.npz", **rear_axle_vectors())
+    print("rear_axle_vectors.npz written")
     rng = np.random.default_rng(20250829)
     np.savez_compressed(OUT / "leaf_vectors.npz", **leaf_vectors(rng))
     print("leaf_vectors.npz written")

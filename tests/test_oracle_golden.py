@@ -34,6 +34,30 @@ def test_kinematic_propagate(orc, leaf):
     close(got, leaf["prop_out"])
 
 
+def test_kinematic_propagate_rear_axle(request, orc):
+    """RearCenter branch (utils.cpp:266-272) against the reference's own rear-axle step, scripts/1-lqr-pathtracking.py:134-140
+    (`update`), imported headless by make_golden.py: x, y, v are the same expressions; yaw is `v / WB * tan(d) * dt` there
+    and `v * tan(d) * dt / wb` in the C++ — the same value up to the rounding of three operations."""
+    g = dict(np.load(GOLDEN / "rear_axle_vectors.npz"))
+    dt, wb = float(g["dt"]), float(g["wb"])
+    got = np.stack([orc.propagate(x, u, dt, wb, 0) for x, u in zip(g["x"], g["u"])])
+    close(got, g["out"])
+    libm = request.node.callspec.params["orc"] == "libm"
+    if libm:  # the same libm on both sides: position and speed to the bit, yaw within the re-association
+        assert np.array_equal(got[:, :3], g["out"][:, :3])
+    # yaw' = yaw + increment: the two increments are <= 2 ulp (of the increment) apart, the sum rounds once more; measured in
+    # units of the largest of the three magnitudes involved (a small yaw' after cancellation has a finer spacing of its own)
+    inc = g["x"][:, 2] * np.tan(g["u"][:, 1]) * dt / wb
+    unit = np.spacing(np.maximum(np.maximum(np.abs(g["x"][:, 3]), np.abs(inc)), np.abs(g["out"][:, 3])))
+    err = np.abs(got[:, 3] - g["out"][:, 3]) / unit
+    assert err.max() <= (2.0 if libm else 4.0), err.max()
+    # chained, as const_velo_prediction / forward_pass chain it (cilqr_solver.cpp:182-197, 442-461)
+    x = g["chain_x0"].copy()
+    for u, want in zip(g["chain_u"], g["chain_out"]):
+        x = orc.propagate(x, u, dt, wb, 0)
+        close(x, want, rtol=1e-12, atol=1e-12)
+
+
 def test_model_derivatives(orc, leaf):
     dt, wb = float(leaf["dt"]), float(leaf["wb"])
     N = leaf["md_u"].shape[0]

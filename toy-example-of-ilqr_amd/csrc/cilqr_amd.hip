@@ -339,6 +339,7 @@ struct cilqr_handle {
     DevBuf tl;
     int tl_B = 0;
     bool last_launch_shared = false;
+    bool last_launch_reset_ctl = false; // the last fused launch zeroed the control words (persistent blocks): its counters are its own
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
     // resumable solves (k_solve's RES: the two-row builds in persistent launches): iterations per slice, 0 = off.  A
     // launch whose batch fits the chip at once (no second round of trajectories) has nothing to reorder and runs whole.
@@ -419,6 +420,20 @@ static void update_window(cilqr_handle* h) {
     h->win_occ = pick(occ_floor);
     fixed = lds_bytes(N, 0, alm, 1, 1);
     h->win_lg = pick(occ_floor);
+}
+
+// One launch per handle at a time (scratch areas, control words, timeline and staging buffers belong to the launch in
+// flight): work enqueued on another stream than the handle's previous launch first waits for it, on the device.  Called
+// before ANY asynchronous work that touches handle buffers.
+static int order_after_last_launch(cilqr_handle* h, hipStream_t s) {
+    if (h->launched && h->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_launch, 0));
+    return CILQR_OK;
+}
+// Host-side wait for the handle's own last launch (before its arrays are replaced): the other handles of the process and
+// their streams are left alone — a hipDeviceSynchronize() here stalled every batch in flight.
+static int wait_last_launch(cilqr_handle* h) {
+    if (h->launched) HIP_TRY(hipEventSynchronize(h->ev_launch));
+    return CILQR_OK;
 }
 
 static int check_ready(cilqr_handle* h) {
@@ -619,7 +634,10 @@ extern "C" int cilqr_set_resume_iters(cilqr_handle* h, int32_t iters) {
 extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
     if (!h || !out) return fail(CILQR_ERR_BAD_ARG, "null argument");
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (!h->sh_ctl.p) return CILQR_OK;
+    h->last_parked = 0;
+    // the control words are zeroed by persistent launches only: after any other launch they still hold an earlier
+    // launch's counts, which are not this handle's last launch's — report zeros then
+    if (!h->sh_ctl.p || !h->last_launch_reset_ctl) return CILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     unsigned w[SH_SLOT0];
@@ -1021,18 +1039,24 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
         if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS)) return fail(CILQR_ERR_DEVICE, "hipMalloc control words");
         HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
     }
-    // work sharing between blocks (builds of horizons above 63, barrier mode): one request and one row of hints per
-    // trajectory
-    if (fused && two_rows(h) && h->resume_iters > 0 && (B > h->park_B || N != h->park_N || !h->park.p)) {
-        HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
+    // resumable solves: only the launches that can park — two rows per lane, barrier mode, persistent blocks (lone
+    // wavefronts two per SIMD, no closed loop), more trajectories than resident blocks
+    const bool can_park = fused && two_rows(h) && h->resume_iters > 0 && h->params[0].solve_type == 0 && !h->looping &&
+                          h->persistent_blocks && lone_two_per_simd(h, B) && h->debug_flags == 0 && !h->profiling &&
+                          (size_t)B > (size_t)h->num_cus; // (more than one round of resident blocks is possible)
+    if (can_park && (B > h->park_B || N != h->park_N || !h->park.p)) {
+        int rcw = wait_last_launch(h); // (this handle's previous launch may be using the old arrays)
+        if (rcw) return rcw;
         h->park.release(); h->rq.release();
         if (h->park.ensure(sizeof(double) * park_doubles(N) * (size_t)B) || h->rq.ensure(sizeof(unsigned long long) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
         h->park_B = B;
         h->park_N = N;
     }
+    // work sharing between blocks (builds of horizons above 63): one request and one row of hints per trajectory
     if (two_rows(h) && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
-        HIP_TRY(hipDeviceSynchronize()); // (a launch on another stream may be using the old arrays)
+        int rcw = wait_last_launch(h);
+        if (rcw) return rcw;
         h->sh_req.release(); h->sh_hints.release();
         if (h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) || h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc work-sharing state");
@@ -1082,6 +1106,8 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     a.loop_states = loop.states;
     a.loop_iters = loop.iters;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_after_last_launch(h, s); // before the first asynchronous touch of a handle buffer (timeline, control words, ...)
+    if (rc) return rc;
     if (h->profiling) {
         if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
         a.prof = static_cast<long long*>(h->prof.p);
@@ -1093,7 +1119,6 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         a.timeline = static_cast<long long*>(h->tl.p);
         h->tl_B = B;
     }
-    if (h->launched && h->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_launch, 0)); // (see cilqr_handle::ev_launch)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     {
         const bool two = (a.N + 1 > CILQR_WAVE);
@@ -1103,6 +1128,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         auto kern = k_solve<false, 1, false, false, false>;
         bool one = false, lg = false, persistent = false;
         h->last_launch_shared = false;
+        h->last_launch_reset_ctl = false;
         if (loop.ticks >= 1) {
             // closed loop in one launch: the plain builds carry it
             if (a.alm) {
@@ -1181,6 +1207,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             grid = B < cap ? B : cap;
             a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
             HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+            h->last_launch_reset_ctl = true;
             // resumable solves: the builds that carry them (two rows per lane, persistent), batches that take more than
             // one round of the resident blocks
             if (two && !a.alm && loop.ticks < 1 && h->resume_iters > 0 && B > grid && h->park.p && h->park_B >= B && h->park_N == a.N) {
@@ -1243,9 +1270,14 @@ extern "C" int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const doub
     if (rc) return rc;
     if (B < 1 || !d_x || !d_x0) return fail(CILQR_ERR_BAD_ARG, "bad batch arguments");
     HIP_TRY(hipSetDevice(h->device));
+    rc = order_after_last_launch(h, static_cast<hipStream_t>(stream)); // (x is the previous solve's output, x0 / tick the next one's input)
+    if (rc) return rc;
     hipLaunchKernelGGL(k_advance, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), B, h->params[0].N, d_x,
                        d_x0, d_tick);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_launch, static_cast<hipStream_t>(stream)));
+    h->last_stream = static_cast<hipStream_t>(stream);
+    h->launched = true;
     return CILQR_OK;
 }
 
@@ -1261,6 +1293,8 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     rc = validate_ids(h, B, scenario_id, param_id, tick);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    rc = order_after_last_launch(h, h->stream); // (the staging buffers are the handle's)
+    if (rc) return rc;
     const int N = h->params[0].N;
     Staged ids;
     rc = stage_ids(h, B, scenario_id, param_id, tick, ids);
@@ -1421,6 +1455,8 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     rc = validate_ids(h, B, scenario_id, param_id, tick);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    rc = order_after_last_launch(h, h->stream); // (they share the handle's scratch areas and staging buffers)
+    if (rc) return rc;
     rc = ensure_scratch(h, B);
     if (rc) return rc;
     rc = stage_ids(h, B, scenario_id, param_id, tick, pc.ids);

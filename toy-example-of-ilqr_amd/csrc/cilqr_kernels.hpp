@@ -252,7 +252,8 @@ enum { SOLVE_PARKED = -1 /* parked again: its number has been queued */, SOLVE_B
 template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS, int NTP, int NC, bool LG, bool SHARE, bool RES, bool LOOP>
 __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const int slot, const bool resumed,
                                           const double* __restrict__ x0,
-                                          const double* __restrict__ last_u, double* __restrict__ u_out,
+                                          const double* last_u, double* u_out, // (not restrict: a later tick of the closed
+                                                                               //  loop warm-starts from the plan in u_out)
                                           double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
                                           cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
@@ -603,7 +604,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
         park_copy(pk, l.x, l.u, l.ridx, sc_, N, lane, 1);
         if (a.timeline && lane == 0) { // resumable solves: first start, and in [2] minus the busy time so far
             if (!resumed) a.timeline[4 * (size_t)b] = tl_start;
-            a.timeline[4 * (size_t)b + 2] -= (long long)__builtin_amdgcn_s_memrealtime() - tl_start;
+            (void)__hip_atomic_fetch_add(a.timeline + 4 * (size_t)b + 2, tl_start - (long long)__builtin_amdgcn_s_memrealtime(),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (slices run on different XCDs)
         }
         rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
         return SOLVE_PARKED;
@@ -639,7 +641,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
         long long* tl_rec = a.timeline + 4 * (size_t)b;
         if (!(RES && resumed)) tl_rec[0] = tl_start;  // (a resumed solve keeps the start of its first slice)
         tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        if (RES && res_on) tl_rec[2] -= tl_rec[1] - tl_start; // (a sliced solve has no one block: minus its busy time instead)
+        if (RES && res_on) // (a sliced solve has no one block: minus its busy time instead)
+            (void)__hip_atomic_fetch_add(tl_rec + 2, tl_start - tl_rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else tl_rec[2] = blockIdx.x;
         tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf; // hwreg(HW_REG_XCC_ID, 0, 4)
     }
@@ -658,8 +661,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
 template <bool DBG, int NCH, bool ALM, bool HELP, bool PROF, int WPS = 1, int NTP = CILQR_NT, int NC = 0, bool LG = false,
           bool SHARE = false, bool RES = false, bool LOOP = false>
 __global__ void __launch_bounds__(HELP ? 2 * CILQR_WAVE : CILQR_WAVE, HELP ? 2 : WPS)
-k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ last_u,
-        double* __restrict__ u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
+k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
+        double* u_out, double* __restrict__ x_out, cilqr_result* __restrict__ res_out,
         cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const bool persistent = !HELP && a.next != nullptr;
@@ -792,5 +795,5 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* __restrict__ l
 #define CILQR_SOLVE_VARIANTS(X) CILQR_SOLVE_VARIANTS_PROD(X) CILQR_SOLVE_VARIANTS_DEV(X)
 #define CILQR_SOLVE_GROUPS 8
 #define CILQR_SOLVE_SIGNATURE                                                                                      \
-    (BatchArgs, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, \
+    (BatchArgs, const double* __restrict__, const double*, double*, double* __restrict__, \
      cilqr_result* __restrict__, cilqr_trace_rec* __restrict__, int)
