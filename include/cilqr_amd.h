@@ -214,6 +214,12 @@ int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next,
  * 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
 
+/* Trajectories per wavefront (horizons up to 63, barrier mode): -1 (default) = automatic — batches beyond the helper
+ * range run two trajectories per wavefront, whose line-search rollouts (src/cilqr_solver.cpp:442-461, a serial chain over
+ * the horizon) share one pass of the instruction stream; 0 or 1 = one trajectory per wavefront everywhere; 2 = two
+ * wherever that build can run (any batch size).  Results are identical in every mode. */
+int cilqr_set_group_mode(cilqr_handle* h, int32_t mode);
+
 /* Work sharing between blocks (horizons above 63, batches beyond the helper range): 1 (default) = blocks that find no
  * trajectory left to solve (large batches run persistent blocks that pull trajectories from a counter) cost
  * line-search trials of the trajectories still being solved; 0 = off.  A cost is a function of the trial trajectory alone, so the results

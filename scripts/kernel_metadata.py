@@ -165,13 +165,19 @@ def loop_report(ins):
 
 def variant_of(dem):
     m = re.search(r"k_solve<(.*?)>\(", dem)
-    return m.group(1) if m else None
+    if m:
+        return m.group(1)
+    m = re.search(r"k_solve_grp<(.*?)>\(", dem)  # the grouped builds: <NC, G>
+    return "grp:" + m.group(1) if m else None
 
 
 TPL = ("DBG", "NCH", "ALM", "HELP", "PROF", "WPS", "NTP", "NC", "LG", "SHARE", "RES", "LOOP")
 
 
 def describe(variant):
+    if variant.startswith("grp:"):
+        nc, g = [p.strip() for p in variant[4:].split(",")]
+        return f"grouped: {g} trajectories per wavefront, waves/SIMD=2" + (f" N={nc}" if nc != "0" else "")
     parts = [p.strip() for p in variant.split(",")]
     kv = dict(zip(TPL, parts))
     tags = []

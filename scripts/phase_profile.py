@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--horizon", type=int, default=50)
+ap.add_argument("--group", type=int, default=0, help="2: the grouped build (two trajectories per wavefront), which runs two wavefronts per SIMD")
 args = ap.parse_args()
 W = pkg.workloads
 if args.config == 2:
@@ -25,6 +26,9 @@ elif args.config == 4:
 else:
     wl = W.config5(B_base=args.batch or 4096, N=args.horizon)
 eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True)  # the cycle accounting lives in the development library
+if args.group:
+    eng.set_group_mode(args.group)
+    eng.set_helper_mode(0)
 ids = dict(scenario_id=wl.scenario_id, param_id=wl.param_id, tick=wl.tick)
 eng.solve_batch(wl.x0, **ids)
 eng.set_phase_profiling(True)
@@ -55,6 +59,9 @@ rep["slowest_8"] = [{"b": int(b), "iters": int(res["iters"][b]), "trials": int(r
                      "trial_cost_cycles": int(cyc[b, 4]), "ref_points_cycles": int(cyc[b, 10]),
                      "ref_scan_fallbacks": int(cyc[b, 8])} for b in order]
 rep["ref_scan_fallbacks_max_per_trajectory"] = int(cyc[:, 8].max())
+if args.group:  # the grouped build books its own bookkeeping in slots 10-12
+    rep["grouped_extra_cycles_per_iteration"] = {n: float(cyc[:, i].sum() / res["iters"].sum()) for n, i in
+                                                 (("segment_setup", 10), ("back_in_solve", 11), ("state_store", 12))}
 if os.environ.get("PHASE_OUT"):
     np.save(os.environ["PHASE_OUT"], cyc)
 print(json.dumps(rep, indent=1))

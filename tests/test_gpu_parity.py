@@ -1576,3 +1576,105 @@ def test_single_ego_cache_under_random_scene_changes(pkg, orc_det, scenarios):
         hits += re
         eng.close()
     assert hits > 0
+
+
+def test_trajectories_in_pairs_per_wavefront_are_transparent(pkg, orc_det, engines, scenarios):
+    """Round 4: the grouped build (k_solve_grp, cilqr_set_group_mode) — two trajectories per wavefront whose line-search
+    rollouts share one pass — against the one-trajectory-per-wavefront build and the oracle: trajectories, costs, counters
+    and the whole decision trace, for every rollout policy, both vehicle models, warm starts with tick offsets, odd batch
+    sizes (a wavefront left with one trajectory), mixed parameter sets and scenarios inside one launch, a zero iteration
+    budget, and ids the device refuses."""
+    for name, N, B in (("three_bend", 50, 97), ("two_straight", 50, 64), ("three_straight", 30, 33), ("two_borrow", 63, 21)):
+        eng, p, sc = engines(name, N, use_last_solution=0)
+        x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 4242 + N)
+        scene = oracle_scene(sc)
+        refs = [orc_det.solver(p).solve(x, scene) for x in x0]
+        eng.set_helper_mode(0)
+        eng.set_group_mode(0)
+        base = eng.solve_batch(x0, trace_cap=128)
+        compare_solves(base, refs, f"{name} N={N} one per wavefront")
+        for rollout in (-1, 0, 1):
+            eng.set_group_mode(2)
+            eng.set_rollout_mode(rollout)
+            g = eng.solve_batch(x0, trace_cap=128)
+            what = f"{name} N={N} pairs rollout={rollout}"
+            compare_solves(g, refs, what)
+            eq_bits(base["u"], g["u"], what + " u")
+            eq_bits(base["x"], g["x"], what + " x")
+            assert (base["res"] == g["res"]).all(), what
+            for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+                eq_bits(base["trace"][f], g["trace"][f], what + " trace." + f)
+        if B > 40:  # wavefronts that ran dry took trajectories over from wavefronts that still held two (the launch's tail)
+            assert eng.resume_stats() > 0, (name, "no trajectory changed wavefronts")
+        eng.set_rollout_mode(-1)
+        eng.set_helper_mode(-1)
+        eng.set_group_mode(-1)
+        assert (base["trace"]["trials"] == 1).any() and (base["trace"]["trials"] > 1).any()
+        if name in ("three_bend", "two_straight"):
+            assert (base["trace"]["trials"] == 20).any()  # failed searches: the second pass and the deep mode were exercised
+    # warm starts and tick offsets (cs:163-180, ut:88-103): a short closed loop, every tick through the grouped build
+    cfg, sc = scenarios["three_straight"]
+    p = pkg.params_from_config(cfg, N=30)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+    eng.set_group_mode(2)
+    eng.set_helper_mode(0)
+    B = 13
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 77)
+    solvers = [orc_det.solver(p) for _ in range(B)]
+    for s_ in solvers:
+        s_.reset()
+    last_u = None
+    for tick in range(6):
+        scene = oracle_scene(sc, tick)
+        out = eng.solve_batch(x0, tick=np.full(B, tick, np.int32), last_u=last_u, trace_cap=128)
+        compare_solves(out, [solvers[b].solve(x0[b], scene) for b in range(B)], f"pairs, closed loop tick {tick}")
+        last_u = out["u"].copy()
+        x0 = out["x"][:, 1].copy()
+    eng.close()
+    # parameter sweep (16 barrier settings) and a zero iteration budget
+    from oracle import Scene
+    wl = pkg.workloads.config5(B_base=5, N=30)
+    for max_iter in (None, 0, 3):
+        params = wl.params if max_iter is None else [pkg.copy_params(q, max_iter=max_iter) for q in wl.params]
+        eng = pkg.BatchedCILQR(params, wl.scenes)
+        eng.set_group_mode(2)
+        eng.set_helper_mode(0)
+        out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, trace_cap=128)
+        sc0 = wl.scenes[0]
+        scene = Scene(sc0.lane_x, sc0.lane_y, sc0.lane_yaw, sc0.obs, sc0.road_borders, sc0.ref_velo)
+        refs = [orc_det.solver(params[wl.param_id[b]]).solve(wl.x0[b], scene) for b in range(wl.B)]
+        compare_solves(out, refs, f"pairs, config5 sweep max_iter={max_iter}")
+        eng.close()
+    # both vehicle models in one launch: the lanes of one rollout pass belong to different models
+    cfg, sc = scenarios["three_bend"]
+    pa = pkg.params_from_config(cfg, N=40, use_last_solution=0)
+    pb = pkg.copy_params(pa, reference_point=1 - pa.reference_point, wheelbase=2.5, dt=0.12)
+    eng = pkg.BatchedCILQR([pa, pb], pkg.SceneTable.from_scenario(sc))
+    eng.set_group_mode(2)
+    eng.set_helper_mode(0)
+    B = 30
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 909)
+    pid = (np.arange(B) % 3 == 0).astype(np.int32)
+    out = eng.solve_batch(x0, param_id=pid, trace_cap=128)
+    scene = oracle_scene(sc)
+    refs = [orc_det.solver([pa, pb][pid[b]]).solve(x0[b], scene) for b in range(B)]
+    compare_solves(out, refs, "pairs, two vehicle models in one launch")
+    eng.close()
+
+
+def test_pairs_at_scale_equal_the_single_build(pkg):
+    """8192 three_bend trajectories (BASELINE config 3) through both builds: every output field identical (the oracle
+    comparison of the full batch is test_full_size_configs_bitexact, which runs the automatic choice = pairs)."""
+    wl = pkg.workloads.config3()
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    outs = {}
+    for mode in (0, -1):
+        eng.set_group_mode(mode)
+        outs[mode] = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, trace_cap=64)
+    a, b = outs[0], outs[-1]
+    eq_bits(a["u"], b["u"], "u")
+    eq_bits(a["x"], b["x"], "x")
+    assert (a["res"] == b["res"]).all()
+    for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+        eq_bits(a["trace"][f], b["trace"][f], "trace." + f)
+    eng.close()

@@ -111,6 +111,7 @@ SIGNATURES = {
     "cilqr_get_phase_cycles": (C.c_int, [_P, _P, _I]),
     "cilqr_set_debug_flags": (C.c_int, [_P, _I]),
     "cilqr_set_helper_mode": (C.c_int, [_P, _I]),
+    "cilqr_set_group_mode": (C.c_int, [_P, _I]),
     "cilqr_set_rollout_mode": (C.c_int, [_P, _I]),
     "cilqr_set_work_sharing": (C.c_int, [_P, _I]),
     "cilqr_work_sharing_stats": (C.c_int, [_P, _P]),

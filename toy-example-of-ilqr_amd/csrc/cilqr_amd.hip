@@ -21,6 +21,8 @@
     extern template __global__ void k_solve<DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP> CILQR_SOLVE_SIGNATURE;
 CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
 #undef CILQR_X_EXTERN
+extern template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -347,6 +349,7 @@ struct cilqr_handle {
     DevBuf park, rq;
     int park_B = 0, park_N = 0;
     unsigned last_parked = 0;
+    bool fused_call = false;   // the call in progress is a fused solve (not a piecewise entry point)
     bool looping = false;      // the call in progress is a closed loop in one launch: the plain builds (see the dispatch)
     DevBuf sh_ctl, sh_req, sh_hints;
     int sh_B = 0, sh_N = 0;
@@ -356,6 +359,11 @@ struct cilqr_handle {
     int occ2_min_batch = 1024; // above this (and above the helper range) the 2-waves-per-SIMD build of the solve kernel
                                // is used; it costs line-search trials one per pass (paired passes were measured again
                                // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
+    int prof_two_per_simd = 0; // development library: cycle accounting in the two-per-SIMD headline build (CILQR_TUNE=prof2=1)
+    int group_mode = -1;       // trajectories per wavefront in the large-batch launches of horizons up to 63, barrier mode
+                               // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
+    int win_grp = 0;           // lane window of those launches
+    int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
     int prof_B = 0;
     DevBuf st[16];
     // resident blocks per CU of each persistent build (asked once per kernel and LDS size, not on every launch)
@@ -371,6 +379,7 @@ struct cilqr_handle {
 // Persistent launches use one scratch area per resident block: never more than this many per CU, whatever the
 // occupancy query says (8 = two wavefronts per SIMD; ensure_scratch sizes the areas with the same number)
 #define CILQR_MAX_BLOCKS_PER_CU 8
+#define CILQR_GROUP 2 /* trajectories per wavefront of the grouped builds (k_solve_grp) */
 static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out) {
     for (const auto& e : h->occ)
         if (e.kern == kern && e.shm == shm) { *out = e.per_cu; return CILQR_OK; }
@@ -420,6 +429,15 @@ static void update_window(cilqr_handle* h) {
     h->win_occ = pick(occ_floor);
     fixed = lds_bytes(N, 0, alm, 1, 1);
     h->win_lg = pick(occ_floor);
+    {
+        // the grouped builds: the window shares the expansion's area (cilqr_group.hpp), so it is free up to that size and
+        // otherwise bounded by 8 blocks per CU
+        const long room = (long)(163840 / CILQR_MAX_BLOCKS_PER_CU) - (long)grp_lds_bytes(N, 0, CILQR_GROUP) +
+                          (long)sizeof(double) * grp_expansion_doubles(N);
+        int wg = (int)(room / 16) / 8 * 8;
+        wg = std::max(wg, grp_expansion_doubles(N) / 2 / 8 * 8);
+        h->win_grp = std::max(8, std::min(want, wg));
+    }
 }
 
 // One launch per handle at a time (scratch areas, control words, timeline and staging buffers belong to the launch in
@@ -486,6 +504,9 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "share_backoff") h->share_backoff = v;
                 else if (k == "persistent_blocks") h->persistent_blocks = v;
                 else if (k == "resume_iters") h->resume_iters = v;
+                else if (k == "group") h->group_mode = v;
+                else if (k == "prof2") h->prof_two_per_simd = v;
+                else if (k == "group_steal") h->group_steal = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -659,6 +680,12 @@ extern "C" int cilqr_resume_stats(cilqr_handle* h, uint32_t* parked) {
 extern "C" int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0 or 1");
     h->helper_mode = mode;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_set_group_mode(cilqr_handle* h, int32_t mode) {
+    if (!h || mode < -1 || mode > CILQR_GROUP) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0, 1 or 2");
+    h->group_mode = mode;
     return CILQR_OK;
 }
 
@@ -918,7 +945,8 @@ static bool lone_two_per_simd(const cilqr_handle* h, int B) {
 // Mirrors the dispatch in cilqr_solve_batch_device, which checks the two against each other.
 static bool single_slot(const cilqr_handle* h, int B) {
     const bool alm = h->params[0].solve_type == 1;
-    if (!alm && !h->looping && (h->debug_flags != 0 || h->profiling)) return false;
+    const bool prof2 = h->profiling && h->prof_two_per_simd && h->params[0].N == 50 && h->debug_flags == 0;
+    if (!alm && !h->looping && (h->debug_flags != 0 || (h->profiling && !prof2))) return false;
     return lone_two_per_simd(h, B);
 }
 
@@ -932,6 +960,17 @@ static bool global_expansion(const cilqr_handle* h, int B) {
     // allow (barrier mode: N >= 76; augmented Lagrangian, whose dense l_xx makes the block larger: every horizon
     // above 63): measured +30-40 % at N = 100, +6 % at N = 80, -5 % at N = 64 (barrier) where nothing is gained
     return h->global_expansion == 1 || lds_bytes(N, 64, alm, 1, 0) * 8 > 163840;
+}
+
+// does this batch run the grouped build (k_solve_grp: CILQR_GROUP trajectories per wavefront, one rollout pass for all)?
+// Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
+static bool grouped(const cilqr_handle* h, int B) {
+    if (h->group_mode == 0 || h->group_mode == 1) return false;
+    if (h->params[0].solve_type == 1 || two_rows(h) || h->looping || h->debug_flags != 0) return false;
+    if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
+    if (!h->persistent_blocks) return false;
+    if (h->group_mode >= 2) return true;
+    return lone_two_per_simd(h, B);
 }
 
 static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
@@ -951,8 +990,10 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.tier = h->rollout_mode;
     a.alm = h->params[0].solve_type == 1 ? 1 : 0;
     // the kernel variant built for two wavefronts per SIMD (see the dispatch in cilqr_solve_batch_device)
-    const bool occ2 = lone_two_per_simd(h, B) && (a.alm || a.flags == 0) && !h->profiling;
+    const bool occ2 = lone_two_per_simd(h, B) && (a.alm || a.flags == 0) &&
+                      (!h->profiling || (h->prof_two_per_simd && a.N == 50));
     a.W = occ2 ? (single_slot(h, B) ? (global_expansion(h, B) ? h->win_lg : h->win_occ) : h->win_occ2) : h->win;
+    if (h->fused_call && grouped(h, B)) a.W = h->win_grp;
     a.alm_mu = static_cast<double*>(h->alm_mu.p);
     a.alm_mu_next = static_cast<double*>(h->alm_mu_next.p);
     a.alm_rho = static_cast<double*>(h->alm_rho.p);
@@ -1030,9 +1071,15 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
         if (rc_alm) return rc_alm;
     }
     size_t areas = (size_t)B;
-    if (fused && h->persistent_blocks && lone_two_per_simd(h, B) && (h->params[0].solve_type == 1 || (h->debug_flags == 0 && !h->profiling)))
+    if (fused && h->persistent_blocks && lone_two_per_simd(h, B) &&
+        (h->params[0].solve_type == 1 || (h->debug_flags == 0 && (!h->profiling || (h->prof_two_per_simd && N == 50)))))
         areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
-    if (h->scratch.ensure(sizeof(double) * scratch_doubles(N) * areas))
+    size_t area = scratch_doubles(N);
+    if (fused && grouped(h, B)) { // (persistent blocks: one area per resident block, CILQR_GROUP trajectories in it)
+        area = std::max(area, (size_t)CILQR_GROUP * grp_scratch_doubles(N));
+        areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
+    }
+    if (h->scratch.ensure(sizeof(double) * area * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
     // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
     if (!h->sh_ctl.p) {
@@ -1052,6 +1099,19 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
             return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
         h->park_B = B;
         h->park_N = N;
+    }
+    // the grouped build hands trajectories from wavefronts that hold two to wavefronts that have run dry (cilqr_group.hpp)
+    if (fused && grouped(h, B) && h->group_steal) {
+        const size_t need = sizeof(double) * grp_park_doubles(N) * (size_t)B;
+        if (B > h->park_B || N != h->park_N || !h->park.p || h->park.cap < need || h->rq.cap < sizeof(unsigned long long) * (size_t)B) {
+            int rcw = wait_last_launch(h);
+            if (rcw) return rcw;
+            h->park.release(); h->rq.release();
+            if (h->park.ensure(need) || h->rq.ensure(sizeof(unsigned long long) * (size_t)B))
+                return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
+            h->park_B = B;
+            h->park_N = N;
+        }
     }
     // work sharing between blocks (builds of horizons above 63): one request and one row of hints per trajectory
     if (two_rows(h) && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
@@ -1093,6 +1153,11 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         LoopScope(cilqr_handle* hh, bool on) : h(hh) { h->looping = on; }
         ~LoopScope() { h->looping = false; }
     } loop_scope(h, loop.ticks >= 1);
+    struct FusedScope {
+        cilqr_handle* h;
+        explicit FusedScope(cilqr_handle* hh) : h(hh) { h->fused_call = true; }
+        ~FusedScope() { h->fused_call = false; }
+    } fused_scope(h);
     if (loop.ticks >= 1 && (h->debug_flags != 0 || h->profiling))
         return fail(CILQR_ERR_UNSUPPORTED, "the closed loop has no testing-aid / cycle-accounting builds");
     rc = ensure_scratch(h, B, true);
@@ -1120,7 +1185,30 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         h->tl_B = B;
     }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
-    {
+    if (loop.ticks < 1 && grouped(h, B)) {
+        // CILQR_GROUP trajectories per wavefront, one rollout pass for all of them (cilqr_group.hpp): persistent blocks
+        auto kg = (a.N == 50) ? k_solve_grp<50, CILQR_GROUP> : k_solve_grp<0, CILQR_GROUP>;
+        const size_t shm = grp_lds_bytes(a.N, a.W, CILQR_GROUP);
+        int per_cu = 0;
+        rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
+        if (rc) return rc;
+        const int cap = per_cu * h->num_cus, want = (B + CILQR_GROUP - 1) / CILQR_GROUP;
+        const int grid = want < cap ? want : cap;
+        h->last_launch_shared = false;
+        a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
+        HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+        h->last_launch_reset_ctl = true;
+        if (h->group_steal && h->park.p && h->park_B >= B && h->park_N == a.N) {
+            a.park = static_cast<double*>(h->park.p);
+            a.rq = static_cast<unsigned long long*>(h->rq.p);
+            HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
+            a.rq_cap = h->park_B;
+        }
+        if (h->scratch.cap < sizeof(double) * (size_t)CILQR_GROUP * grp_scratch_doubles(a.N) * (size_t)grid)
+            return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
+        hipLaunchKernelGGL(kg, dim3(grid), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out, d_res_out, d_trace_out,
+                           d_trace_out ? trace_cap : 0);
+    } else {
         const bool two = (a.N + 1 > CILQR_WAVE);
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
         const bool help = wants_helper(h, B);
@@ -1166,6 +1254,12 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         } else if (a.prof) {
             kern = help ? (two ? k_solve<false, 2, false, true, true> : k_solve<false, 1, false, true, true>)
                         : (two ? k_solve<false, 2, false, false, true> : k_solve<false, 1, false, false, true>);
+            if (!help && a.N == 50 && h->prof_two_per_simd && lone_two_per_simd(h, B)) {
+                // the headline build itself with the accounting: persistent blocks, two wavefronts per SIMD
+                kern = k_solve<false, 1, false, false, true, 2, 1, 50>;
+                one = true;
+                persistent = true;
+            }
 #endif
         } else if (help) {
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;

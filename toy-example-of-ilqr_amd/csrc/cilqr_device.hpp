@@ -89,14 +89,16 @@ struct Cst {
 
 // fills the by-value part on every lane and, from lane 0, the LDS part at `ck` (followed by a wave_sync:
 // both wavefronts of a helper-mode block do this, writing identical values)
-__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane);
+// (fill = false: the LDS part is there already — a trajectory of a grouped wavefront coming back for its next segment)
+__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane, bool fill = true);
 
-__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane) {
+__device__ inline void make_cst(Cst& c, const cilqr_params& p, const DevScene& s, int tick, CstK* ck, int lane, bool fill) {
     c.N = p.N; c.rp = p.reference_point; c.M = s.M; c.L = s.L; c.T = s.T; c.tick = tick;
     c.max_iter = p.max_iter; c.pad = 0;
     c.dt = p.dt; c.wb = p.wheelbase; c.half_wb = 0.5 * p.wheelbase;
     c.lane_xy = (gdouble*)s.lane_xy; c.lane_aux = (gdouble*)s.lane_aux; c.obs = (gdouble*)s.obs;
     c.k = ck;
+    if (!fill) return;
     if (lane == 0) {
         CstK k;
         k.w_pos = p.w_pos; k.w_vel = p.w_vel; k.w_yaw = p.w_yaw; k.w_acc = p.w_acc; k.w_stl = p.w_stl;
@@ -284,27 +286,34 @@ __host__ __device__ inline size_t scratch_doubles(int N) {
 // ---------------------------------------------------------------------------------------------
 // ut:262-283 kinematic_propagate
 // TRIG = flavour of the elementary functions (detmath.h: DM_PIN, DM_NOSHORT, DM_SMALL)
+// (dt, wb by value: wave-uniform scalars for the one-trajectory rollouts, per-lane values where the lanes of one pass
+//  belong to different trajectories — rollout_group)
 template <int RP, int TRIG = 0>
-__device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4],
-                                 const DmPinned* pk = nullptr) {
+__device__ inline void propagate_v(const double dt, const double wb, const double x[4], const double u[2], double xn[4],
+                                   const DmPinned* pk = nullptr) {
     if (RP == 0) {
         double sn, cs;
         dm_sincos<TRIG>(x[3], &sn, &cs, pk);
         double tn = dm_tan<TRIG>(u[1], pk);
-        xn[0] = x[0] + x[2] * cs * c.dt;
-        xn[1] = x[1] + x[2] * sn * c.dt;
-        xn[2] = x[2] + u[0] * c.dt;
-        xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
+        xn[0] = x[0] + x[2] * cs * dt;
+        xn[1] = x[1] + x[2] * sn * dt;
+        xn[2] = x[2] + u[0] * dt;
+        xn[3] = x[3] + x[2] * tn * dt / wb;
     } else {
         double beta = dm_atan<TRIG>(dm_tan<TRIG>(u[1], pk) / 2);
         double sn, cs;
         dm_sincos<TRIG>(beta + x[3], &sn, &cs, pk);
         double sb = dm_sin<TRIG>(beta, pk);
-        xn[0] = x[0] + x[2] * cs * c.dt;
-        xn[1] = x[1] + x[2] * sn * c.dt;
-        xn[2] = x[2] + u[0] * c.dt;
-        xn[3] = x[3] + 2 * x[2] * sb * c.dt / c.wb;
+        xn[0] = x[0] + x[2] * cs * dt;
+        xn[1] = x[1] + x[2] * sn * dt;
+        xn[2] = x[2] + u[0] * dt;
+        xn[3] = x[3] + 2 * x[2] * sb * dt / wb;
     }
+}
+template <int RP, int TRIG = 0>
+__device__ inline void propagate(const Cst& c, const double x[4], const double u[2], double xn[4],
+                                 const DmPinned* pk = nullptr) {
+    propagate_v<RP, TRIG>(c.dt, c.wb, x, u, xn, pk);
 }
 
 // The same step for small angles on every active lane, straight-line: all range reductions and
@@ -313,17 +322,17 @@ __device__ inline void propagate(const Cst& c, const double x[4], const double u
 // angle beta + yaw is only known here: returns false, with xn untouched, when it is not small on
 // some lane — the caller then redoes the step the general way.  pk: the pinned coefficients (dm_pin_load).
 template <int RP, int PIN = DM_PIN>
-__device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4],
-                                       const DmPinned* pk) {
+__device__ inline bool propagate_small_v(const double dt, const double wb, const double x[4], const double u[2], double xn[4],
+                                         const DmPinned* pk) {
     constexpr int T = PIN | DM_SMALL;
     if (RP == 0) {
         double sn, cs;
         dm_sincos<T>(x[3], &sn, &cs, pk);
         double tn = dm_tan<T>(u[1], pk);
-        xn[0] = x[0] + x[2] * cs * c.dt;
-        xn[1] = x[1] + x[2] * sn * c.dt;
-        xn[2] = x[2] + u[0] * c.dt;
-        xn[3] = x[3] + x[2] * tn * c.dt / c.wb;
+        xn[0] = x[0] + x[2] * cs * dt;
+        xn[1] = x[1] + x[2] * sn * dt;
+        xn[2] = x[2] + u[0] * dt;
+        xn[3] = x[3] + x[2] * tn * dt / wb;
     } else {
         double beta = dm_atan<T>(dm_tan<T>(u[1], pk) / 2);
         const double ang = beta + x[3];
@@ -331,12 +340,17 @@ __device__ inline bool propagate_small(const Cst& c, const double x[4], const do
         double sn, cs;
         dm_sincos<T>(ang, &sn, &cs, pk);
         double sb = dm_sin<T>(beta, pk);
-        xn[0] = x[0] + x[2] * cs * c.dt;
-        xn[1] = x[1] + x[2] * sn * c.dt;
-        xn[2] = x[2] + u[0] * c.dt;
-        xn[3] = x[3] + 2 * x[2] * sb * c.dt / c.wb;
+        xn[0] = x[0] + x[2] * cs * dt;
+        xn[1] = x[1] + x[2] * sn * dt;
+        xn[2] = x[2] + u[0] * dt;
+        xn[3] = x[3] + 2 * x[2] * sb * dt / wb;
     }
     return true;
+}
+template <int RP, int PIN = DM_PIN>
+__device__ inline bool propagate_small(const Cst& c, const double x[4], const double u[2], double xn[4],
+                                       const DmPinned* pk) {
+    return propagate_small_v<RP, PIN>(c.dt, c.wb, x, u, xn, pk);
 }
 
 // cs:295-311 for row 0 (start_index = 0): all 64 lanes evaluate consecutive candidates.
@@ -2117,9 +2131,12 @@ __device__ inline double gl_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, row_off, 0));
 }
 // ROWD = doubles per row of the expansion in global memory (CILQR_GL_ROW, CILQR_GL_ROW_ALM), 0 = expansion in LDS
-template <int ROWD = 0>
+// GGAIN: the gains go to `gains` in global memory — [N][CILQR_KD] doubles, the layout of Lds::kd — instead of over the
+// step's Jacobians in LDS (the builds that hold several trajectories per wavefront keep one Jacobian array for all of
+// them; the rollout reads the gains back through L1 / L2, one step ahead)
+template <int ROWD = 0, bool GGAIN = false>
 __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
-                                            int* fail_step = nullptr) {
+                                            int* fail_step = nullptr, double* gains = nullptr) {
     constexpr bool LG = ROWD != 0;
     constexpr int GL_CHUNK = LG ? CILQR_WAVE / ROWD : 4; // rows per chunk of 64 doubles
     const int N = c.N;
@@ -2144,6 +2161,8 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         l.xch[CILQR_XCH_CONST + 3] = 0.0;
     }
     wave_sync();
+    __amdgpu_buffer_rsrc_t ggr;
+    if (GGAIN) ggr = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(gains), 0, N * CILQR_KD * (int)sizeof(double), 0x00020000);
     // W = [l_xx[N] | l_x[N]], element (r, c) in the register `wn` of lane 8 r + c (r < 4, c <= 4)
     double wn;
     if (LG) wn = gl_load(grs, (cc < 4) ? goq : gov, N * ROWB);
@@ -2281,10 +2300,16 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         int lanev = lane;
         __asm__("" : "+v"(lanev));
         if (lanev < 5) { // row r' = 0 holds (K | d) column c
-            // over the Jacobians of this step: every lane loaded its coefficients at the top of the step
-            double* kd = l.kd + CILQR_KD * i + lane;
-            kd[0] = kc0;
-            kd[CILQR_KD_ROW] = kc1;
+            if (GGAIN) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc0), ggr, 8u * (unsigned)lane, i * (CILQR_KD * 8), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc1), ggr, 8u * (unsigned)lane + 8u * CILQR_KD_ROW,
+                                                      i * (CILQR_KD * 8), 0);
+            } else {
+                // over the Jacobians of this step: every lane loaded its coefficients at the top of the step
+                double* kd = l.kd + CILQR_KD * i + lane;
+                kd[0] = kc0;
+                kd[CILQR_KD_ROW] = kc1;
+            }
         }
         // expected cost reduction (cs:435-436): delta_V[0] += (0.5 d)^T Q_uu d on lane 36, delta_V[1] += d^T Q_u on lane 44
         int rpv = rp;

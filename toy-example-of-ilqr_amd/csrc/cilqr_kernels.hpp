@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cilqr_device.hpp"
+#include "cilqr_group.hpp"
 
 using namespace cilqr;
 
@@ -84,12 +85,12 @@ enum { PH_INIT = 0, PH_DERIV = 1, PH_BACKWARD = 2, PH_ROLLOUT = 3, PH_TRIAL_COST
     } while (0)
 
 template <bool LOOP = false>
-__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l, int lane) {
+__device__ inline void load_cst(Cst& c, const BatchArgs& a, int b, const Lds& l, int lane, bool fill = true) {
     int pid = a.param_id ? a.param_id[b] : 0;
     int sid = a.scenario_id ? a.scenario_id[b] : 0;
     int tk = a.tick ? a.tick[b] : 0;
     if (LOOP) tk = uniform_int((int)sh_ld(reinterpret_cast<const unsigned*>(a.loop_tick + b))); // (advanced inside this launch)
-    make_cst(c, a.params[pid], a.scenes[sid], tk, l.ck, lane);
+    make_cst(c, a.params[pid], a.scenes[sid], tk, l.ck, lane, fill);
 }
 
 // The device-pointer entry point cannot check its index arrays on the host.  A trajectory whose ids point
@@ -739,6 +740,337 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_solve_grp: the solve for large batches of horizons up to 63, barrier mode — G trajectories per wavefront, one rollout
+// pass for all of them (cilqr_group.hpp).  Persistent blocks pulling trajectories from a.next, like k_solve's.
+// Every trajectory runs CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381) through the same device functions as in
+// solve_one, cut into segments at the two points where its line search needs a rollout pass:
+//   GP_ITER   -> expansion, backward sweep; gains to global memory; ask for the first trial alone (or all 20 step sizes
+//                when the previous search went deep) and yield                                   [phase GP_SEARCH, t0 = 0]
+//   GP_SEARCH -> cost trials t0, t0 + 1, ... in order; first trial rejected and only it rolled out: ask for all 20 and
+//                yield [t0 = 1]; verdict reached or all 20 rejected: back in solve (cs:113-141), then GP_ITER or done
+// A trajectory that ends is replaced at once (pull, initial trajectory, first expansion) inside the same segment.
+template <int NC, int G>
+__global__ void __launch_bounds__(CILQR_WAVE, 2)
+k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, double* u_out, double* __restrict__ x_out,
+            cilqr_result* __restrict__ res_out, cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
+    const int lane = threadIdx.x & (CILQR_WAVE - 1);
+    const int N = NC ? NC : a.N;
+    double* const scr_blk = a.scratch + (size_t)blockIdx.x * G * grp_scratch_doubles(N);
+    if (lane < G) {
+        GrpSt* st = grp_state(g_lds, N, lane);
+        st->phase = GP_EMPTY;
+        st->req = 0;
+    }
+    wave_sync();
+    bool fresh_left = true;
+    const bool steal = a.park != nullptr; // the tail of the launch: idle wavefronts take over trajectories of wavefronts that hold two
+    AlmSt al;
+    al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    for (;;) {
+        int n_live = 0;
+        for (int g = 0; g < G; ++g) {
+            Lds l;
+            carve_group(l, g_lds, N, G, g);
+            GrpSt* const st = grp_state(g_lds, N, g);
+            int phase = uniform_int(st->phase);
+            if (phase == GP_DONE) continue;
+            double* const scr = scr_blk + (size_t)g * grp_scratch_doubles(N);
+            double* const first = scr + slab_doubles(N);
+            double* const gains = first + (size_t)CILQR_TRIAL_ROWS * (N + 1);
+            long long* const pacc = grp_prof(g_lds, N, g);
+            const bool prof = CILQR_GPROF && a.prof != nullptr;
+            long long t_ph = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define GPROF_ADD(ph)                                                        \
+    do {                                                                     \
+        if (prof) {                                                          \
+            const long long t_now_ = (long long)__builtin_readcyclecounter(); \
+            if (lane == 0) { pacc[ph] += t_now_ - t_ph; pacc[PH_TOTAL] += t_now_ - t_ph; } \
+            t_ph = t_now_;                                                   \
+        }                                                                    \
+    } while (0)
+            Cst c;
+            int b = 0, idx0 = 0, status = CILQR_RUNNING, iters = 0, ls_trials = 0, cost_evals = 0, tl = 0, flag = 0, t0 = 0, trials = 0;
+            bool deep_next = false, have_all = false;
+            double J_cur = 0.0, J_init = 0.0, lamb = 0.0, new_J = 0.0, dV[2] = {0.0, 0.0};
+            long long tl_start = 0;
+            bool resume = (phase == GP_SEARCH);
+            // is a wavefront waiting for work?  (asked here, needed when this trajectory is back in solve: the answer's
+            // latency is hidden; only a wavefront that holds two trajectories will act on it)
+            unsigned waiting_probe = 0;
+            if (steal && lane == 0) waiting_probe = sh_ld(a.ctl + SH_HELPING);
+            if (phase == GP_STOLEN) {
+                // a trajectory another wavefront parked between two iterations: its x, u, lane indices and scalars
+                b = uniform_int(st->b);
+                if (prof) {
+                    for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) pacc[e] = 0; // (its cycles so far stay behind)
+                    wave_sync();
+                }
+                grp_park_copy(a.park + (size_t)b * grp_park_doubles(N), l.x, l.u, l.ridx, st, N, lane, 0);
+                idx0 = uniform_int(st->idx0);
+                status = uniform_int(st->status); iters = uniform_int(st->iters); ls_trials = uniform_int(st->ls_trials);
+                cost_evals = uniform_int(st->cost_evals); tl = uniform_int(st->tl); flag = uniform_int(st->flag);
+                deep_next = uniform_int(st->deep_next) != 0;
+                J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb;
+                tl_start = st->tl_start;
+                load_cst(c, a, b, l, lane); // (fills this slot's copy of the cost model's constants)
+                if (NC) c.N = NC;
+                if (lane == 0) { *grp_cst(g_lds, N, g) = c; st->b = b; st->req = 0; }
+                seed_trial_indices(l, N, 1, lane);
+                phase = GP_ITER;
+                GPROF_ADD(PH_TC_REF);
+            } else if (phase != GP_EMPTY) {
+                b = uniform_int(st->b);
+                idx0 = uniform_int(st->idx0);
+                status = uniform_int(st->status); iters = uniform_int(st->iters); ls_trials = uniform_int(st->ls_trials);
+                cost_evals = uniform_int(st->cost_evals); tl = uniform_int(st->tl); flag = uniform_int(st->flag);
+                t0 = uniform_int(st->t0); trials = uniform_int(st->trials);
+                deep_next = uniform_int(st->deep_next) != 0; have_all = uniform_int(st->have_all) != 0;
+                J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb; new_J = st->new_J; dV[0] = st->dV0; dV[1] = st->dV1;
+                tl_start = st->tl_start;
+                load_cst_lds(c, grp_cst(g_lds, N, g));
+                stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
+                GPROF_ADD(PH_TC_REF); // (grouped build: slot 10 = the segment's set-up — state, constants, lane window)
+            }
+            for (;;) {
+                int alpha_idx = -1;
+                if (!resume) {
+                    if (phase == GP_EMPTY) {
+                        unsigned nb = (unsigned)a.B;
+                        if (fresh_left) nb = sh_add_u(a.next, 1u, lane);
+                        if (nb >= (unsigned)a.B) { fresh_left = false; phase = GP_DONE; break; }
+                        b = (int)nb;
+                        if (prof) {
+                            for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) pacc[e] = 0;
+                            wave_sync();
+                            t_ph = (long long)__builtin_readcyclecounter();
+                        }
+                        tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+                        if (!ids_valid(a, b)) { // as in solve_one: NaN outputs, CILQR_END_BAD_INPUT; the slot takes the next trajectory
+                            const double qnan = dm_from_bits(0x7ff8000000000000ULL);
+                            for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = qnan;
+                            for (int e = lane; e < 2 * N; e += CILQR_WAVE) u_out[(size_t)b * 2 * N + e] = qnan;
+                            if (lane == 0 && res_out) {
+                                cilqr_result r;
+                                r.J_init = qnan; r.J_final = qnan; r.iters = 0; r.end_reason = CILQR_END_BAD_INPUT;
+                                r.final_status = CILQR_RUNNING; r.ls_trials = 0; r.cost_evals = 0; r.trace_len = 0;
+                                res_out[b] = r;
+                            }
+                            if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
+                            continue;
+                        }
+                        load_cst(c, a, b, l, lane);
+                        if (NC) c.N = NC;
+                        if (lane == 0) { st->dt = c.dt; st->wb = c.wb; st->rp = c.rp; st->nfb = 0; *grp_cst(g_lds, N, g) = c; }
+                        lds_sync();
+                        J_cur = grp_init<NC, G>(g_lds, g, N, lane, x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3],
+                                                last_u ? last_u + (size_t)b * N * 2 : nullptr, a.W);
+                        idx0 = uniform_int(st->idx0);
+                        J_init = J_cur;
+                        lamb = c.k->init_lamb;
+                        status = CILQR_RUNNING;
+                        iters = 0; ls_trials = 0; cost_evals = 1; tl = 0; flag = 0;
+                        deep_next = false;
+                        phase = GP_ITER;
+                        GPROF_ADD(PH_INIT);
+                    }
+                    if (iters < c.max_iter) {
+                        // ---- iter_step ----
+                        cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
+                        if (prof) { GPROF_ADD(PH_TC_STAGE); }
+                        const bool ok = grp_expand_backward<NC, G>(g_lds, g, N, lane, lamb, gains, prof ? pacc : nullptr);
+                        if (prof) t_ph = (long long)__builtin_readcyclecounter(); // (booked inside)
+                        status = CILQR_RUNNING;
+                        dV[0] = st->dV0;
+                        dV[1] = st->dV1;
+                        new_J = J_cur;
+                        trials = 0;
+                        if (ok) {
+                            flag = 0;
+                            have_all = (a.tier == 0) || (a.tier < 0 && deep_next);
+                            t0 = 0;
+                            if (lane == 0) st->req = have_all ? 2 : 1;
+                            phase = GP_SEARCH;
+                            break; // until the pass has run
+                        }
+                        status = CILQR_BACKWARD_PASS_FAIL;
+                    }
+                } else {
+                    resume = false;
+                    // ---- the line search of cs:354-372, from trial t0 on ----
+                    bool done = false, again = false;
+                    while (t0 < CILQR_MAX_ALPHA_TRIALS && !done) {
+                        if (t0 == 1 && !have_all) { // the first trial was rejected and only it exists: all step sizes, next pass
+                            have_all = true;
+                            again = true;
+                            break;
+                        }
+                        const double* src = have_all ? scr : first;
+                        const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
+                        new_J = grp_cost_trial<NC, G>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
+                        GPROF_ADD(PH_TRIAL_COST);
+                        trials++;
+                        const int verdict = trial_verdict(J_cur, new_J, t0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
+                        if (verdict == 1) {
+                            status = CILQR_CONVERGED;
+                            alpha_idx = t0;
+                            done = true;
+                        } else if (verdict == 2) {
+                            if (t0 != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
+                            flag = 1;
+                            alpha_idx = t0;
+                            accept_trial(c, l, src, t0, 0, lane, as);
+                            GPROF_ADD(PH_ACCEPT);
+                            J_cur = new_J;
+                            done = true;
+                        }
+                        t0 += 1;
+                    }
+                    if (again) {
+                        if (lane == 0) st->req = 2;
+                        break; // phase stays GP_SEARCH, t0 = 1
+                    }
+                    deep_next = (trials > 1);
+                    if (!done) status = CILQR_FORWARD_PASS_FAIL;
+                }
+                bool leave = true; // (max_iter reached before the first iteration: nothing below applies)
+                if (iters < c.max_iter) {
+                    // ---- back in solve (cs:113-141) ----
+                    iters++;
+                    ls_trials += trials;
+                    cost_evals += trials;
+                    if (status == CILQR_BACKWARD_PASS_FAIL || status == CILQR_FORWARD_PASS_FAIL) {
+                        double la = lamb * c.k->lamb_amplify;
+                        lamb = (c.k->lamb_amplify < la) ? la : c.k->lamb_amplify;
+                    } else if (status == CILQR_RUNNING) {
+                        lamb *= c.k->lamb_decay;
+                    }
+                    if (trace_out && tl < trace_cap && lane == 0) {
+                        cilqr_trace_rec r;
+                        r.status = status; r.trials = trials; r.accepted = flag; r.alpha_idx = alpha_idx;
+                        r.lamb = lamb; r.new_J = new_J;
+                        trace_out[(size_t)b * trace_cap + tl] = r;
+                    }
+                    tl++;
+                    leave = false;
+                }
+                int end_reason = CILQR_END_MAX_ITER;
+                if (!leave) {
+                    if (lamb > c.k->max_lamb) { end_reason = CILQR_END_MAX_LAMB; leave = true; }
+                    else if (status == CILQR_CONVERGED) { end_reason = CILQR_END_CONVERGED; leave = true; }
+                    else if (iters >= c.max_iter) leave = true;
+                }
+                GPROF_ADD(PH_TC_STAGE); // (slot 11 = back in solve: counters, lambda schedule, trace record)
+                if (!leave) {
+                    phase = GP_ITER;
+                    if (steal && __builtin_amdgcn_readfirstlane((int)waiting_probe) != 0) {
+                        // somebody is waiting for work and this wavefront holds another live trajectory: hand this one over
+                        bool other = false;
+                        for (int h = 0; h < G; ++h)
+                            if (h != g && uniform_int(grp_state(g_lds, N, h)->phase) == GP_SEARCH) other = true;
+                        if (other && grp_take_ticket(a.ctl, lane)) {
+                            if (lane == 0) {
+                                st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
+                                st->cost_evals = cost_evals; st->tl = tl; st->flag = flag;
+                                st->deep_next = deep_next ? 1 : 0;
+                                st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->tl_start = tl_start;
+                            }
+                            lds_sync();
+                            grp_park_copy(a.park + (size_t)b * grp_park_doubles(N), l.x, l.u, l.ridx, st, N, lane, 1);
+                            rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
+                            phase = GP_DONE; // (the counter is dry — or somebody would not be waiting: nothing to pull)
+                            break;
+                        }
+                        waiting_probe = 0; // (asked once per segment)
+                    }
+                    continue;
+                }
+                // results: u, x of the last accepted trajectory
+                for (int k = lane; k <= N; k += CILQR_WAVE) {
+                    double* xo = x_out + ((size_t)b * (N + 1) + k) * 4;
+                    xo[0] = l.x[4 * k]; xo[1] = l.x[4 * k + 1]; xo[2] = l.x[4 * k + 2]; xo[3] = l.x[4 * k + 3];
+                    if (k < N) {
+                        double* uo = u_out + ((size_t)b * N + k) * 2;
+                        uo[0] = l.u[2 * k]; uo[1] = l.u[2 * k + 1];
+                    }
+                }
+                if (prof) {
+                    GPROF_ADD(PH_ACCEPT);
+                    if (lane == 0) {
+                        pacc[PH_ITERS] = iters; pacc[PH_REF_FALLBACKS] = st->nfb; pacc[PH_TRIALS] = ls_trials;
+                        for (int e = 0; e < CILQR_PROF_SLOTS; ++e) a.prof[(size_t)b * CILQR_PROF_SLOTS + e] = pacc[e];
+                    }
+                }
+                if (lane == 0 && res_out) {
+                    cilqr_result r;
+                    r.J_init = J_init; r.J_final = J_cur; r.iters = iters; r.end_reason = end_reason;
+                    r.final_status = status; r.ls_trials = ls_trials; r.cost_evals = cost_evals;
+                    r.trace_len = (trace_out && tl > trace_cap) ? trace_cap : tl;
+                    res_out[b] = r;
+                }
+                if (a.timeline && lane == 0) {
+                    long long* tl_rec = a.timeline + 4 * (size_t)b;
+                    tl_rec[0] = tl_start;
+                    tl_rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
+                    tl_rec[2] = blockIdx.x;
+                    tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf;
+                }
+                wave_sync(); // (x, u are read before the slot's next trajectory overwrites them)
+                if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
+                phase = GP_EMPTY;
+            }
+            // what the trajectory carries to its next segment
+            if (lane == 0) {
+                st->phase = phase;
+                if (phase == GP_SEARCH) {
+                    st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
+                    st->cost_evals = cost_evals; st->tl = tl; st->flag = flag; st->t0 = t0; st->trials = trials;
+                    st->deep_next = deep_next ? 1 : 0; st->have_all = have_all ? 1 : 0;
+                    st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->new_J = new_J; st->dV0 = dV[0]; st->dV1 = dV[1];
+                    st->tl_start = tl_start;
+                }
+            }
+            lds_sync(); // (not wave_sync: the sweep's gain stores may still be in flight; rollout_group waits for them)
+            GPROF_ADD(PH_TC_SUM); // (slot 12 = parking the state)
+#undef GPROF_ADD
+            if (phase == GP_SEARCH) n_live++;
+        }
+        if (n_live == 0) {
+            if (!steal) break;
+            const int pb = grp_wait_for_work(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)a.B, lane);
+            if (pb < 0) break;
+            if (lane == 0) { GrpSt* st0 = grp_state(g_lds, N, 0); st0->b = pb; st0->phase = GP_STOLEN; st0->req = 0; }
+            lds_sync();
+            continue;
+        }
+        // one rollout pass for every trajectory that asked (the polynomial coefficients as scalar-register literals: the
+        // flavour the two-per-SIMD builds of k_solve measured best with)
+        if (CILQR_GPROF && a.prof) {
+            // the pass's cycles, shared out among the trajectories it served
+            int reqs[G], n_req = 0;
+            for (int g = 0; g < G; ++g) { reqs[g] = uniform_int(grp_state(g_lds, N, g)->req); n_req += reqs[g] != 0; }
+            const long long t0_ = (long long)__builtin_readcyclecounter();
+            rollout_group<G, 0>(g_lds, scr_blk, N, lane);
+            const long long dt_ = ((long long)__builtin_readcyclecounter() - t0_) / (n_req > 0 ? n_req : 1);
+            if (lane == 0)
+                for (int g = 0; g < G; ++g)
+                    if (reqs[g]) {
+                        long long* pa = grp_prof(g_lds, N, g);
+                        pa[PH_ROLLOUT] += dt_; pa[PH_TOTAL] += dt_;
+                        pa[reqs[g] == 1 ? PH_ROLL_FIRST : (uniform_int(grp_state(g_lds, N, g)->t0) == 1 ? PH_ROLL_SECOND : PH_ROLL_ALL)] += 1;
+                    }
+            wave_sync();
+        } else {
+            rollout_group<G, 0>(g_lds, scr_blk, N, lane);
+        }
+    }
+}
+
+#define CILQR_GRP_SIGNATURE                                                                                  \
+    (BatchArgs, const double* __restrict__, const double*, double*, double* __restrict__, cilqr_result* __restrict__, \
+     cilqr_trace_rec* __restrict__, int)
+
 // ------------------------------------------------------------------------------------------------
 // The builds of k_solve the library carries: X(group, DBG, NCH, ALM, HELP, PROF, WPS, NTP, NC, LG, SHARE, RES, LOOP).
 // `group` = which compilation of cilqr_solve_inst.hip instantiates it (toy-example-of-ilqr_amd/build.py runs the
@@ -788,7 +1120,9 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
     X(5, false, 1, false, true, true, 1, CILQR_NT, 0, false, false, false, false)             \
     X(6, false, 2, false, true, true, 1, CILQR_NT, 0, false, false, false, false)             \
     X(7, false, 1, false, false, true, 1, CILQR_NT, 0, false, false, false, false)            \
-    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false, false, false)
+    X(7, false, 2, false, false, true, 1, CILQR_NT, 0, false, false, false, false)            \
+    /* the headline build with the cycle accounting: two wavefronts per SIMD, as it runs (the others account at one) */ \
+    X(4, false, 1, false, false, true, 2, 1, 50, false, false, false, false)
 #else
 #define CILQR_SOLVE_VARIANTS_DEV(X)
 #endif

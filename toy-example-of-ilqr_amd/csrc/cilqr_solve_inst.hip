@@ -46,3 +46,10 @@
 #error "CILQR_INST_GROUP out of range"
 #endif
 CILQR_SOLVE_VARIANTS(CILQR_X_INST)
+
+// the grouped builds (k_solve_grp: G trajectories per wavefront), spread over the lighter groups
+#if CILQR_INST_GROUP == 6
+template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 7
+template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
+#endif

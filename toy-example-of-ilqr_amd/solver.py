@@ -180,6 +180,10 @@ class BatchedCILQR:
         """-1 automatic, 0 one wavefront per trajectory, 1 main + helper wavefront"""
         self._check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
 
+    def set_group_mode(self, mode):
+        """-1 automatic, 0 / 1 one trajectory per wavefront, 2 two per wavefront wherever that build can run"""
+        self._check(self._lib.cilqr_set_group_mode(self._h, int(mode)), "cilqr_set_group_mode")
+
     def set_rollout_mode(self, mode):
         """-1 adaptive, 0 all 20 step sizes in one rollout pass, 1 the first trial alone first"""
         self._check(self._lib.cilqr_set_rollout_mode(self._h, int(mode)), "cilqr_set_rollout_mode")
