@@ -813,6 +813,14 @@ def test_block_timeline_of_persistent_blocks(pkg):
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
     ref = eng.solve_batch(wl.x0)
     eng.set_block_timeline(True)
+    # the grouped build first (round 4: two trajectories per wavefront): a record per trajectory, the block that FINISHED it
+    # (a trajectory may change wavefronts at the launch's tail), never more than two of a block's trajectories at a time
+    pairs = eng.solve_batch(wl.x0)
+    tlp = eng.block_timeline(wl.B)
+    eq_bits(ref["x"], pairs["x"], "x with the timeline on (pairs)")
+    assert (tlp[:, 1] > tlp[:, 0]).all() and (tlp[:, 0] > 0).all() and tlp[:, 2].max() < 2048
+    assert len(np.unique(tlp[:, 2])) <= 2048 and np.bincount(tlp[:, 2].astype(np.int64)).max() >= 2
+    eng.set_group_mode(0)  # one trajectory per wavefront: the persistent blocks of k_solve
     out = eng.solve_batch(wl.x0)
     tl = eng.block_timeline(wl.B)
     small = eng.solve_batch(wl.x0[:300])
@@ -1397,6 +1405,9 @@ def test_resumable_solves_are_transparent(pkg, orc_det):
     for iters, share in ((8, 1), (32, 1), (5, 0), (100000, 1)):
         eng.set_resume_iters(iters)
         eng.set_work_sharing(share)
+        # (without work sharing a batch of this size and horizon would get helper wavefronts, which do not slice their
+        #  solves: lone wavefronts asked for — round 3 passed this case on the stale counter of the launch before)
+        eng.set_helper_mode(-1 if share else 0)
         out = eng.solve_batch(wl.x0, *ids, trace_cap=128)
         parked = eng.resume_stats()
         for k in ("u", "x"):
