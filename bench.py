@@ -619,7 +619,8 @@ def main():
                 "iterations_per_launch_rank0": float(res_s["iters"].sum()),
                 "slowest_trajectory_iterations": int(res_s["iters"].max()),
                 "converged": int(st_s[2]), "max_lamb": int(st_s[3]), "max_iter": int(st_s[4]), "nan_costs": int(st_s[6]),
-                "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "note": note}
+                "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "fp64_useful": rl["fp64_useful"],
+                "note": note}
 
     def closed_loop_extra():
         cl = closed_loop_run(pkg, torch, local_rank, rank, barrier)
@@ -664,7 +665,8 @@ def main():
                          "first ranks' shards)", cpu_check_rows=512)
         closed = guarded(closed_loop_extra)
         alm5 = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm (cs:88-93, 253-261, "
-                       "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True)
+                       "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True,
+                       cpu_check_rows=1024)
 
     if rank == 0:
         my_iters = float(res["iters"].sum())

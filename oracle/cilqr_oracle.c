@@ -39,6 +39,21 @@ int orc_math_mode(void) { return 0; }
 
 #define ORC_EPS 1e-5 /* include/utils.hpp:28 */
 
+/* The FUSED flavour (round 4, an experiment the review of round 3 asked for: what does bit-identity with an unfused
+ * reference cost, and what would an explicitly fused contract inside north_star's 1e-5 buy?).  -DORC_FUSED turns the
+ * multiply-adds of four NAMED groups of sites into explicit fma() — the same sites, in the same association, carry
+ * CQ_MADD in csrc/cilqr_device.hpp (-DCILQR_FUSED), so the device stays bit-identical to THIS build:
+ *   F1 the quadratic forms of get_total_cost (cs:211-212), F2 every product of backward_pass (cs:400-436),
+ *   F3 forward_pass's K dx and + alpha d (cs:452-455), F4 the affine updates of kinematic_propagate (ut:266-281).
+ * Everything else — barrier terms, cost derivatives, geometry, the elementary functions — is untouched. */
+#ifdef ORC_FUSED
+#define CQ_MADD(a, b, c) __builtin_fma((a), (b), (c))
+int orc_fused(void) { return 1; }
+#else
+#define CQ_MADD(a, b, c) ((a) * (b) + (c))
+int orc_fused(void) { return 0; }
+#endif
+
 double orc_m_exp(double x) { return M_EXP(x); }
 double orc_m_sin(double x) { return M_SIN(x); }
 double orc_m_cos(double x) { return M_COS(x); }
@@ -87,6 +102,19 @@ static void matmul(const double* A, const double* B, double* C, int m, int k, in
     }
 }
 
+/* the same product with the accumulation written as CQ_MADD: the sites F1-F3 (identical to matmul unless ORC_FUSED) */
+static void matmul_f(const double* A, const double* B, double* C, int m, int k, int n) {
+    for (int i = 0; i < m; ++i) {
+        for (int j = 0; j < n; ++j) {
+            double acc = A[i * k] * B[j];
+            for (int t = 1; t < k; ++t) {
+                acc = CQ_MADD(A[i * k + t], B[t * n + j], acc);
+            }
+            C[i * n + j] = acc;
+        }
+    }
+}
+
 static void transpose(const double* A, double* At, int m, int n) {
     for (int i = 0; i < m; ++i) {
         for (int j = 0; j < n; ++j) {
@@ -102,16 +130,16 @@ static int sign_of(double v) { return (v < 0) ? -1 : 1; }
 void orc_kinematic_propagate(const double x[4], const double u[2], double dt, double wheelbase,
                              int32_t reference_point, double out[4]) {
     if (reference_point == 0) { /* RearCenter */
-        double n0 = x[0] + x[2] * M_COS(x[3]) * dt;
-        double n1 = x[1] + x[2] * M_SIN(x[3]) * dt;
-        double n2 = x[2] + u[0] * dt;
+        double n0 = CQ_MADD(x[2] * M_COS(x[3]), dt, x[0]);
+        double n1 = CQ_MADD(x[2] * M_SIN(x[3]), dt, x[1]);
+        double n2 = CQ_MADD(u[0], dt, x[2]);
         double n3 = x[3] + x[2] * M_TAN(u[1]) * dt / wheelbase;
         out[0] = n0; out[1] = n1; out[2] = n2; out[3] = n3;
     } else { /* GravityCenter */
         double beta = M_ATAN(M_TAN(u[1]) / 2);
-        double n0 = x[0] + x[2] * M_COS(beta + x[3]) * dt;
-        double n1 = x[1] + x[2] * M_SIN(beta + x[3]) * dt;
-        double n2 = x[2] + u[0] * dt;
+        double n0 = CQ_MADD(x[2] * M_COS(beta + x[3]), dt, x[0]);
+        double n1 = CQ_MADD(x[2] * M_SIN(beta + x[3]), dt, x[1]);
+        double n2 = CQ_MADD(u[0], dt, x[2]);
         double n3 = x[3] + 2 * x[2] * M_SIN(beta) * dt / wheelbase;
         out[0] = n0; out[1] = n1; out[2] = n2; out[3] = n3;
     }
@@ -358,15 +386,15 @@ double orc_total_cost(orc_solver* s, const double* u, const double* x, const orc
         double e[4] = {x[k * 4 + 0] - ref[k * 3 + 0], x[k * 4 + 1] - ref[k * 3 + 1],
                        x[k * 4 + 2] - sc->ref_velo, x[k * 4 + 3] - ref[k * 3 + 2]};
         double t[4], dk;
-        matmul(e, W, t, 1, 4, 4);
-        matmul(t, e, &dk, 1, 4, 1);
+        matmul_f(e, W, t, 1, 4, 4);
+        matmul_f(t, e, &dk, 1, 4, 1);
         states_devt = (k == 0) ? dk : (states_devt + dk);
     }
     double ctrl_energy = 0.0;
     for (int k = 0; k < N; ++k) {
         double t[2], dk;
-        matmul(u + k * 2, R, t, 1, 2, 2);
-        matmul(t, u + k * 2, &dk, 1, 2, 1);
+        matmul_f(u + k * 2, R, t, 1, 2, 2);
+        matmul_f(t, u + k * 2, &dk, 1, 2, 1);
         ctrl_energy = (k == 0) ? dk : (ctrl_energy + dk);
     }
     double J_prime = states_devt + ctrl_energy;
@@ -624,20 +652,20 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
         double tmp4[4], tmp2[2], AtV[16], BtV[8], prod16[16], prod4[4], prod8[8];
         double Q_x[4], Q_u[2], Q_xx[16], Q_uu[4], Q_ux[8];
 
-        matmul(At, V_x, tmp4, 4, 4, 1);
+        matmul_f(At, V_x, tmp4, 4, 4, 1);
         for (int e = 0; e < 4; ++e) Q_x[e] = s->l_x[i * 4 + e] + tmp4[e];
-        matmul(Bt, V_x, tmp2, 2, 4, 1);
+        matmul_f(Bt, V_x, tmp2, 2, 4, 1);
         for (int e = 0; e < 2; ++e) Q_u[e] = s->l_u[i * 2 + e] + tmp2[e];
-        matmul(At, V_xx, AtV, 4, 4, 4);
-        matmul(AtV, A, prod16, 4, 4, 4);
+        matmul_f(At, V_xx, AtV, 4, 4, 4);
+        matmul_f(AtV, A, prod16, 4, 4, 4);
         for (int e = 0; e < 16; ++e) Q_xx[e] = s->l_xx[i * 16 + e] + prod16[e];
-        matmul(Bt, V_xx, BtV, 2, 4, 4);
-        matmul(BtV, B, prod4, 2, 4, 2);
+        matmul_f(Bt, V_xx, BtV, 2, 4, 4);
+        matmul_f(BtV, B, prod4, 2, 4, 2);
         for (int e = 0; e < 4; ++e) {
             double lam_e = (e == 0 || e == 3) ? lamb * 1.0 : lamb * 0.0;
             Q_uu[e] = (s->l_uu[i * 4 + e] + prod4[e]) + lam_e;
         }
-        matmul(BtV, A, prod8, 2, 4, 4);
+        matmul_f(BtV, A, prod8, 2, 4, 4);
         for (int e = 0; e < 8; ++e) Q_ux[e] = 0.0 + prod8[e]; /* l_ux is zero (cs:79-80) */
 
         /* Eigen::LLT on the lower triangle (cs:415-420): fails iff a pivot is <= 0 */
@@ -676,29 +704,29 @@ static int backward_pass(orc_solver* s, const double* u, const double* x, double
 
         double* d_i = d + i * 2;
         double* K_i = K + i * 8; /* 2x4 */
-        matmul(neg_inv, Q_u, d_i, 2, 2, 1);
-        matmul(neg_inv, Q_ux, K_i, 2, 2, 4);
+        matmul_f(neg_inv, Q_u, d_i, 2, 2, 1);
+        matmul_f(neg_inv, Q_ux, K_i, 2, 2, 4);
 
         /* cs:427-432 value function update */
         double Kt[8], Quxt[8], KtQuu[8], t4a[4], t4b[4], t4c[4], t16a[16], t16b[16], t16c[16];
         transpose(K_i, Kt, 2, 4);    /* 4x2 */
         transpose(Q_ux, Quxt, 2, 4); /* 4x2 */
-        matmul(Kt, Q_uu, KtQuu, 4, 2, 2);
-        matmul(KtQuu, d_i, t4a, 4, 2, 1);
-        matmul(Kt, Q_u, t4b, 4, 2, 1);
-        matmul(Quxt, d_i, t4c, 4, 2, 1);
+        matmul_f(Kt, Q_uu, KtQuu, 4, 2, 2);
+        matmul_f(KtQuu, d_i, t4a, 4, 2, 1);
+        matmul_f(Kt, Q_u, t4b, 4, 2, 1);
+        matmul_f(Quxt, d_i, t4c, 4, 2, 1);
         for (int e = 0; e < 4; ++e) V_x[e] = ((Q_x[e] + t4a[e]) + t4b[e]) + t4c[e];
-        matmul(KtQuu, K_i, t16a, 4, 2, 4);
-        matmul(Kt, Q_ux, t16b, 4, 2, 4);
-        matmul(Quxt, K_i, t16c, 4, 2, 4);
+        matmul_f(KtQuu, K_i, t16a, 4, 2, 4);
+        matmul_f(Kt, Q_ux, t16b, 4, 2, 4);
+        matmul_f(Quxt, K_i, t16c, 4, 2, 4);
         for (int e = 0; e < 16; ++e) V_xx[e] = ((Q_xx[e] + t16a[e]) + t16b[e]) + t16c[e];
 
         /* cs:435-436 expected cost reduction */
         double hd[2] = {0.5 * d_i[0], 0.5 * d_i[1]};
         double hdQ[2], q0, q1;
-        matmul(hd, Q_uu, hdQ, 1, 2, 2);
-        matmul(hdQ, d_i, &q0, 1, 2, 1);
-        matmul(d_i, Q_u, &q1, 1, 2, 1);
+        matmul_f(hd, Q_uu, hdQ, 1, 2, 2);
+        matmul_f(hdQ, d_i, &q0, 1, 2, 1);
+        matmul_f(d_i, Q_u, &q1, 1, 2, 1);
         delta_V[0] += q0;
         delta_V[1] += q1;
     }
@@ -719,8 +747,8 @@ void orc_forward_pass(const orc_params* p, const double* u, const double* x, con
     for (int i = 0; i < N; ++i) {
         double dx[4], Kdx[2];
         for (int e = 0; e < 4; ++e) dx[e] = new_x[i * 4 + e] - x[i * 4 + e];
-        matmul(K + i * 8, dx, Kdx, 2, 4, 1);
-        for (int e = 0; e < 2; ++e) new_u[i * 2 + e] = (u[i * 2 + e] + Kdx[e]) + alpha * d[i * 2 + e];
+        matmul_f(K + i * 8, dx, Kdx, 2, 4, 1);
+        for (int e = 0; e < 2; ++e) new_u[i * 2 + e] = CQ_MADD(alpha, d[i * 2 + e], u[i * 2 + e] + Kdx[e]);
         orc_kinematic_propagate(new_x + i * 4, new_u + i * 2, p->dt, p->wheelbase, p->reference_point,
                                 new_x + (i + 1) * 4);
     }

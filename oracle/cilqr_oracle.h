@@ -110,7 +110,8 @@ typedef struct orc_margin_rec {
 } orc_margin_rec;
 void orc_set_margin_buffer(orc_solver* s, orc_margin_rec* buf, int32_t cap);
 
-int orc_math_mode(void); /* 0 = libm, 1 = detmath */
+int orc_math_mode(void);
+int orc_fused(void); /* 1 in the fused-flavour build (-DORC_FUSED: an experiment, see cilqr_oracle.c) */ /* 0 = libm, 1 = detmath */
 
 orc_solver* orc_create(const orc_params* p);
 void orc_destroy(orc_solver* s);

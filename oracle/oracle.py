@@ -3,7 +3,8 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
 shipped package (toy-example-of-ilqr_amd/) never does.  Two builds are wrapped:
 ``Oracle("det")``  -> liboracle_det.so  (elementary functions from csrc/detmath.h: bit-identical to
-the HIP kernels) and ``Oracle("libm")`` -> liboracle_libm.so (glibc libm, as the reference uses).
+the HIP kernels) and ``Oracle("libm")`` -> liboracle_libm.so (glibc libm, as the reference uses); ``Oracle("fused")`` ->
+liboracle_fused.so, the round-4 experiment (detmath + explicit fma at four named groups of sites).
 """
 import ctypes as C
 import pathlib
@@ -102,7 +103,12 @@ class Scene:
 
 class Oracle:
     def __init__(self, mode="det"):
-        assert mode in ("det", "libm")
+        assert mode in ("det", "libm", "fused")
+        # round-4 experiment: CILQR_ORACLE_FUSED=1 makes "det" mean the fused-flavour build (detmath + explicit fma at four
+        # named groups of sites), the checker of a device library compiled with -DCILQR_FUSED
+        import os
+        if mode == "det" and os.environ.get("CILQR_ORACLE_FUSED") == "1":
+            mode = "fused"
         path = HERE / f"liboracle_{mode}.so"
         if not path.exists():
             ensure_built()
@@ -144,7 +150,9 @@ class Oracle:
             fn.restype = res
             fn.argtypes = args
         self.lib = lib
-        assert lib.orc_math_mode() == (1 if mode == "det" else 0)
+        assert lib.orc_math_mode() == (0 if mode == "libm" else 1)
+        lib.orc_fused.restype = C.c_int
+        assert lib.orc_fused() == (1 if mode == "fused" else 0)
 
     # ---- solver object ----
     def solver(self, params):

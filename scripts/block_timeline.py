@@ -16,6 +16,8 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 wl = {2: pkg.workloads.config2, 3: pkg.workloads.config3, 5: pkg.workloads.config5}.get(cfg)
 wl = wl() if wl else pkg.workloads.config4(B=int(sys.argv[2]) if len(sys.argv) > 2 else 8192, N=100)
 eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+if os.environ.get("GROUP_MODE"):
+    eng.set_group_mode(int(os.environ["GROUP_MODE"]))
 eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
 eng.set_block_timeline(True)
 eng.set_timing(True)

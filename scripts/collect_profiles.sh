@@ -21,8 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config5" -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config2" -- $BENCH --config 2 $ONLY > "$OUT/stats_config2.log" 2>&1
 
 # 3. HBM traffic and SQ counters per workload, one small counter group per pass
-wl_args() { case $1 in c5) echo "--config 5";; c3) echo "--config 3";; c2) echo "--config 2";; c2b16k) echo "--config 2 --batch 16384";; c4) echo "--config 4";; esac; }
-for wl in c5 c3 c2 c2b16k c4; do
+wl_args() { case $1 in c5|c5alm) echo "--config 5";; c3) echo "--config 3";; c2) echo "--config 2";; c2b16k) echo "--config 2 --batch 16384";; c4) echo "--config 4";; esac; }
+for wl in c5 c3 c2 c2b16k c4 c5alm; do
+    if [ $wl = c5alm ]; then export CILQR_BENCH_ALM=1; else unset CILQR_BENCH_ALM; fi  # (the headline batch with solve_type alm)
     for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
                "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
         name=$(echo $grp | tr ' ' '+')
@@ -30,6 +31,7 @@ for wl in c5 c3 c2 c2b16k c4; do
             $BENCH $(wl_args $wl) --steps 3 --warmup 1 $ONLY > "$OUT/pmc_${wl}_$name.log" 2>&1
     done
 done
+unset CILQR_BENCH_ALM
 
 # 4. the other BASELINE configurations (one bench line each) and a batch sweep of config 2
 for c in 2 3 4; do
@@ -47,9 +49,16 @@ for c in 5 3 4; do
 done
 fi
 
-# 5. in-kernel phase accounting
-for c in 2 3 5 4; do
+# 5. in-kernel phase accounting.  Configs 3 and 5 run the grouped build (two trajectories per wavefront, two wavefronts per
+# SIMD: --group 2); next to it the one-trajectory build they ran before, accounted at two wavefronts per SIMD as well
+# (CILQR_TUNE=prof2=1) and at one (the r01-r03 figures)
+for c in 2 4; do
     $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
+done
+for c in 3 5; do
+    $PY $ROOT/scripts/phase_profile.py --config $c --group 2 > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
+    CILQR_TUNE=prof2=1 $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config${c}_single_2wps.json" 2>> "$OUT/phase_config$c.err"
+    $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config${c}_single_1wps.json" 2>> "$OUT/phase_config$c.err"
 done
 
 # 6. the RCCL branch of bench.py on one rank (init_process_group("nccl") + the two all-reduces + barrier)
@@ -63,6 +72,11 @@ ls "$OUT" | head -80
 # 8. how the launches fill the chip: block timelines (raw records kept next to the summaries)
 for c in 3 4 5; do
     TIMELINE_OUT="$OUT/timeline_c$c.npy" $PY $ROOT/scripts/block_timeline.py $c > "$OUT/timeline_config$c.json" 2> "$OUT/timeline_config$c.err"
+done
+
+# 8b. the same launches with one trajectory per wavefront (the r03 shape), for the timelines' before / after
+for c in 3 5; do
+    GROUP_MODE=0 $PY $ROOT/scripts/block_timeline.py $c > "$OUT/timeline_config${c}_single.json" 2>> "$OUT/timeline_config$c.err"
 done
 
 # 9. where the wave-cycles go (SQ wait / active counters), headline and the two 8192-trajectory launches

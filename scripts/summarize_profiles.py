@@ -59,7 +59,7 @@ for c in ("config5", "config2"):
 
 # per-workload counters.  The workload name of each pass comes from the bench line the pass printed.
 pmc_all = {}
-for wl in ("c5", "c3", "c2", "c2b16k", "c4"):
+for wl in ("c5", "c3", "c2", "c2b16k", "c4", "c5alm"):
     name = alg = iters = kernel_ms = None
     for log in glob.glob(os.path.join(src, f"pmc_{wl}_*.log")):
         for line in open(log, errors="replace"):
@@ -136,9 +136,10 @@ if b:
     json.dump(pl, open(os.path.join(dst, f"{tag}_pipelined.json"), "w"), indent=1)
 
 for c in (2, 3, 5, 4):
-    p = os.path.join(src, f"phase_config{c}.json")
-    if os.path.exists(p) and os.path.getsize(p):
-        shutil.copy(p, os.path.join(dst, f"{tag}_phase_config{c}.json"))
+    for suffix in ("", "_single_2wps", "_single_1wps"):
+        p = os.path.join(src, f"phase_config{c}{suffix}.json")
+        if os.path.exists(p) and os.path.getsize(p):
+            shutil.copy(p, os.path.join(dst, f"{tag}_phase_config{c}{suffix}.json"))
 
 # SQ wait / active counters of scripts/stall_counters.sh (per launch, averaged over launches)
 for name in ("c5", "c4", "c3", "c2"):
@@ -156,9 +157,10 @@ if b:
                        "and MAX all-reduces of the statistics, destroy_process_group",
                "bench_line": b, "stderr_tail": err}, open(os.path.join(dst, f"{tag}_force_dist.json"), "w"), indent=1)
 for c in (3, 4, 5):
-    p = os.path.join(src, f"timeline_config{c}.json")
-    if os.path.exists(p) and os.path.getsize(p):
-        shutil.copy(p, os.path.join(dst, f"{tag}_timeline_config{c}.json"))
+    for suffix in ("", "_single"):
+        p = os.path.join(src, f"timeline_config{c}{suffix}.json")
+        if os.path.exists(p) and os.path.getsize(p):
+            shutil.copy(p, os.path.join(dst, f"{tag}_timeline_config{c}{suffix}.json"))
     # the raw per-trajectory records (start, end, block, XCC): what scripts/schedule_sim.py replays
     p = os.path.join(src, f"timeline_c{c}.npy")
     if os.path.exists(p) and c in (3, 4):

@@ -1604,11 +1604,11 @@ def test_trajectories_in_pairs_per_wavefront_are_transparent(pkg, orc_det, engin
         eng.set_group_mode(0)
         base = eng.solve_batch(x0, trace_cap=128)
         compare_solves(base, refs, f"{name} N={N} one per wavefront")
-        for rollout in (-1, 0, 1):
-            eng.set_group_mode(2)
+        for gm, rollout in ((2, -1), (2, 0), (2, 1), (3, -1), (3, 0), (3, 1)):  # two / three trajectories per wavefront
+            eng.set_group_mode(gm)
             eng.set_rollout_mode(rollout)
             g = eng.solve_batch(x0, trace_cap=128)
-            what = f"{name} N={N} pairs rollout={rollout}"
+            what = f"{name} N={N} {gm} per wavefront, rollout={rollout}"
             compare_solves(g, refs, what)
             eq_bits(base["u"], g["u"], what + " u")
             eq_bits(base["x"], g["x"], what + " x")

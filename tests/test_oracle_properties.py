@@ -169,3 +169,25 @@ def test_libm_tolerance_diagnosis_on_the_detmath_twin(pkg, orc_det):
     for r in rep["records"]:
         assert r["gap"] <= 1.5 * r["libm_spread_under_1ulp_x0"]
         assert all(np.isfinite(v) and v >= 0 for v in r["smallest_decision_margin_at_split"].values())
+
+
+def test_fused_flavour_of_the_oracle_is_a_different_but_close_arithmetic(pkg_cpu=None):
+    """Round-4 experiment (profiles/r04_experiments/fused_flavour_ab.txt): liboracle_fused.so — explicit fma at four named
+    groups of sites — is not bit-identical to the detmath build, and on a well-conditioned solve it lands within 1e-9."""
+    import importlib
+    import sys
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    pkg = importlib.import_module("cilqr_amd")
+    from oracle import Oracle, Scene
+    cfg = pkg.GlobalConfig.get_instance("three_bend")
+    sc = pkg.build_scenario(cfg, "three_bend")
+    p = pkg.params_from_config(cfg, N=50, use_last_solution=0)
+    scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 16, 99)
+    det = Oracle("det").solve_batch(p, scene, x0, n_threads=2)
+    fus = Oracle("fused").solve_batch(p, scene, x0, n_threads=2)
+    assert (det["res"]["iters"] == fus["res"]["iters"]).all()
+    assert not np.array_equal(det["x"], fus["x"])
+    assert np.abs(det["x"] - fus["x"]).max() < 1e-9 and np.abs(det["res"]["J_final"] - fus["res"]["J_final"]).max() < 1e-9

@@ -47,7 +47,8 @@ def _run(cmd, verbose):
     subprocess.run([str(c) for c in cmd], check=True, cwd=str(CSRC))
 
 
-def build_library(force=False, verbose=False, dev=False, out=None, jobs=None):
+def build_library(force=False, verbose=False, dev=False, out=None, jobs=None, extra_defs=()):
+    """extra_defs: experiments only (e.g. ("-DCILQR_FUSED",) into ab/libF.so, profiles/r04_experiments)"""
     lib = pathlib.Path(out) if out else (LIB_DEV if dev else LIB)
     if not force and _newer(lib, _deps()):
         return lib
@@ -55,7 +56,7 @@ def build_library(force=False, verbose=False, dev=False, out=None, jobs=None):
     tag = "dev" if dev else "prod"
     objdir = OBJ / (tag if out is None else tag + "_" + lib.stem)
     objdir.mkdir(parents=True, exist_ok=True)
-    defs = ["-DCILQR_DEV_BUILD"] if dev else []
+    defs = (["-DCILQR_DEV_BUILD"] if dev else []) + list(extra_defs)
     units = [(CSRC / "cilqr_amd.hip", objdir / "cilqr_amd.o", []), (CSRC / "scenario.cpp", objdir / "scenario.o", [])]
     units += [(CSRC / "cilqr_solve_inst.hip", objdir / f"solve_inst_{g}.o", [f"-DCILQR_INST_GROUP={g}"]) for g in range(GROUPS)]
     jobs = jobs or min(len(units), os.cpu_count() or 1)

@@ -23,6 +23,8 @@ CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
 #undef CILQR_X_EXTERN
 extern template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -379,7 +381,8 @@ struct cilqr_handle {
 // Persistent launches use one scratch area per resident block: never more than this many per CU, whatever the
 // occupancy query says (8 = two wavefronts per SIMD; ensure_scratch sizes the areas with the same number)
 #define CILQR_MAX_BLOCKS_PER_CU 8
-#define CILQR_GROUP 2 /* trajectories per wavefront of the grouped builds (k_solve_grp) */
+#define CILQR_GROUP_MAX 3 /* trajectories per wavefront of the grouped builds (k_solve_grp): 2 or 3 */
+static int grp_n(const cilqr_handle* h); // (2 unless cilqr_set_group_mode asked for 3)
 static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out) {
     for (const auto& e : h->occ)
         if (e.kern == kern && e.shm == shm) { *out = e.per_cu; return CILQR_OK; }
@@ -432,7 +435,7 @@ static void update_window(cilqr_handle* h) {
     {
         // the grouped builds: the window shares the expansion's area (cilqr_group.hpp), so it is free up to that size and
         // otherwise bounded by 8 blocks per CU
-        const long room = (long)(163840 / CILQR_MAX_BLOCKS_PER_CU) - (long)grp_lds_bytes(N, 0, CILQR_GROUP) +
+        const long room = (long)(163840 / CILQR_MAX_BLOCKS_PER_CU) - (long)grp_lds_bytes(N, 0, grp_n(h)) +
                           (long)sizeof(double) * grp_expansion_doubles(N);
         int wg = (int)(room / 16) / 8 * 8;
         wg = std::max(wg, grp_expansion_doubles(N) / 2 / 8 * 8);
@@ -453,6 +456,8 @@ static int wait_last_launch(cilqr_handle* h) {
     if (h->launched) HIP_TRY(hipEventSynchronize(h->ev_launch));
     return CILQR_OK;
 }
+
+static int grp_n(const cilqr_handle* h) { return h->group_mode == 3 ? 3 : 2; }
 
 static int check_ready(cilqr_handle* h) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
@@ -684,8 +689,9 @@ extern "C" int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode) {
 }
 
 extern "C" int cilqr_set_group_mode(cilqr_handle* h, int32_t mode) {
-    if (!h || mode < -1 || mode > CILQR_GROUP) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0, 1 or 2");
+    if (!h || mode < -1 || mode > CILQR_GROUP_MAX) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0, 1, 2 or 3");
     h->group_mode = mode;
+    update_window(h);
     return CILQR_OK;
 }
 
@@ -1076,7 +1082,7 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
         areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
     size_t area = scratch_doubles(N);
     if (fused && grouped(h, B)) { // (persistent blocks: one area per resident block, CILQR_GROUP trajectories in it)
-        area = std::max(area, (size_t)CILQR_GROUP * grp_scratch_doubles(N));
+        area = std::max(area, (size_t)grp_n(h) * grp_scratch_doubles(N));
         areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
     }
     if (h->scratch.ensure(sizeof(double) * area * areas))
@@ -1187,12 +1193,14 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
     if (loop.ticks < 1 && grouped(h, B)) {
         // CILQR_GROUP trajectories per wavefront, one rollout pass for all of them (cilqr_group.hpp): persistent blocks
-        auto kg = (a.N == 50) ? k_solve_grp<50, CILQR_GROUP> : k_solve_grp<0, CILQR_GROUP>;
-        const size_t shm = grp_lds_bytes(a.N, a.W, CILQR_GROUP);
+        const int G = grp_n(h);
+        auto kg = (a.N == 50) ? k_solve_grp<50, 2> : k_solve_grp<0, 2>;
+        if (G == 3) kg = (a.N == 50) ? k_solve_grp<50, 3> : k_solve_grp<0, 3>;
+        const size_t shm = grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
         if (rc) return rc;
-        const int cap = per_cu * h->num_cus, want = (B + CILQR_GROUP - 1) / CILQR_GROUP;
+        const int cap = per_cu * h->num_cus, want = (B + G - 1) / G;
         const int grid = want < cap ? want : cap;
         h->last_launch_shared = false;
         a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
@@ -1204,7 +1212,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
             a.rq_cap = h->park_B;
         }
-        if (h->scratch.cap < sizeof(double) * (size_t)CILQR_GROUP * grp_scratch_doubles(a.N) * (size_t)grid)
+        if (h->scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kg, dim3(grid), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out, d_res_out, d_trace_out,
                            d_trace_out ? trace_cap : 0);

@@ -29,6 +29,16 @@
 #include "detmath.h"
 
 #define CILQR_WAVE 64
+
+// The FUSED flavour (round-4 experiment, see oracle/cilqr_oracle.c): -DCILQR_FUSED turns the multiply-adds of four named
+// groups of sites — F1 the quadratic forms of the stage cost, F2 every product of the backward sweep, F3 the rollout's
+// K dx + alpha d, F4 the affine updates of the kinematic step — into explicit fma, in the association the oracle's
+// -DORC_FUSED build uses.  Default: the plain product and sum (the build the library ships).
+#ifdef CILQR_FUSED
+#define CQ_MADD(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define CQ_MADD(a, b, c) ((a) * (b) + (c))
+#endif
 #define CILQR_DBG_SERIAL_REF_SCAN 1 /* cilqr_set_debug_flags: always take the serial reference-point chain */
 #define CILQR_DBG_UNIFORM_BACKWARD 2 /* use the wave-uniform backward sweep instead of the lane-parallel one */
 
@@ -295,18 +305,18 @@ __device__ inline void propagate_v(const double dt, const double wb, const doubl
         double sn, cs;
         dm_sincos<TRIG>(x[3], &sn, &cs, pk);
         double tn = dm_tan<TRIG>(u[1], pk);
-        xn[0] = x[0] + x[2] * cs * dt;
-        xn[1] = x[1] + x[2] * sn * dt;
-        xn[2] = x[2] + u[0] * dt;
+        xn[0] = CQ_MADD(x[2] * cs, dt, x[0]);
+        xn[1] = CQ_MADD(x[2] * sn, dt, x[1]);
+        xn[2] = CQ_MADD(u[0], dt, x[2]);
         xn[3] = x[3] + x[2] * tn * dt / wb;
     } else {
         double beta = dm_atan<TRIG>(dm_tan<TRIG>(u[1], pk) / 2);
         double sn, cs;
         dm_sincos<TRIG>(beta + x[3], &sn, &cs, pk);
         double sb = dm_sin<TRIG>(beta, pk);
-        xn[0] = x[0] + x[2] * cs * dt;
-        xn[1] = x[1] + x[2] * sn * dt;
-        xn[2] = x[2] + u[0] * dt;
+        xn[0] = CQ_MADD(x[2] * cs, dt, x[0]);
+        xn[1] = CQ_MADD(x[2] * sn, dt, x[1]);
+        xn[2] = CQ_MADD(u[0], dt, x[2]);
         xn[3] = x[3] + 2 * x[2] * sb * dt / wb;
     }
 }
@@ -329,9 +339,9 @@ __device__ inline bool propagate_small_v(const double dt, const double wb, const
         double sn, cs;
         dm_sincos<T>(x[3], &sn, &cs, pk);
         double tn = dm_tan<T>(u[1], pk);
-        xn[0] = x[0] + x[2] * cs * dt;
-        xn[1] = x[1] + x[2] * sn * dt;
-        xn[2] = x[2] + u[0] * dt;
+        xn[0] = CQ_MADD(x[2] * cs, dt, x[0]);
+        xn[1] = CQ_MADD(x[2] * sn, dt, x[1]);
+        xn[2] = CQ_MADD(u[0], dt, x[2]);
         xn[3] = x[3] + x[2] * tn * dt / wb;
     } else {
         double beta = dm_atan<T>(dm_tan<T>(u[1], pk) / 2);
@@ -340,9 +350,9 @@ __device__ inline bool propagate_small_v(const double dt, const double wb, const
         double sn, cs;
         dm_sincos<T>(ang, &sn, &cs, pk);
         double sb = dm_sin<T>(beta, pk);
-        xn[0] = x[0] + x[2] * cs * dt;
-        xn[1] = x[1] + x[2] * sn * dt;
-        xn[2] = x[2] + u[0] * dt;
+        xn[0] = CQ_MADD(x[2] * cs, dt, x[0]);
+        xn[1] = CQ_MADD(x[2] * sn, dt, x[1]);
+        xn[2] = CQ_MADD(u[0], dt, x[2]);
         xn[3] = x[3] + 2 * x[2] * sb * dt / wb;
     }
     return true;
@@ -673,9 +683,9 @@ __device__ inline void stage_cost(const Cst& c, const Lds& l, const AlmSt& al, i
     gdouble* aux = c.lane_aux + (size_t)ridx * CILQR_AUX_STRIDE;
     const double ryaw = aux[0], sr = aux[1], cr = aux[2];
     double e0 = xk[0] - rx, e1 = xk[1] - ry, e2 = xk[2] - c.k->ref_velo, e3 = xk[3] - ryaw;
-    sd = (((e0 * c.k->w_pos) * e0 + (e1 * c.k->w_pos) * e1) + (e2 * c.k->w_vel) * e2) + (e3 * c.k->w_yaw) * e3;
+    sd = CQ_MADD(e3 * c.k->w_yaw, e3, CQ_MADD(e2 * c.k->w_vel, e2, CQ_MADD(e1 * c.k->w_pos, e1, (e0 * c.k->w_pos) * e0)));
     ce = 0.0;
-    if (k < c.N) ce = (uk[0] * c.k->w_acc) * uk[0] + (uk[1] * c.k->w_stl) * uk[1];
+    if (k < c.N) ce = CQ_MADD(uk[1] * c.k->w_stl, uk[1], (uk[0] * c.k->w_acc) * uk[0]);
     jb = 0.0;
     if (k >= 1) {
         double acc_up = ukm1[0] - c.k->acc_max, acc_lo = c.k->acc_min - ukm1[0];
@@ -1156,11 +1166,11 @@ struct RollOut {
 template <int RP, bool SMALL, int PIN = DM_PIN>
 __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], RollOut& o) {
     const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
-    const double k0 = ((g.k[0] * dx0 + g.k[1] * dx1) + g.k[2] * dx2) + g.k[3] * dx3;
-    const double k1 = ((g.k[5] * dx0 + g.k[6] * dx1) + g.k[7] * dx2) + g.k[8] * dx3;
+    const double k0 = CQ_MADD(g.k[3], dx3, CQ_MADD(g.k[2], dx2, CQ_MADD(g.k[1], dx1, g.k[0] * dx0)));
+    const double k1 = CQ_MADD(g.k[8], dx3, CQ_MADD(g.k[7], dx2, CQ_MADD(g.k[6], dx1, g.k[5] * dx0)));
     double un[2];
-    un[0] = (g.u[0] + k0) + alpha * g.k[CILQR_KD_D(0)];
-    un[1] = (g.u[1] + k1) + alpha * g.k[CILQR_KD_D(1)];
+    un[0] = CQ_MADD(alpha, g.k[CILQR_KD_D(0)], g.u[0] + k0);
+    un[1] = CQ_MADD(alpha, g.k[CILQR_KD_D(1)], g.u[1] + k1);
     double xn[4];
     if (SMALL) {
         if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) return false;
@@ -2235,14 +2245,14 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         // pass 1: column wc of W from the lanes 8 k + wc
         const double w0 = lane_gather(wn, wc), w1 = lane_gather(wn, 8 + wc);
         const double w2 = lane_gather(wn, 16 + wc), w3 = lane_gather(wn, 24 + wc);
-        const double X = ((m1[0] * w0 + m1[1] * w1) + m1[2] * w2) + m1[3] * w3;
+        const double X = CQ_MADD(m1[3], w3, CQ_MADD(m1[2], w2, CQ_MADD(m1[1], w1, m1[0] * w0)));
         const double Zv = lv + X; // (Q_x, Q_u) on the lanes of column 4
         // pass 2: row r' of X[:, 0:4] sits in lanes 8 r' + 0..3; bring it to both quads of the row, then
         // broadcast inside each quad
         const double Xq = dpp_move_banks<0x114, 0xA>(X);  // row_shr:4 on the lanes with cc >= 4 (banks 1 and 3)
         const double x0 = dpp_move<0x00>(Xq), x1 = dpp_move<0x55>(Xq);
         const double x2 = dpp_move<0xAA>(Xq), x3 = dpp_move<0xFF>(Xq);
-        const double Y = ((x0 * m2[0] + x1 * m2[1]) + x2 * m2[2]) + x3 * m2[3];
+        const double Y = CQ_MADD(x3, m2[3], CQ_MADD(x2, m2[2], CQ_MADD(x1, m2[1], x0 * m2[0])));
         double Q = Lq + Y;
         if (diag) Q = Q + lamb;
         // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
@@ -2286,15 +2296,15 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
             return false;
         }
         const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
-        const double kc0 = n00 * c0 + n01 * c1, kc1 = n10 * c0 + n11 * c1; // (K | d)[:, c]
-        double kr0 = n00 * r0 + n01 * r1, kr1 = n10 * r0 + n11 * r1; // K[:, r]
+        const double kc0 = CQ_MADD(n01, c1, n00 * c0), kc1 = CQ_MADD(n11, c1, n10 * c0); // (K | d)[:, c]
+        double kr0 = CQ_MADD(n01, r1, n00 * r0), kr1 = CQ_MADD(n11, r1, n10 * r0); // K[:, r]
         kr0 = kr0 * krf; // (exact: the factor is 1, or 0.5 on row 4 — hd = 0.5 d of cs:435)
         kr1 = kr1 * krf;
-        const double p0 = kr0 * Quu0 + kr1 * Quu2;                         // (K^T Q_uu)[r][:]
-        const double p1 = kr0 * Quu1 + kr1 * Quu3;
-        const double ta = p0 * kc0 + p1 * kc1;
-        const double tb = kr0 * c0 + kr1 * c1;
-        const double tc = r0 * kc0 + r1 * kc1;
+        const double p0 = CQ_MADD(kr1, Quu2, kr0 * Quu0);                  // (K^T Q_uu)[r][:]
+        const double p1 = CQ_MADD(kr1, Quu3, kr0 * Quu1);
+        const double ta = CQ_MADD(p1, kc1, p0 * kc0);
+        const double tb = CQ_MADD(kr1, c1, kr0 * c0);
+        const double tc = CQ_MADD(r1, kc1, r0 * kc0);
         const double own = (ccv < 4) ? Q : Zv;
         wn = ((own + ta) + tb) + tc;
         int lanev = lane;

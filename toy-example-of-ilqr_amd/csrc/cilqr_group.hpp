@@ -313,12 +313,15 @@ __device__ inline void lds_sync() {
 struct GrpRoll {
     double alpha, dt, wb;
     unsigned xaddr, uaddr; // LDS byte addresses of the trajectory's x, u
-    unsigned kaddr;        // ... of its gains (staged for the pass, see rollout_group)
+    unsigned kaddr;        // ... of its gains when they are staged for the pass (rollout_group), else:
+    unsigned goff;         // byte offset of its gains in the block's scratch area
     unsigned vrow0;        // ... of row 0, pair 0 of this lane's trial
     unsigned csb, rowb;    // pair / row stride of the destination (slab: 20 step sizes per row, first-trial buffer: 1)
 };
 
-__device__ inline void roll_fetch_g(RollIn& g, unsigned xa, unsigned ua, unsigned ka, int i) {
+template <bool STAGE>
+__device__ inline void roll_fetch_g(RollIn& g, __amdgpu_buffer_rsrc_t rs, const GrpRoll& q, int i) {
+    const unsigned xa = q.xaddr, ua = q.uaddr, ka = q.kaddr;
     const f64x2 a = *(lds_cf64x2*)(size_t)(xa + 32u * (unsigned)i);
     const f64x2 b = *(lds_cf64x2*)(size_t)(xa + 32u * (unsigned)i + 16u);
     const f64x2 u = *(lds_cf64x2*)(size_t)(ua + 16u * (unsigned)i);
@@ -326,9 +329,17 @@ __device__ inline void roll_fetch_g(RollIn& g, unsigned xa, unsigned ua, unsigne
     g.u[0] = u.x; g.u[1] = u.y;
 #pragma unroll
     for (int j = 0; j < CILQR_KD / 2; ++j) {
-        const f64x2 v = *(lds_cf64x2*)(size_t)(ka + (unsigned)(CILQR_KD * 8) * (unsigned)i + 16u * (unsigned)j);
-        g.k[2 * j] = v.x;
-        g.k[2 * j + 1] = v.y;
+        if (STAGE) {
+            const f64x2 v = *(lds_cf64x2*)(size_t)(ka + (unsigned)(CILQR_KD * 8) * (unsigned)i + 16u * (unsigned)j);
+            g.k[2 * j] = v.x;
+            g.k[2 * j + 1] = v.y;
+        } else { // straight from global memory (L2), one step ahead like the rest
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, q.goff, i * (CILQR_KD * 8) + 16 * j, 0);
+            u32x2 lo, hi;
+            lo.x = v.x; lo.y = v.y; hi.x = v.z; hi.y = v.w;
+            g.k[2 * j] = __builtin_bit_cast(double, lo);
+            g.k[2 * j + 1] = __builtin_bit_cast(double, hi);
+        }
     }
 }
 
@@ -345,11 +356,11 @@ template <int RP, bool SMALL, int PIN>
 __device__ inline bool roll_step_g(const GrpRoll& q, __amdgpu_buffer_rsrc_t rs, const DmPinned& pk, const RollIn& g, double xc[4],
                                    GrpOut& o) {
     const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
-    const double k0 = ((g.k[0] * dx0 + g.k[1] * dx1) + g.k[2] * dx2) + g.k[3] * dx3;
-    const double k1 = ((g.k[5] * dx0 + g.k[6] * dx1) + g.k[7] * dx2) + g.k[8] * dx3;
+    const double k0 = CQ_MADD(g.k[3], dx3, CQ_MADD(g.k[2], dx2, CQ_MADD(g.k[1], dx1, g.k[0] * dx0)));
+    const double k1 = CQ_MADD(g.k[8], dx3, CQ_MADD(g.k[7], dx2, CQ_MADD(g.k[6], dx1, g.k[5] * dx0)));
     double un[2];
-    un[0] = (g.u[0] + k0) + q.alpha * g.k[CILQR_KD_D(0)];
-    un[1] = (g.u[1] + k1) + q.alpha * g.k[CILQR_KD_D(1)];
+    un[0] = CQ_MADD(q.alpha, g.k[CILQR_KD_D(0)], g.u[0] + k0);
+    un[1] = CQ_MADD(q.alpha, g.k[CILQR_KD_D(1)], g.u[1] + k1);
     double xn[4];
     if (SMALL) {
         if (!DM_WAVE_ALL(__builtin_fabs(xc[3]) < 0.785 && __builtin_fabs(un[1]) < 0.7)) return false;
@@ -368,7 +379,7 @@ __device__ inline bool roll_step_g(const GrpRoll& q, __amdgpu_buffer_rsrc_t rs, 
 }
 
 // the lanes of one vehicle model (the others are masked off by the caller's branch)
-template <int RP, int PIN>
+template <int RP, int PIN, bool STAGE>
 __device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const GrpRoll& q) {
     const f64x2 a0 = *(lds_cf64x2*)(size_t)(q.xaddr);
     const f64x2 b0 = *(lds_cf64x2*)(size_t)(q.xaddr + 16u);
@@ -386,27 +397,27 @@ __device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const 
     int i = 0;
     {
         RollIn ga, gb;
-        roll_fetch_g(ga, q.xaddr, q.uaddr, q.kaddr, 0);
+        roll_fetch_g<STAGE>(ga, rs, q, 0);
         for (;;) {
             if (i >= N) break;
-            if (i + 1 < N) roll_fetch_g(gb, q.xaddr, q.uaddr, q.kaddr, i + 1);
+            if (i + 1 < N) roll_fetch_g<STAGE>(gb, rs, q, i + 1);
             if (!roll_step_g<RP, true, PIN>(q, rs, pk, ga, xc, o)) break;
             ++i;
             if (i >= N) break;
-            if (i + 1 < N) roll_fetch_g(ga, q.xaddr, q.uaddr, q.kaddr, i + 1);
+            if (i + 1 < N) roll_fetch_g<STAGE>(ga, rs, q, i + 1);
             if (!roll_step_g<RP, true, PIN>(q, rs, pk, gb, xc, o)) break;
             ++i;
         }
     }
     if (i < N) {
         RollIn ga, gb;
-        roll_fetch_g(ga, q.xaddr, q.uaddr, q.kaddr, i);
+        roll_fetch_g<STAGE>(ga, rs, q, i);
         for (;;) {
-            if (i + 1 < N) roll_fetch_g(gb, q.xaddr, q.uaddr, q.kaddr, i + 1);
+            if (i + 1 < N) roll_fetch_g<STAGE>(gb, rs, q, i + 1);
             roll_step_g<RP, false, PIN>(q, rs, pk, ga, xc, o);
             ++i;
             if (i >= N) break;
-            if (i + 1 < N) roll_fetch_g(ga, q.xaddr, q.uaddr, q.kaddr, i + 1);
+            if (i + 1 < N) roll_fetch_g<STAGE>(ga, rs, q, i + 1);
             roll_step_g<RP, false, PIN>(q, rs, pk, gb, xc, o);
             ++i;
             if (i >= N) break;
@@ -420,7 +431,9 @@ __device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const 
 // Out of line: at the call site nothing of a solve is live in registers (a trajectory's state is in LDS between its
 // segments), so the call costs nothing and the pass gets a register allocation of its own — inlined into the kernel its
 // loops carried scratch reloads (2 per step) and 16 lane moves of spilled scalars per step.
-template <int G, int PIN>
+// STAGE: the gains of the pass are copied into the wavefront's shared LDS area first (two trajectories fit); otherwise the
+// lanes read them from global memory one step ahead.
+template <int G, int PIN, bool STAGE>
 __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double* scr_blk, int N, int lane) {
     const int R = N + 1;
     int start = 0, gl = -1, al = 0, rq = 0;
@@ -439,9 +452,10 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
     // does.  (Read straight from global memory one step ahead, the loop ran at the latency of a load from the fabric behind
     // the slab stores: SQ_WAIT_ANY + 59 %, the launch 4 % SLOWER than one trajectory per wavefront.)
     double* const stage = lds_base + (size_t)G * grp_pg_doubles(N);
-    static_assert(G <= 2, "the shared area holds the gains of two trajectories (2 x 10 N <= 10 N + 15 N + 15 doubles)");
+    static_assert(G <= 3, "lanes: three searches of 20 step sizes fit a wavefront");
+    static_assert(!STAGE || G <= 2, "the shared area holds the gains of two trajectories (2 x 10 N <= 10 N + 15 N + 15 doubles)");
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; STAGE && g < G; ++g) {
         if (uniform_int(grp_state(lds_base, N, g)->req) == 0) continue;
         const double* src = scr_blk + (size_t)g * grp_scratch_doubles(N) + slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * R;
         const f64x2* s2 = reinterpret_cast<const f64x2*>(src);
@@ -462,14 +476,15 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
         const unsigned as = (rq == 2) ? (unsigned)CILQR_MAX_ALPHA_TRIALS : 1u;
         const unsigned gbase = (unsigned)gl * (unsigned)(grp_scratch_doubles(N) * sizeof(double));
         q.kaddr = lds_addr(stage + (size_t)gl * CILQR_KD * N);
+        q.goff = gbase + (unsigned)((slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * R) * sizeof(double));
         q.rowb = as * 16u;
         q.csb = (unsigned)R * as * 16u;
         q.vrow0 = gbase + ((rq == 2) ? 0u : (unsigned)(slab_doubles(N) * sizeof(double))) + 16u * (unsigned)al;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)uniform_ptr(scr_blk), 0, (int)(G * grp_scratch_doubles(N) * sizeof(double)), 0x00020000);
         // one loop pair per vehicle model: only that model's polynomial constants are live inside it
-        if (rp == 0) rollout_group_rp<0, PIN>(N, rs, q);
-        else rollout_group_rp<1, PIN>(N, rs, q);
+        if (rp == 0) rollout_group_rp<0, PIN, STAGE>(N, rs, q);
+        else rollout_group_rp<1, PIN, STAGE>(N, rs, q);
     }
     wave_sync();
     if (lane < G) grp_state(lds_base, N, lane)->req = 0;

@@ -1051,7 +1051,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             int reqs[G], n_req = 0;
             for (int g = 0; g < G; ++g) { reqs[g] = uniform_int(grp_state(g_lds, N, g)->req); n_req += reqs[g] != 0; }
             const long long t0_ = (long long)__builtin_readcyclecounter();
-            rollout_group<G, 0>(g_lds, scr_blk, N, lane);
+            rollout_group<G, 0, (G <= 2)>(g_lds, scr_blk, N, lane);
             const long long dt_ = ((long long)__builtin_readcyclecounter() - t0_) / (n_req > 0 ? n_req : 1);
             if (lane == 0)
                 for (int g = 0; g < G; ++g)
@@ -1062,7 +1062,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     }
             wave_sync();
         } else {
-            rollout_group<G, 0>(g_lds, scr_blk, N, lane);
+            rollout_group<G, 0, (G <= 2)>(g_lds, scr_blk, N, lane);
         }
     }
 }

@@ -52,4 +52,8 @@ CILQR_SOLVE_VARIANTS(CILQR_X_INST)
 template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 7
 template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 5
+template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 3
+template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
 #endif
