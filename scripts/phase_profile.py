@@ -62,6 +62,8 @@ rep["ref_scan_fallbacks_max_per_trajectory"] = int(cyc[:, 8].max())
 if args.group:  # the grouped build books its own bookkeeping in slots 10-12
     rep["grouped_extra_cycles_per_iteration"] = {n: float(cyc[:, i].sum() / res["iters"].sum()) for n, i in
                                                  (("segment_setup", 10), ("back_in_solve", 11), ("state_store", 12))}
+    passes = cyc[:, 14].sum() + cyc[:, 15].sum() + cyc[:, 16].sum()
+    rep["rollout_steps_in_the_small_angle_form_frac"] = float(cyc[:, 13].sum() / max(1, passes * wl.N))
 if os.environ.get("PHASE_OUT"):
     np.save(os.environ["PHASE_OUT"], cyc)
 print(json.dumps(rep, indent=1))

@@ -39,14 +39,18 @@ enum { GP_EMPTY = 0, GP_ITER = 1, GP_SEARCH = 2, GP_DONE = 3, GP_STOLEN = 4 /* b
 struct GrpSt {
     double J_cur, J_init, lamb, dV0, dV1, new_J, dt, wb;
     long long tl_start;
-    int b, phase, status, iters, ls_trials, cost_evals, tl, flag, deep_next, idx0, t0, have_all, trials, req, nfb, rp, pad0, pad1;
+    double J_pair; // the second cost of a paired costing pass (grp_cost_trials2)
+    int b, phase, status, iters, ls_trials, cost_evals, tl, flag, deep_next, idx0, t0, have_all, trials, req, nfb, rp;
+    int small_steps; // (development aid) steps of the last rollout pass that ran the straight-line small-angle form
+    int pad0, pad1, pad2;
 };
-static_assert(sizeof(GrpSt) == 144, "GrpSt layout");
-#define CILQR_GRPST_DOUBLES 18
+static_assert(sizeof(GrpSt) == 160, "GrpSt layout");
+#define CILQR_GRPST_DOUBLES 20
 static_assert(sizeof(Cst) == 88, "Cst layout");
 #define CILQR_CST_DOUBLES 12 /* the by-value constants (Cst) of the trajectory, kept so that a segment need not walk the tables again */
 
-__host__ __device__ inline int grp_idx_doubles(int N) { return ((N + 2) + 1) & ~1; } // ridx + tidx: 2 (N + 2) ints, 16-byte granules
+// ridx + two rows of tidx (the trials costed in pairs keep one row of lane-index guesses each): 3 (N + 2) ints, 16-byte granules
+__host__ __device__ inline int grp_idx_doubles(int N) { return ((3 * (N + 2) + 1) / 2 + 1) & ~1; }
 __host__ __device__ inline int grp_pg_doubles(int N) { // per trajectory
     return 4 * (N + 1) + 2 * N + grp_idx_doubles(N) + CILQR_CSTK_DOUBLES + CILQR_GRPST_DOUBLES + CILQR_CST_DOUBLES +
            (CILQR_GPROF ? CILQR_PROF_SLOTS + 1 : 0);
@@ -248,6 +252,35 @@ __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, i
     return J1[0];
 }
 
+// Two trials at once, t and t + 1 (slab only): their reference-point searches, row loads and barrier chains overlap inside
+// the wavefront — the second cost comes back in GrpSt::J_pair.  A search that has gone past its first trial usually goes on
+// (14 % of the headline's iterations try all 20 step sizes: 55 % of all trial costs), so the second cost is rarely wasted;
+// k_solve's two-per-SIMD builds could not afford the registers of the paired form (NTP = 2: 68 spilled), a function of
+// its own can.
+template <int NC, int G>
+__device__ __attribute__((noinline)) double grp_cost_trials2(double* lds, int g, int n_rt, int lane, const double* src, int t,
+                                                              int w0, int W) {
+    const int N = NC ? NC : n_rt;
+    Lds l;
+    carve_group(l, lds, N, G, g);
+    l.w0 = w0;
+    l.W = W;
+    Cst c;
+    load_cst_lds(c, grp_cst(lds, N, g));
+    AlmSt al;
+    al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    int nfb = 0;
+    double J2[2];
+    total_cost_trials<false, 1, false, 2>(c, l, al, src, t, 2, lane, w0, 0, &nfb, J2, nullptr, 0, CILQR_MAX_ALPHA_TRIALS);
+    if (lane == 0) {
+        GrpSt* st = grp_state(lds, N, g);
+        st->J_pair = J2[1];
+        if (nfb != 0) st->nfb += nfb;
+    }
+    wave_sync();
+    return J2[0];
+}
+
 // The initial trajectory of the trajectory in slot g and its cost (cs:155-197, cs:104): fills x, u, the lane indices and
 // the trial-index seeds; the row-0 lane index comes back in *idx0_out (LDS: GrpSt::idx0).  Once per solve: out of line so
 // that its serial rollout's register needs stay out of the kernel's.
@@ -264,7 +297,7 @@ __device__ __attribute__((noinline)) double grp_init(double* lds, int g, int n_r
     const double xs[4] = {xs0, xs1, xs2, xs3};
     int idx0 = 0;
     init_trajectory(c, l, xs, last_u, lane, idx0, Wcap);
-    seed_trial_indices(l, N, 1, lane);
+    seed_trial_indices(l, N, 2, lane);
     const double J = total_cost_lds<false>(c, l, al, lane);
     if (lane == 0) grp_state(lds, N, g)->idx0 = idx0;
     wave_sync();
@@ -380,7 +413,7 @@ __device__ inline bool roll_step_g(const GrpRoll& q, __amdgpu_buffer_rsrc_t rs, 
 
 // the lanes of one vehicle model (the others are masked off by the caller's branch)
 template <int RP, int PIN, bool STAGE>
-__device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const GrpRoll& q) {
+__device__ inline int rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const GrpRoll& q) {
     const f64x2 a0 = *(lds_cf64x2*)(size_t)(q.xaddr);
     const f64x2 b0 = *(lds_cf64x2*)(size_t)(q.xaddr + 16u);
     double xc[4] = {a0.x, a0.y, b0.x, b0.y};
@@ -409,6 +442,7 @@ __device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const 
             ++i;
         }
     }
+    const int i_small = i;
     if (i < N) {
         RollIn ga, gb;
         roll_fetch_g<STAGE>(ga, rs, q, i);
@@ -423,6 +457,7 @@ __device__ inline void rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const 
             if (i >= N) break;
         }
     }
+    return i_small;
 }
 
 // One pass for every trajectory of the wavefront that has asked for one (GrpSt::req: 1 = the first trial alone into the
@@ -483,8 +518,10 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)uniform_ptr(scr_blk), 0, (int)(G * grp_scratch_doubles(N) * sizeof(double)), 0x00020000);
         // one loop pair per vehicle model: only that model's polynomial constants are live inside it
-        if (rp == 0) rollout_group_rp<0, PIN, STAGE>(N, rs, q);
-        else rollout_group_rp<1, PIN, STAGE>(N, rs, q);
+        int i_small;
+        if (rp == 0) i_small = rollout_group_rp<0, PIN, STAGE>(N, rs, q);
+        else i_small = rollout_group_rp<1, PIN, STAGE>(N, rs, q);
+        if (CILQR_GPROF && al == 0) grp_state(lds_base, N, gl)->small_steps = i_small;
     }
     wave_sync();
     if (lane < G) grp_state(lds_base, N, lane)->req = 0;

@@ -61,6 +61,7 @@ struct BatchArgs {
     int32_t* loop_tick;         // [B] in / out
     double* loop_states;        // optional [B][loop_ticks][4]: the ego state after every tick
     int32_t* loop_iters;        // optional [loop_ticks][B]: iterations of every tick's solve
+    int pair_costs;             // grouped build: line-search trials after the first costed two per pass
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -817,7 +818,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 load_cst(c, a, b, l, lane); // (fills this slot's copy of the cost model's constants)
                 if (NC) c.N = NC;
                 if (lane == 0) { *grp_cst(g_lds, N, g) = c; st->b = b; st->req = 0; }
-                seed_trial_indices(l, N, 1, lane);
+                seed_trial_indices(l, N, 2, lane);
                 phase = GP_ITER;
                 GPROF_ADD(PH_TC_REF);
             } else if (phase != GP_EMPTY) {
@@ -908,24 +909,37 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         }
                         const double* src = have_all ? scr : first;
                         const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
-                        new_J = grp_cost_trial<NC, G>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
-                        GPROF_ADD(PH_TRIAL_COST);
-                        trials++;
-                        const int verdict = trial_verdict(J_cur, new_J, t0, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
-                        if (verdict == 1) {
-                            status = CILQR_CONVERGED;
-                            alpha_idx = t0;
-                            done = true;
-                        } else if (verdict == 2) {
-                            if (t0 != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
-                            flag = 1;
-                            alpha_idx = t0;
-                            accept_trial(c, l, src, t0, 0, lane, as);
-                            GPROF_ADD(PH_ACCEPT);
-                            J_cur = new_J;
-                            done = true;
+                        // past the first trial the costs come two per pass (the searches that get here mostly go on)
+                        const int nt = (a.pair_costs && have_all && t0 >= 1 && t0 + 1 < CILQR_MAX_ALPHA_TRIALS) ? 2 : 1;
+                        double Jp[2];
+                        if (nt == 2) {
+                            Jp[0] = grp_cost_trials2<NC, G>(g_lds, g, N, lane, src, t0, l.w0, l.W);
+                            Jp[1] = st->J_pair;
+                        } else {
+                            Jp[0] = grp_cost_trial<NC, G>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
+                            Jp[1] = 0.0;
                         }
-                        t0 += 1;
+                        GPROF_ADD(PH_TRIAL_COST);
+                        for (int tt = 0; tt < nt && !done; ++tt) {
+                            const int t = t0 + tt;
+                            new_J = Jp[tt];
+                            trials++;
+                            const int verdict = trial_verdict(J_cur, new_J, t, dV[0], dV[1], c.k->conv_thr, c.k->accept_thr);
+                            if (verdict == 1) {
+                                status = CILQR_CONVERGED;
+                                alpha_idx = t;
+                                done = true;
+                            } else if (verdict == 2) {
+                                if (t != 0) status = CILQR_FORWARD_PASS_SMALL_STEP;
+                                flag = 1;
+                                alpha_idx = t;
+                                accept_trial(c, l, src, t, tt, lane, as);
+                                GPROF_ADD(PH_ACCEPT);
+                                J_cur = new_J;
+                                done = true;
+                            }
+                        }
+                        t0 += nt;
                     }
                     if (again) {
                         if (lane == 0) st->req = 2;
@@ -1058,6 +1072,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     if (reqs[g]) {
                         long long* pa = grp_prof(g_lds, N, g);
                         pa[PH_ROLLOUT] += dt_; pa[PH_TOTAL] += dt_;
+                        pa[PH_TC_SAMPLED] += grp_state(g_lds, N, g)->small_steps; // (slot 13: straight-line steps of its passes)
                         pa[reqs[g] == 1 ? PH_ROLL_FIRST : (uniform_int(grp_state(g_lds, N, g)->t0) == 1 ? PH_ROLL_SECOND : PH_ROLL_ALL)] += 1;
                     }
             wave_sync();
