@@ -234,6 +234,10 @@ class GpuRun:
         elapsed = time.perf_counter() - t0
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
         res = np.frombuffer(self.d_res.cpu().numpy().tobytes(), dtype=self.pkg.RESULT_DTYPE)
+        try:
+            self.launch_info = self.eng.last_launch_info()
+        except Exception:  # noqa: BLE001
+            self.launch_info = None
         return elapsed, kernel_ms, res
 
     def pipelined(self, steps, S):
@@ -275,7 +279,7 @@ def counters_for(workload):
         return None
 
 
-def roofline_block(pkg, wl, res, kernel_ms, world):
+def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None):
     N, M_of = wl.N, wl.M_of
     alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
@@ -318,7 +322,8 @@ def roofline_block(pkg, wl, res, kernel_ms, world):
             "traffic_is": "bytes crossing the L2 <-> fabric boundary per launch (Infinity Cache + HBM; the counters cannot "
                           "tell the two apart: profiles/r03_traffic_calibration.json), from the counter passes of the same "
                           "command — a static file, not this run",
-            "kernel": "k_solve", "kernel_ms": kernel_ms,
+            "kernel": ("k_solve_grp" if (launch_info or {}).get("trajectories_per_wavefront", 1) > 1 else "k_solve"),
+            "launch": launch_info, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",
             "valu_issue": valu,
@@ -565,6 +570,7 @@ def main():
     N = wl.N
     run = GpuRun(pkg, torch, wl, B, local_rank)
     elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier)
+    launch_info_main = getattr(run, "launch_info", None)
     stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, red_dev)
     value = stats[0] * args.steps / tmax
     # every rank's own clock and kernel time: a straggler rank (or a GPU that throttles) is visible in the line
@@ -586,6 +592,7 @@ def main():
                                           wl_s.scenes, wl_s.x0, wl_s.scenario_id, wl_s.param_id, wl_s.tick)
         run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
         el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier)
+        li_s = getattr(run_s, "launch_info", None)
         st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, red_dev)
         chk = None
         if rank == 0 and cpu_check_rows and not args.no_cpu_baseline:
@@ -595,7 +602,7 @@ def main():
         pr_s = gather_objects(dist, kms_s, world)
         if rank != 0:
             return None
-        rl = roofline_block(pkg, wl_s, res_s, kms_s, world)
+        rl = roofline_block(pkg, wl_s, res_s, kms_s, world, li_s)
         cpu_chk = None
         if chk is not None:  # the launch that was just timed against the oracle's libm build (checker only)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -619,7 +626,7 @@ def main():
                 "iterations_per_launch_rank0": float(res_s["iters"].sum()),
                 "slowest_trajectory_iterations": int(res_s["iters"].max()),
                 "converged": int(st_s[2]), "max_lamb": int(st_s[3]), "max_iter": int(st_s[4]), "nan_costs": int(st_s[6]),
-                "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "fp64_useful": rl["fp64_useful"],
+                "kernel": rl["kernel"], "launch": rl["launch"], "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "fp64_useful": rl["fp64_useful"],
                 "note": note}
 
     def closed_loop_extra():
@@ -678,7 +685,7 @@ def main():
             "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B,
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
                        "parallelism": f"trajectory-sharded x{world}, one wavefront per trajectory"},
-            "roofline": roofline_block(pkg, wl, res, kernel_ms, world),
+            "roofline": roofline_block(pkg, wl, res, kernel_ms, world, launch_info_main),
             "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
                       "line_search_trials_per_step": float(stats[1]),
                       "solves_per_s": stats[8] * args.steps / tmax,

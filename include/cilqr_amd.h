@@ -197,6 +197,9 @@ int cilqr_closed_loop_batch_device(cilqr_handle* h, int32_t B, int32_t ticks, do
 
 /* Wall time of the most recent solve kernel measured with HIP events on its own stream (ms). */
 int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
+/* Shape of the most recent fused launch: out = { trajectories per wavefront (1: k_solve, 2 or 3: k_solve_grp), blocks in the
+ * grid, threads per block (128 = main + helper wavefront), lane-window samples in LDS }. */
+int cilqr_last_launch_info(cilqr_handle* h, int32_t out[4]);
 /* When enabled, every cilqr_solve_batch*_ call brackets its kernel with HIP events. */
 int cilqr_set_timing(cilqr_handle* h, int32_t enabled);
 

@@ -101,6 +101,18 @@ def disassemble(co, symbol):
     return ins
 
 
+def device_functions(co, patterns=("grp_", "rollout_group")):
+    """the out-of-line device functions of the grouped build (no kernel descriptor: names from the symbol table)"""
+    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--symbols", "--wide", co], check=True, text=True,
+                         capture_output=True).stdout
+    syms = []
+    for ln in txt.splitlines():
+        f = ln.split()
+        if len(f) >= 8 and f[3] == "FUNC" and f[6] != "UND":
+            syms.append(f[7])
+    return sorted({s_ for s_ in syms if any(p_ in s_ for p_ in patterns) and not s_.endswith(".kd") and "k_solve" not in s_})
+
+
 def is_fp64_valu(op):
     return op.startswith("v_") and "_f64" in op
 
@@ -243,6 +255,26 @@ def main():
                     }
                     rec["innermost_loops"] = loop_report(ins)
             out["kernels"].append(rec)
+        # the grouped build's phases are functions of their own (cilqr_group.hpp): instructions, scratch accesses (their
+        # prologue / epilogue save callee-saved registers) and what their innermost loops hold
+        out["functions"] = []
+        if a.loops or a.markdown:
+            for co in cos:
+                syms = device_functions(co)
+                names = demangle(syms)
+                for sy in syms:
+                    ins = disassemble(co, sy)
+                    ops = [op for (_, op, _) in ins]
+                    if not ops:
+                        continue
+                    vmax = 0
+                    for (_, _, rest) in ins:
+                        pass
+                    out["functions"].append({
+                        "function": names[sy].split("(")[0], "instructions": len(ops),
+                        "scratch": sum(1 for o in ops if o.startswith("scratch_")),
+                        "readlane_writelane": sum(1 for o in ops if o.startswith("v_readlane") or o.startswith("v_writelane")),
+                        "innermost_loops": loop_report(ins)})
     if a.markdown:
         print("| build of `k_solve` | VGPR | VGPR spills | SGPR spills | scratch B | instructions | backward step: instr / scratch / lane moves | rollout loops: count, scratch / lane moves inside |")
         print("|---|---|---|---|---|---|---|---|")

@@ -226,3 +226,15 @@ def test_register_budget_of_the_shipped_kernels(pkg, tmp_path):
         for lp in k["innermost_loops"]:
             if lp["kind"] == "backward_step" and "rows/lane=1" in k["variant"]:
                 assert lp["scratch"] == 0, (k["variant"], lp)   # (the two-row builds: see DESIGN.md's table)
+    # round 4: the grouped build (two trajectories per wavefront) — the kernel itself is control flow (no spilled vector
+    # registers to speak of), its phases are functions of their own whose loops never touch scratch
+    grp = [k for k in ks if k["variant"].startswith("grouped: 2") and "N=50" in k["variant"]]
+    assert len(grp) == 1 and grp[0]["vgpr_spills"] <= 8, grp
+    fns = {f["function"]: f for f in json.load(open(out))["functions"]}
+    for name in ("cilqr::grp_expand_backward<50, 2>", "cilqr::grp_cost_trial<50, 2>", "cilqr::grp_cost_trials2<50, 2>",
+                 "cilqr::rollout_group<2, 0, true>"):
+        hit = [f for n, f in fns.items() if n.endswith(name)]
+        assert len(hit) == 1, (name, sorted(fns))
+        assert all(lp["scratch"] == 0 for lp in hit[0]["innermost_loops"]), (name, hit[0]["innermost_loops"])
+    sweep = [f for n, f in fns.items() if n.endswith("cilqr::grp_expand_backward<50, 2>")][0]
+    assert any(lp["kind"] == "backward_step" and lp["instructions"] <= 160 for lp in sweep["innermost_loops"]), sweep

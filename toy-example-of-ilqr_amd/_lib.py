@@ -112,6 +112,7 @@ SIGNATURES = {
     "cilqr_set_debug_flags": (C.c_int, [_P, _I]),
     "cilqr_set_helper_mode": (C.c_int, [_P, _I]),
     "cilqr_set_group_mode": (C.c_int, [_P, _I]),
+    "cilqr_last_launch_info": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "cilqr_set_rollout_mode": (C.c_int, [_P, _I]),
     "cilqr_set_work_sharing": (C.c_int, [_P, _I]),
     "cilqr_work_sharing_stats": (C.c_int, [_P, _P]),

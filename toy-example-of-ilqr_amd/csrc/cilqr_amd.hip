@@ -343,6 +343,7 @@ struct cilqr_handle {
     DevBuf tl;
     int tl_B = 0;
     bool last_launch_shared = false;
+    int last_info[4] = {0, 0, 0, 0}; // cilqr_last_launch_info
     bool last_launch_reset_ctl = false; // the last fused launch zeroed the control words (persistent blocks): its counters are its own
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
     // resumable solves (k_solve's RES: the two-row builds in persistent launches): iterations per slice, 0 = off.  A
@@ -714,6 +715,12 @@ extern "C" int cilqr_last_kernel_ms(cilqr_handle* h, float* ms) {
         h->timed_pending = false;
     }
     *ms = h->last_ms;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_last_launch_info(cilqr_handle* h, int32_t out[4]) {
+    if (!h || !out) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) out[i] = h->last_info[i];
     return CILQR_OK;
 }
 
@@ -1219,6 +1226,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kg, dim3(grid), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out, d_res_out, d_trace_out,
                            d_trace_out ? trace_cap : 0);
+        h->last_info[0] = G; h->last_info[1] = grid; h->last_info[2] = CILQR_WAVE; h->last_info[3] = a.W;
     } else {
         const bool two = (a.N + 1 > CILQR_WAVE);
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
@@ -1332,6 +1340,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+        h->last_info[0] = 1; h->last_info[1] = grid; h->last_info[2] = helped ? 2 * CILQR_WAVE : CILQR_WAVE; h->last_info[3] = a.W;
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) {

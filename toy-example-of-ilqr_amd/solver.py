@@ -180,6 +180,13 @@ class BatchedCILQR:
         """-1 automatic, 0 one wavefront per trajectory, 1 main + helper wavefront"""
         self._check(self._lib.cilqr_set_helper_mode(self._h, int(mode)), "cilqr_set_helper_mode")
 
+    def last_launch_info(self):
+        """shape of the most recent fused launch: trajectories per wavefront, grid blocks, threads per block, window samples"""
+        out = (C.c_int32 * 4)()
+        self._check(self._lib.cilqr_last_launch_info(self._h, out), "cilqr_last_launch_info")
+        return {"trajectories_per_wavefront": int(out[0]), "blocks": int(out[1]), "threads_per_block": int(out[2]),
+                "lane_window_samples": int(out[3])}
+
     def set_group_mode(self, mode):
         """-1 automatic, 0 / 1 one trajectory per wavefront, 2 two per wavefront wherever that build can run"""
         self._check(self._lib.cilqr_set_group_mode(self._h, int(mode)), "cilqr_set_group_mode")
