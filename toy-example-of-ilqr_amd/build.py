@@ -37,7 +37,7 @@ def hipcc_path():
 
 def _deps():
     return [CSRC / "cilqr_amd.hip", CSRC / "cilqr_solve_inst.hip", CSRC / "scenario.cpp", CSRC / "cilqr_kernels.hpp",
-            CSRC / "cilqr_device.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
+            CSRC / "cilqr_device.hpp", CSRC / "cilqr_group.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
             pathlib.Path(__file__)]  # the flags live in this file
 
 

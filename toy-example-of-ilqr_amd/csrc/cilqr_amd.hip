@@ -366,6 +366,7 @@ struct cilqr_handle {
     int group_mode = -1;       // trajectories per wavefront in the large-batch launches of horizons up to 63, barrier mode
                                // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
     int win_grp = 0;           // lane window of those launches
+    int group_dual_probe = 0;  // development probe (CILQR_TUNE=grp_dual_probe=1)
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
     int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
     int prof_B = 0;
@@ -515,6 +516,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "prof2") h->prof_two_per_simd = v;
                 else if (k == "group_steal") h->group_steal = v;
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
+                else if (k == "grp_dual_probe") h->group_dual_probe = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -1032,6 +1034,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.loop_states = nullptr;
     a.loop_iters = nullptr;
     a.pair_costs = h->group_pair_costs;
+    a.dual_probe = h->group_dual_probe;
     return a;
 }
 

@@ -189,6 +189,211 @@ __device__ inline void carve_group(Lds& l, double* base, int N, int G, int g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward_sweep_lanes (cilqr_device.hpp) for NS trajectories AT ONCE: the same step body, once per trajectory, on register
+// sets of its own inside one loop, so that the wavefront has NS independent dependent chains to issue from (a step of one
+// sweep is ~145 instructions on one chain: W gather, two 4-term passes, the 2 x 2 inverse with its IEEE division, the rank-2
+// update — a lone wavefront keeps its SIMD half busy with it).  Every element is the expression backward_sweep_lanes
+// evaluates, in its order: same bits.  base[s] = the trajectory's Lds::x (its arrays are addressed relative to it, as in
+// make_lane_map), gains[s] = where its gains go (global memory), alive: a sweep that meets a non-PD Q_uu (cs:415-420) stops
+// there — its later steps keep their Jacobians, as in the one-trajectory form — while the others go on.
+// Returns the mask of the sweeps that completed.  (A sweep that fails — non-PD Q_uu, cs:415-420 — is only marked.)
+template <int NS>
+__device__ inline unsigned backward_sweep_lanes_multi(const Cst* c, const Lds* l, const double* lamb, int lane, double (*dV)[2],
+                                                      double* const* gains) {
+    const int N = c[0].N; // (one horizon per handle)
+    const int rp = (lane >> 3) % 6, cc = lane & 7;
+    LaneMap mp[NS];
+    __amdgpu_buffer_rsrc_t ggr[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        make_lane_map<false>(l[s], lane, mp[s]);
+        if (lane == 0) {
+            l[s].xch[CILQR_XCH_CONST + 0] = 0.0;
+            l[s].xch[CILQR_XCH_CONST + 1] = 1.0;
+            l[s].xch[CILQR_XCH_CONST + 2] = c[s].dt;
+            l[s].xch[CILQR_XCH_CONST + 3] = 0.0;
+        }
+        ggr[s] = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(gains[s]), 0, N * CILQR_KD * (int)sizeof(double), 0x00020000);
+    }
+    wave_sync();
+    const int wc = (cc <= 4) ? cc : 4;
+    const bool diag = (rp >= 4) && (cc == rp);
+    const int r4 = rp & 3;
+    const int src_c0 = 32 + wc, src_c1 = 40 + wc;
+    const int src_r0 = (rp >= 4) ? 36 : 32 + r4, src_r1 = (rp >= 4) ? 44 : 40 + r4;
+    const double krf = (rp == 4) ? 0.5 : 1.0;
+    double wn[NS], dvacc[NS];
+    unsigned am1[NS][4], am2[NS][4], alq[NS], alv[NS];
+    unsigned dm1[NS][4], dm2[NS][4], dlq[NS], dlv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double* const base = l[s].x;
+        wn[s] = (cc < 4) ? base[mp[s].lq + mp[s].slq * N] : base[mp[s].lv + mp[s].slv * N];
+        dvacc[s] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            am1[s][k] = lds_addr(base + mp[s].m1[k] + mp[s].s1[k] * (N - 1));
+            am2[s][k] = lds_addr(base + mp[s].m2[k] + mp[s].s2[k] * (N - 1));
+            dm1[s][k] = 8u * (unsigned)mp[s].s1[k];
+            dm2[s][k] = 8u * (unsigned)mp[s].s2[k];
+        }
+        alq[s] = lds_addr(base + mp[s].lq + mp[s].slq * (N - 1));
+        alv[s] = lds_addr(base + mp[s].lv + mp[s].slv * (N - 1));
+        dlq[s] = 8u * (unsigned)mp[s].slq;
+        dlv[s] = 8u * (unsigned)mp[s].slv;
+    }
+    // One straight-line block per step: phase by phase over the sweeps, so that the scheduler can interleave their chains.  A
+    // sweep whose Q_uu turns out not to be positive definite is only MARKED: it keeps running on whatever numbers it has (its
+    // gains are never used: the iteration ends as BACKWARD_PASS_FAIL and expands afresh; no address leaves its arrays), which
+    // keeps the loop free of per-sweep control flow.  The exact pivot test (sqrt, quotient) is one rare branch for all sweeps.
+    unsigned failed = 0u;
+    for (int i = N - 1; i >= 0; --i) {
+        double Q[NS], Zv[NS], S[NS], c0[NS], c1[NS], r0[NS], r1[NS], invdet[NS], Quu0[NS], Quu1[NS], Quu2[NS], Quu3[NS];
+        double m1[NS][4], m2[NS][4], Lq[NS], lv[NS], w0[NS], w1[NS], w2[NS], w3[NS], X[NS], Xq[NS];
+        unsigned need_exact = 0u;
+        int ccv = cc;
+        __asm__("" : "+v"(ccv));
+        // (sub-phase by sub-phase over the sweeps — written out in the order the chains should be issued: every LDS round
+        //  trip of one sweep in flight together with the other's)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m1[s][k] = lds_load(am1[s][k]);
+                m2[s][k] = lds_load(am2[s][k]);
+                am1[s][k] -= dm1[s][k];
+                am2[s][k] -= dm2[s][k];
+            }
+            Lq[s] = lds_load(alq[s]);
+            lv[s] = lds_load(alv[s]);
+            alq[s] -= dlq[s];
+            alv[s] -= dlv[s];
+            w0[s] = lane_gather(wn[s], wc); w1[s] = lane_gather(wn[s], 8 + wc);
+            w2[s] = lane_gather(wn[s], 16 + wc); w3[s] = lane_gather(wn[s], 24 + wc);
+        }
+        // (statement by statement over the sweeps: consecutive instructions belong to different chains)
+#define EACH_S for (int s = 0; s < NS; ++s)
+        double tX[NS], x0[NS], x1[NS], x2[NS], x3[NS], tY[NS], det[NS];
+#pragma unroll
+        EACH_S tX[s] = m1[s][0] * w0[s];
+#pragma unroll
+        EACH_S tX[s] = CQ_MADD(m1[s][1], w1[s], tX[s]);
+#pragma unroll
+        EACH_S tX[s] = CQ_MADD(m1[s][2], w2[s], tX[s]);
+#pragma unroll
+        EACH_S X[s] = CQ_MADD(m1[s][3], w3[s], tX[s]);
+#pragma unroll
+        EACH_S Zv[s] = lv[s] + X[s];
+#pragma unroll
+        EACH_S Xq[s] = dpp_move_banks<0x114, 0xA>(X[s]);
+#pragma unroll
+        EACH_S x0[s] = dpp_move<0x00>(Xq[s]);
+#pragma unroll
+        EACH_S x1[s] = dpp_move<0x55>(Xq[s]);
+#pragma unroll
+        EACH_S x2[s] = dpp_move<0xAA>(Xq[s]);
+#pragma unroll
+        EACH_S x3[s] = dpp_move<0xFF>(Xq[s]);
+#pragma unroll
+        EACH_S tY[s] = x0[s] * m2[s][0];
+#pragma unroll
+        EACH_S tY[s] = CQ_MADD(x1[s], m2[s][1], tY[s]);
+#pragma unroll
+        EACH_S tY[s] = CQ_MADD(x2[s], m2[s][2], tY[s]);
+#pragma unroll
+        EACH_S tY[s] = CQ_MADD(x3[s], m2[s][3], tY[s]);
+#pragma unroll
+        EACH_S Q[s] = Lq[s] + tY[s];
+#pragma unroll
+        EACH_S { if (diag) Q[s] = Q[s] + lamb[s]; }
+#pragma unroll
+        EACH_S S[s] = (ccv == 4) ? Zv[s] : Q[s];
+#pragma unroll
+        EACH_S { c0[s] = lane_gather(S[s], src_c0); c1[s] = lane_gather(S[s], src_c1); }
+#pragma unroll
+        EACH_S { r0[s] = lane_gather(S[s], src_r0); r1[s] = lane_gather(S[s], src_r1); }
+#pragma unroll
+        EACH_S { Quu0[s] = lane_bcast<36>(Q[s]); Quu1[s] = lane_bcast<37>(Q[s]); Quu2[s] = lane_bcast<44>(Q[s]); Quu3[s] = lane_bcast<45>(Q[s]); }
+#pragma unroll
+        EACH_S det[s] = Quu0[s] * Quu3[s] - Quu2[s] * Quu1[s];
+#pragma unroll
+        EACH_S invdet[s] = 1.0 / det[s];
+#pragma unroll
+        EACH_S {
+            const unsigned h0 = (unsigned)(dm_to_bits(Quu0[s]) >> 32), h3 = (unsigned)(dm_to_bits(Quu3[s]) >> 32);
+            const bool ordinary = ((h0 - 0x2B300000u) < 0x29800000u) && ((h3 - 0x2B300000u) < 0x29800000u);
+            const bool surely_pd = ordinary && (Quu0[s] * Quu3[s] > (Quu2[s] * Quu2[s]) * 1.0000000000009095);
+            if (!surely_pd) need_exact |= (1u << s);
+        }
+        if (need_exact != 0u) { // Eigen::LLT's verdict evaluated exactly (see backward_sweep_lanes)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!(need_exact & (1u << s)) || (failed & (1u << s))) continue;
+                bool fail = false;
+                if (Quu0[s] <= 0.0) {
+                    fail = true;
+                } else {
+                    double l00 = dm_sqrt(Quu0[s]);
+                    double l10 = Quu2[s] / l00;
+                    double piv1 = Quu3[s] - l10 * l10;
+                    if (piv1 <= 0.0) fail = true;
+                }
+                if (fail) failed |= (1u << s);
+            }
+            if (failed == (1u << NS) - 1u) break; // nobody left
+        }
+        double kc0[NS], kc1[NS], n00[NS], n01[NS], n10[NS], n11[NS], kr0[NS], kr1[NS], p0[NS], p1[NS], ta[NS], tb[NS], tc[NS];
+        int rpv = rp;
+        __asm__("" : "+v"(rpv));
+#pragma unroll
+        EACH_S { n00[s] = -(Quu3[s] * invdet[s]); n01[s] = -(-Quu1[s] * invdet[s]); n10[s] = -(-Quu2[s] * invdet[s]); n11[s] = -(Quu0[s] * invdet[s]); }
+#pragma unroll
+        EACH_S { kc0[s] = n00[s] * c0[s]; kc1[s] = n10[s] * c0[s]; kr0[s] = n00[s] * r0[s]; kr1[s] = n10[s] * r0[s]; }
+#pragma unroll
+        EACH_S { kc0[s] = CQ_MADD(n01[s], c1[s], kc0[s]); kc1[s] = CQ_MADD(n11[s], c1[s], kc1[s]);
+                 kr0[s] = CQ_MADD(n01[s], r1[s], kr0[s]); kr1[s] = CQ_MADD(n11[s], r1[s], kr1[s]); }
+#pragma unroll
+        EACH_S { kr0[s] = kr0[s] * krf; kr1[s] = kr1[s] * krf; }
+#pragma unroll
+        EACH_S { p0[s] = kr0[s] * Quu0[s]; p1[s] = kr0[s] * Quu1[s]; tb[s] = kr0[s] * c0[s]; tc[s] = r0[s] * kc0[s]; }
+#pragma unroll
+        EACH_S { p0[s] = CQ_MADD(kr1[s], Quu2[s], p0[s]); p1[s] = CQ_MADD(kr1[s], Quu3[s], p1[s]);
+                 tb[s] = CQ_MADD(kr1[s], c1[s], tb[s]); tc[s] = CQ_MADD(r1[s], kc1[s], tc[s]); }
+#pragma unroll
+        EACH_S ta[s] = p0[s] * kc0[s];
+#pragma unroll
+        EACH_S ta[s] = CQ_MADD(p1[s], kc1[s], ta[s]);
+#pragma unroll
+        EACH_S { const double own = (ccv < 4) ? Q[s] : Zv[s]; wn[s] = own + ta[s]; }
+#pragma unroll
+        EACH_S wn[s] = wn[s] + tb[s];
+#pragma unroll
+        EACH_S wn[s] = wn[s] + tc[s];
+#pragma unroll
+        EACH_S dvacc[s] = dvacc[s] + ((rpv == 4) ? ta[s] : tb[s]);
+#undef EACH_S
+        int lanev = lane;
+        __asm__("" : "+v"(lanev));
+        if (lanev < 5) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc0[s]), ggr[s], 8u * (unsigned)lane, i * (CILQR_KD * 8), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc1[s]), ggr[s], 8u * (unsigned)lane + 8u * CILQR_KD_ROW,
+                                                      i * (CILQR_KD * 8), 0);
+            }
+        }
+    }
+    const unsigned alive = ((1u << NS) - 1u) & ~failed;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        dV[s][0] = lane_bcast<36>(dvacc[s]);
+        dV[s][1] = lane_bcast<44>(dvacc[s]);
+    }
+    wave_sync();
+    return alive;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Expansion + backward sweep of the trajectory in slot g (cs:463-690, cs:383-440), OUT OF LINE: everything it needs is in
 // LDS (x, u, lane indices, constants) or an argument, everything it produces goes to LDS (Jacobians, expansion — consumed
 // inside —, the expected cost reduction) or global memory (the gains), so the call carries nothing and the sweep's serial
@@ -197,7 +402,7 @@ __device__ inline void carve_group(Lds& l, double* base, int N, int G, int g) {
 // prof: development library, cycle accounting (PH_DERIV = 1, PH_BACKWARD = 2, PH_TOTAL = 6 of the slot's accumulators).
 template <int NC, int G>
 __device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g, int n_rt, int lane, double lamb, double* gains,
-                                                               long long* prof) {
+                                                               long long* prof, int dual_probe = 0) {
     const int N = NC ? NC : n_rt;
     Lds l;
     carve_group(l, lds, N, G, g);
@@ -216,7 +421,22 @@ __device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g
         t0 = t1;
     }
     double dV[2];
-    const bool ok = backward_sweep_lanes<0, true>(c, l, lamb, lane, dV, nullptr, gains);
+    bool ok;
+    if (CILQR_GPROF && dual_probe) {
+        // development probe (profiles/r04_experiments): the SAME sweep twice in one loop, two independent chains — what would
+        // two trajectories' sweeps cost side by side?  (identical inputs, identical outputs, the gains stored twice)
+        const Cst c2[2] = {c, c};
+        const Lds l2[2] = {l, l};
+        const double lamb2[2] = {lamb, lamb};
+        double dV2[2][2];
+        double* const gains2[2] = {gains, gains};
+        const unsigned done = backward_sweep_lanes_multi<2>(c2, l2, lamb2, lane, dV2, gains2);
+        ok = (done & 1u) != 0u;
+        dV[0] = dV2[0][0];
+        dV[1] = dV2[0][1];
+    } else {
+        ok = backward_sweep_lanes<0, true>(c, l, lamb, lane, dV, nullptr, gains);
+    }
     if (lane == 0) {
         GrpSt* st = grp_state(lds, N, g);
         st->dV0 = dV[0];

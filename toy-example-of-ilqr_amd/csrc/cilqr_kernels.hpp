@@ -62,6 +62,7 @@ struct BatchArgs {
     double* loop_states;        // optional [B][loop_ticks][4]: the ego state after every tick
     int32_t* loop_iters;        // optional [loop_ticks][B]: iterations of every tick's solve
     int pair_costs;             // grouped build: line-search trials after the first costed two per pass
+    int dual_probe;             // development probe: the backward sweep twice in one loop (CILQR_TUNE=grp_dual_probe=1)
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -880,7 +881,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         // ---- iter_step ----
                         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
                         if (prof) { GPROF_ADD(PH_TC_STAGE); }
-                        const bool ok = grp_expand_backward<NC, G>(g_lds, g, N, lane, lamb, gains, prof ? pacc : nullptr);
+                        const bool ok = grp_expand_backward<NC, G>(g_lds, g, N, lane, lamb, gains, prof ? pacc : nullptr, a.dual_probe);
                         if (prof) t_ph = (long long)__builtin_readcyclecounter(); // (booked inside)
                         status = CILQR_RUNNING;
                         dV[0] = st->dV0;
