@@ -2144,7 +2144,10 @@ __device__ inline double gl_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
 // GGAIN: the gains go to `gains` in global memory — [N][CILQR_KD] doubles, the layout of Lds::kd — instead of over the
 // step's Jacobians in LDS (the builds that hold several trajectories per wavefront keep one Jacobian array for all of
 // them; the rollout reads the gains back through L1 / L2, one step ahead)
-template <int ROWD = 0, bool GGAIN = false>
+// QLDS: the four entries of Q_uu reach every lane through ds_bpermute (the LDS crossbar, issued next to the gathers of
+// (Q_ux | Q_u) that leave at the same moment) instead of eight v_readlane: with two wavefronts per SIMD the sweep is bound by
+// the vector unit's issue slots, and these are eight of them per step.
+template <int ROWD = 0, bool GGAIN = false, bool QLDS = false>
 __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double lamb, int lane, double dV[2],
                                             int* fail_step = nullptr, double* gains = nullptr) {
     constexpr bool LG = ROWD != 0;
@@ -2190,6 +2193,8 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
     const int src_r0 = (rp >= 4) ? 36 : 32 + r4, src_r1 = (rp >= 4) ? 44 : 40 + r4;
     const double krf = (rp == 4) ? 0.5 : 1.0;
     double dvacc = 0.0; // lane 36: delta_V[0], lane 44: delta_V[1]
+    int q_src[4] = {36, 37, 44, 45};
+    if (QLDS) __asm__("" : "+v"(q_src[0]), "+v"(q_src[1]), "+v"(q_src[2]), "+v"(q_src[3]));
     // this lane's ten coefficient addresses (LDS byte addresses) walk backwards with the step
     unsigned am1[4], am2[4], dm1[4], dm2[4];
 #pragma unroll
@@ -2256,8 +2261,16 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         double Q = Lq + Y;
         if (diag) Q = Q + lamb;
         // Q_uu, Q_u on every lane; PD test and inverse (cs:415-421)
-        const double Quu0 = lane_bcast<36>(Q), Quu1 = lane_bcast<37>(Q);
-        const double Quu2 = lane_bcast<44>(Q), Quu3 = lane_bcast<45>(Q);
+        double Quu0, Quu1, Quu2, Quu3;
+        if (QLDS) {
+            // (source lanes in vector registers the optimiser cannot see through: a ds_bpermute from a constant lane would be
+            //  turned back into v_readlane)
+            Quu0 = lane_gather(Q, q_src[0]); Quu1 = lane_gather(Q, q_src[1]);
+            Quu2 = lane_gather(Q, q_src[2]); Quu3 = lane_gather(Q, q_src[3]);
+        } else {
+            Quu0 = lane_bcast<36>(Q); Quu1 = lane_bcast<37>(Q);
+            Quu2 = lane_bcast<44>(Q); Quu3 = lane_bcast<45>(Q);
+        }
         // (the lane predicates are recomputed from a vector register each step: one compare instead of the two
         //  v_readlane a spilled scalar mask costs)
         int ccv = cc;
@@ -2279,7 +2292,8 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
         {
             const unsigned h0 = (unsigned)(dm_to_bits(Quu0) >> 32), h3 = (unsigned)(dm_to_bits(Quu3) >> 32);
             const bool ordinary = ((h0 - 0x2B300000u) < 0x29800000u) && ((h3 - 0x2B300000u) < 0x29800000u);
-            const bool surely_pd = ordinary && (Quu0 * Quu3 > (Quu2 * Quu2) * 1.0000000000009095);
+            bool surely_pd = ordinary && (Quu0 * Quu3 > (Quu2 * Quu2) * 1.0000000000009095);
+            if (QLDS) surely_pd = (__ballot(!surely_pd) == 0ULL); // (every lane holds the same four numbers: make the verdict scalar)
             if (!surely_pd) {
                 if (Quu0 <= 0.0) {
                     fail = true;
@@ -2289,6 +2303,7 @@ __device__ inline bool backward_sweep_lanes(const Cst& c, const Lds& l, double l
                     double piv1 = Quu3 - l10 * l10;
                     if (piv1 <= 0.0) fail = true;
                 }
+                if (QLDS) fail = (__ballot(fail) != 0ULL);
             }
         }
         if (fail) {

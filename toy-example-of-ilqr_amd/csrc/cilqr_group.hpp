@@ -33,6 +33,10 @@ namespace cilqr {
 #define CILQR_GPROF 0
 #endif
 
+#ifndef CILQR_GRP_QLDS
+#define CILQR_GRP_QLDS false /* true: Q_uu to the lanes through the LDS crossbar instead of v_readlane — measured 1 % slower (r04_experiments) */
+#endif
+
 enum { GP_EMPTY = 0, GP_ITER = 1, GP_SEARCH = 2, GP_DONE = 3, GP_STOLEN = 4 /* b names a parked trajectory to take over */ };
 
 // the scalars cs:110-141 carries from one iteration to the next, plus where the line search stands
@@ -435,7 +439,7 @@ __device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g
         dV[0] = dV2[0][0];
         dV[1] = dV2[0][1];
     } else {
-        ok = backward_sweep_lanes<0, true>(c, l, lamb, lane, dV, nullptr, gains);
+        ok = backward_sweep_lanes<0, true, CILQR_GRP_QLDS>(c, l, lamb, lane, dV, nullptr, gains);
     }
     if (lane == 0) {
         GrpSt* st = grp_state(lds, N, g);
