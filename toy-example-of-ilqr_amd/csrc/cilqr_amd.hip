@@ -1224,6 +1224,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             a.rq = static_cast<unsigned long long*>(h->rq.p);
             HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
             a.rq_cap = h->park_B;
+            h->last_launch_shared = true; // (the host-buffer entry point then checks the launch's error word: a bounded wait that expired)
         }
         if (h->scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
@@ -1446,7 +1447,7 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     if (h->sh_ctl.p && h->last_launch_shared)
         HIP_TRY(hipMemcpyAsync(&sh_err, static_cast<unsigned*>(h->sh_ctl.p) + SH_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (sh_err) return fail(CILQR_ERR_DEVICE, "work sharing between blocks: a claimed line-search trial was not delivered in time");
+    if (sh_err) return fail(CILQR_ERR_DEVICE, "a bounded wait inside the launch expired (work sharing between blocks / trajectories handed over at the tail)");
     return CILQR_OK;
 }
 
