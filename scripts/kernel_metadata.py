@@ -101,7 +101,7 @@ def disassemble(co, symbol):
     return ins
 
 
-def device_functions(co, patterns=("grp_", "rollout_group")):
+def device_functions(co, patterns=("grp_", "rollout_group", "ool_")):
     """the out-of-line device functions of the grouped build (no kernel descriptor: names from the symbol table)"""
     txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--symbols", "--wide", co], check=True, text=True,
                          capture_output=True).stdout

@@ -11,6 +11,15 @@ using namespace cilqr;
 
 extern __shared__ double g_lds[];
 
+#ifndef CILQR_OOL_TWO_ROWS
+#define CILQR_OOL_TWO_ROWS 0 /* 1: the two-rows-per-lane large-batch builds of k_solve run their heavy phases out of line (ool_expand_sweep) — measured 1-2 % slower on configs[3] (r04_experiments): off */
+#endif
+#ifndef CILQR_OOL_SWEEP
+#define CILQR_OOL_SWEEP 1
+#endif
+#ifndef CILQR_OOL_COST
+#define CILQR_OOL_COST 1
+#endif
 #ifndef CILQR_SOLVE_WAVES_PER_SIMD
 #define CILQR_SOLVE_WAVES_PER_SIMD 1
 #endif
@@ -246,6 +255,56 @@ __device__ __attribute__((noinline)) void park_copy(double* pk, double* lx, doub
     wave_sync();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the lesson of the grouped build (cilqr_group.hpp) applied to the two-rows-per-lane builds of k_solve (horizons
+// above 63 in large batches: work sharing, resumable solves, expansion in LDS or in global memory).  Those builds carried 99
+// spilled vector registers and a scratch access inside the backward step: everything a solve keeps in registers is live across
+// its phases.  With OOL the three heavy phases — expansion + sweep, trial cost — are functions of their own that rebuild
+// what they need from LDS (the trajectory's arrays through carve(), its by-value constants from a copy parked in the unused
+// cycle-accounting slots) and a handful of arguments, and hand their results back through LDS.  Same device functions, same
+// bits.
+template <int NCH, int NC, bool LG>
+__device__ __attribute__((noinline)) bool ool_expand_sweep(double* lds, int n_rt, int Wcap, double* gl, int w0, int Wcur, double lamb,
+                                                            int lane, int expand) {
+    const int N = NC ? NC : n_rt;
+    Lds l;
+    carve(l, lds, N, Wcap, 0, 1, LG ? 1 : 0);
+    l.gl = gl;
+    l.w0 = w0;
+    l.W = Wcur;
+    Cst c;
+    load_cst_lds(c, reinterpret_cast<const Cst*>(l.prof));
+    AlmSt al;
+    al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    if (expand) cost_and_model_derivatives<false, LG>(c, l, al, lane);
+    else model_jacobians(c, l, lane); // (cs:469-475: the expansion of the unchanged trajectory is kept)
+    double dV[2];
+    const bool ok = backward_sweep_lanes<LG ? CILQR_GL_ROW : 0>(c, l, lamb, lane, dV);
+    wave_sync();
+    if (lane == 0) { l.ctld[CTLD_DV] = dV[0]; l.ctld[CTLD_DV + 1] = dV[1]; }
+    wave_sync();
+    return ok;
+}
+template <int NCH, int NC, bool LG>
+__device__ __attribute__((noinline)) double ool_cost_trial(double* lds, int n_rt, int Wcap, int w0, int Wcur, const double* src, int t,
+                                                            int as, int idx0, int lane) {
+    const int N = NC ? NC : n_rt;
+    Lds l;
+    carve(l, lds, N, Wcap, 0, 1, LG ? 1 : 0);
+    l.w0 = w0;
+    l.W = Wcur;
+    Cst c;
+    load_cst_lds(c, reinterpret_cast<const Cst*>(l.prof));
+    AlmSt al;
+    al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    int nfb = 0;
+    double J1[1];
+    total_cost_trials<false, NCH, false, 1>(c, l, al, src, t, 1, lane, idx0, 0, &nfb, J1, nullptr, 0, as);
+    if (nfb != 0 && lane == 0) l.ctli[7] += nfb;
+    return J1[0];
+}
+
 // what solve_one returns besides a finished solve's iteration count
 enum { SOLVE_PARKED = -1 /* parked again: its number has been queued */, SOLVE_BAD_INPUT = -2 };
 
@@ -268,6 +327,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
     static_assert(!LOOP || (!RES && !SHARE && !PROF), "closed loop: plain builds");
     const bool res_on = RES && a.park != nullptr;
     const bool share = SHARE && a.sh_ctl != nullptr;
+    // the heavy phases out of line (see ool_expand_sweep): the two-rows-per-lane barrier builds of the large batches
+    constexpr bool OOL = CILQR_OOL_TWO_ROWS && NCH == 2 && !DBG && !ALM && !HELP && !PROF && !LOOP && NTP == 1;
     const int N = NC ? NC : a.N; // one horizon per handle
     if (!ids_valid<LOOP>(a, b)) { // wave-uniform, before the wavefronts of a helper-mode block part ways
         if (share || res_on) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
@@ -290,6 +351,10 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
     Cst c;
     load_cst<LOOP>(c, a, b, l, lane);
     if (NC) c.N = NC;
+    if (OOL) {
+        if (lane == 0) { *reinterpret_cast<Cst*>(l.prof) = c; l.ctli[7] = 0; }
+        wave_sync();
+    }
     double* scr = a.scratch + (size_t)slot * scratch_doubles(N);
     if (LG) l.gl = scr + scratch_gl_offset(N);
     double* first = scr + slab_doubles(N); // the first-trial buffer
@@ -432,7 +497,17 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed (barrier mode)
         if (ALM) J_cur = total_cost_lds<ALM>(c, l, al, lane); // the multipliers may have moved since
         // cs:469-475: in barrier mode the expansion of the unchanged trajectory is kept after a failed pass
-        if (ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP || (RES && fresh_expansion)) {
+        const bool expand = ALM || status == CILQR_RUNNING || status == CILQR_FORWARD_PASS_SMALL_STEP || (RES && fresh_expansion);
+        double dV[2];
+        bool ok;
+        if (OOL && CILQR_OOL_SWEEP) {
+            ok = ool_expand_sweep<NCH, NC, LG>(g_lds, N, a.W, l.gl, l.w0, l.W, lamb, lane, expand ? 1 : 0);
+            dV[0] = l.ctld[CTLD_DV];
+            dV[1] = l.ctld[CTLD_DV + 1];
+            status = CILQR_RUNNING;
+            if (RES) fresh_expansion = false;
+        } else {
+        if (expand) {
             // (resumed after a failed pass: the same trajectory expanded again — the same bits as the kept expansion)
             cost_and_model_derivatives<ALM, LG>(c, l, al, lane);
         } else {
@@ -441,10 +516,10 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
         PROF_ADD(PH_DERIV);
         status = CILQR_RUNNING;
         if (RES) fresh_expansion = false;
-        double dV[2];
-        bool ok = backward_sweep<(DBG && !ALM), LG ? (ALM ? CILQR_GL_ROW_ALM : CILQR_GL_ROW) : 0>(c, l, lamb, lane, dV, a.flags);
+        ok = backward_sweep<(DBG && !ALM), LG ? (ALM ? CILQR_GL_ROW_ALM : CILQR_GL_ROW) : 0>(c, l, lamb, lane, dV, a.flags);
         wave_sync();
         PROF_ADD(PH_BACKWARD);
+        }
         double new_J = J_cur;
         int trials = 0, alpha_idx = -1;
         if (!ok) {
@@ -504,6 +579,8 @@ __device__ __forceinline__ int solve_one(const BatchArgs& a, const int b, const 
                 }
                 if (SHARE && foreign) {
                     // nothing to compute
+                } else if (OOL && CILQR_OOL_COST) {
+                    Jp[0] = ool_cost_trial<NCH, NC, LG>(g_lds, N, a.W, l.w0, l.W, src, t0, as, idx0, lane);
                 } else if (HELP || nt == 1) {
                     double J1[1];
                     total_cost_trials<DBG, NCH, ALM, 1>(c, l, al, src, t0, 1, lane, idx0, a.flags, &n_fallback, J1,
