@@ -10,7 +10,7 @@ fi
 for rep in $(seq $REPS); do
   for m in $MODES; do
     for c in $CFGS; do
-      if [ $m = single ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=group=0; elif [ $m = triples ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=group=3; elif [ $m = tune ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=$TUNE; else unset CILQR_AMD_LIB CILQR_TUNE; fi
+      if [ $m = single ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=group=0; elif [ $m = triples ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=group=3; elif [ $m = g1 ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=group=4; elif [ $m = tune ]; then export CILQR_AMD_LIB=$ROOT/toy-example-of-ilqr_amd/libcilqr_amd_dev.so CILQR_TUNE=$TUNE; else unset CILQR_AMD_LIB CILQR_TUNE; fi
       timeout 300 python bench.py --config $c --steps $STEPS --warmup 2 --no-cpu-baseline --no-extras 2>>"$OUT/err.log" | python -c "
 import json,sys
 for l in sys.stdin:

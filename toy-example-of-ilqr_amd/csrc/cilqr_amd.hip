@@ -384,6 +384,7 @@ struct cilqr_handle {
 // Persistent launches use one scratch area per resident block: never more than this many per CU, whatever the
 // occupancy query says (8 = two wavefronts per SIMD; ensure_scratch sizes the areas with the same number)
 #define CILQR_MAX_BLOCKS_PER_CU 8
+#define CILQR_MAX_BLOCKS_PER_CU_G1 8
 #define CILQR_GROUP_MAX 3 /* trajectories per wavefront of the grouped builds (k_solve_grp): 2 or 3 */
 static int grp_n(const cilqr_handle* h); // (2 unless cilqr_set_group_mode asked for 3)
 static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out) {
@@ -391,7 +392,7 @@ static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out
         if (e.kern == kern && e.shm == shm) { *out = e.per_cu; return CILQR_OK; }
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CILQR_WAVE, shm));
-    per_cu = per_cu < 1 ? 1 : (per_cu > CILQR_MAX_BLOCKS_PER_CU ? CILQR_MAX_BLOCKS_PER_CU : per_cu);
+    per_cu = per_cu < 1 ? 1 : (per_cu > CILQR_MAX_BLOCKS_PER_CU_G1 ? CILQR_MAX_BLOCKS_PER_CU_G1 : per_cu);
     h->occ.push_back({kern, shm, per_cu});
     *out = per_cu;
     return CILQR_OK;
@@ -438,7 +439,7 @@ static void update_window(cilqr_handle* h) {
     {
         // the grouped builds: the window shares the expansion's area (cilqr_group.hpp), so it is free up to that size and
         // otherwise bounded by 8 blocks per CU
-        const long room = (long)(163840 / CILQR_MAX_BLOCKS_PER_CU) - (long)grp_lds_bytes(N, 0, grp_n(h)) +
+        const long room = (long)(163840 / (grp_n(h) == 1 ? CILQR_MAX_BLOCKS_PER_CU_G1 : CILQR_MAX_BLOCKS_PER_CU)) - (long)grp_lds_bytes(N, 0, grp_n(h)) +
                           (long)sizeof(double) * grp_expansion_doubles(N);
         int wg = (int)(room / 16) / 8 * 8;
         wg = std::max(wg, grp_expansion_doubles(N) / 2 / 8 * 8);
@@ -1096,7 +1097,7 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     size_t area = scratch_doubles(N);
     if (fused && grouped(h, B)) { // (persistent blocks: one area per resident block, CILQR_GROUP trajectories in it)
         area = std::max(area, (size_t)grp_n(h) * grp_scratch_doubles(N));
-        areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU * (size_t)h->num_cus);
+        areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU_G1 * (size_t)h->num_cus);
     }
     if (h->scratch.ensure(sizeof(double) * area * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");

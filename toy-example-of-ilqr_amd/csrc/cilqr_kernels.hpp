@@ -831,7 +831,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
 //                yield [t0 = 1]; verdict reached or all 20 rejected: back in solve (cs:113-141), then GP_ITER or done
 // A trajectory that ends is replaced at once (pull, initial trajectory, first expansion) inside the same segment.
 template <int NC, int G>
-__global__ void __launch_bounds__(CILQR_WAVE, 2)
+__global__ void __launch_bounds__(CILQR_WAVE, G == 1 ? 3 : 2)
 k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, double* u_out, double* __restrict__ x_out,
             cilqr_result* __restrict__ res_out, cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
@@ -988,10 +988,10 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         const double* src = have_all ? scr : first;
                         const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
                         // past the first trial the costs come two per pass (the searches that get here mostly go on)
-                        const int nt = (a.pair_costs && have_all && t0 >= 1 && t0 + 1 < CILQR_MAX_ALPHA_TRIALS) ? 2 : 1;
+                        const int nt = (G > 1 && a.pair_costs && have_all && t0 >= 1 && t0 + 1 < CILQR_MAX_ALPHA_TRIALS) ? 2 : 1; // (G = 1: three wavefronts per SIMD, 168 VGPRs — the paired form needs 208)
                         double Jp[2];
-                        if (nt == 2) {
-                            Jp[0] = grp_cost_trials2<NC, G>(g_lds, g, N, lane, src, t0, l.w0, l.W);
+                        if (G > 1 && nt == 2) {
+                            Jp[0] = grp_cost_trials2<NC, (G > 1 ? G : 2)>(g_lds, g, N, lane, src, t0, l.w0, l.W);
                             Jp[1] = st->J_pair;
                         } else {
                             Jp[0] = grp_cost_trial<NC, G>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
