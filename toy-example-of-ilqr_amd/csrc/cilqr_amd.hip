@@ -25,6 +25,8 @@ extern template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -366,6 +368,7 @@ struct cilqr_handle {
     int group_mode = -1;       // trajectories per wavefront in the large-batch launches of horizons up to 63, barrier mode
                                // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
     int win_grp = 0;           // lane window of those launches
+    int group_loop = 1;        // the closed loop in one launch runs the grouped build too (0: k_solve's LOOP builds)
     int group_dual_probe = 0;  // development probe (CILQR_TUNE=grp_dual_probe=1)
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
     int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
@@ -518,6 +521,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "group_steal") h->group_steal = v;
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
                 else if (k == "grp_dual_probe") h->group_dual_probe = v;
+                else if (k == "group_loop") h->group_loop = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -984,7 +988,8 @@ static bool global_expansion(const cilqr_handle* h, int B) {
 // Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
 static bool grouped(const cilqr_handle* h, int B) {
     if (h->group_mode == 0 || h->group_mode == 1) return false;
-    if (h->params[0].solve_type == 1 || two_rows(h) || h->looping || h->debug_flags != 0) return false;
+    if (h->params[0].solve_type == 1 || two_rows(h) || h->debug_flags != 0) return false;
+    if (h->looping && (!h->group_loop || h->profiling)) return false; // (closed loop in one launch: the LOOP builds of k_solve_grp)
     if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
     if (!h->persistent_blocks) return false;
     if (h->group_mode >= 2) return true;
@@ -1205,11 +1210,12 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         h->tl_B = B;
     }
     if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
-    if (loop.ticks < 1 && grouped(h, B)) {
+    if (grouped(h, B)) {
         // CILQR_GROUP trajectories per wavefront, one rollout pass for all of them (cilqr_group.hpp): persistent blocks
-        const int G = grp_n(h);
+        const int G = (loop.ticks >= 1) ? 2 : grp_n(h);
         auto kg = (a.N == 50) ? k_solve_grp<50, 2> : k_solve_grp<0, 2>;
         if (G == 3) kg = (a.N == 50) ? k_solve_grp<50, 3> : k_solve_grp<0, 3>;
+        if (loop.ticks >= 1) kg = (a.N == 50) ? k_solve_grp<50, 2, true> : k_solve_grp<0, 2, true>;
         const size_t shm = grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);

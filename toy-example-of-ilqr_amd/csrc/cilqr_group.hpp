@@ -46,7 +46,8 @@ struct GrpSt {
     double J_pair; // the second cost of a paired costing pass (grp_cost_trials2)
     int b, phase, status, iters, ls_trials, cost_evals, tl, flag, deep_next, idx0, t0, have_all, trials, req, nfb, rp;
     int small_steps; // (development aid) steps of the last rollout pass that ran the straight-line small-angle form
-    int pad0, pad1, pad2;
+    int t_done;      // closed loop in one launch: ticks of this ego that are done
+    int pad1, pad2;
 };
 static_assert(sizeof(GrpSt) == 160, "GrpSt layout");
 #define CILQR_GRPST_DOUBLES 20

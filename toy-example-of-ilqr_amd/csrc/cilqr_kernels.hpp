@@ -830,8 +830,11 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
 //   GP_SEARCH -> cost trials t0, t0 + 1, ... in order; first trial rejected and only it rolled out: ask for all 20 and
 //                yield [t0 = 1]; verdict reached or all 20 rejected: back in solve (cs:113-141), then GP_ITER or done
 // A trajectory that ends is replaced at once (pull, initial trajectory, first expansion) inside the same segment.
-template <int NC, int G>
-__global__ void __launch_bounds__(CILQR_WAVE, G == 1 ? 3 : 2)
+// LOOP: the closed planning loop in one launch (cilqr_closed_loop_batch_device; mp:180-197, cs:163-180): a trajectory slot keeps
+// its ego for all its ticks — solve, ego <- x.row(1), tick + 1, next solve warm from the plan just stored where the ego's
+// configuration says so — as k_solve's LOOP builds do, but two egos per wavefront share their rollout passes.
+template <int NC, int G, bool LOOP = false>
+__global__ void __launch_bounds__(CILQR_WAVE, 2)
 k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, double* u_out, double* __restrict__ x_out,
             cilqr_result* __restrict__ res_out, cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
@@ -844,6 +847,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
     }
     wave_sync();
     bool fresh_left = true;
+    const int T = LOOP ? a.loop_ticks : 1;
     const bool steal = a.park != nullptr; // the tail of the launch: idle wavefronts take over trajectories of wavefronts that hold two
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
@@ -872,6 +876,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             Cst c;
             int b = 0, idx0 = 0, status = CILQR_RUNNING, iters = 0, ls_trials = 0, cost_evals = 0, tl = 0, flag = 0, t0 = 0, trials = 0;
             bool deep_next = false, have_all = false;
+            int keep_b = -1, t_done = 0; // closed loop: the slot's next trajectory is the same ego, its next tick
             double J_cur = 0.0, J_init = 0.0, lamb = 0.0, new_J = 0.0, dV[2] = {0.0, 0.0};
             long long tl_start = 0;
             bool resume = (phase == GP_SEARCH);
@@ -882,6 +887,10 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             if (phase == GP_STOLEN) {
                 // a trajectory another wavefront parked between two iterations: its x, u, lane indices and scalars
                 b = uniform_int(st->b);
+                if (LOOP) { // its earlier ticks' plan (the warm start of the next tick) was written by another wavefront
+                    sh_acquire();
+                    __builtin_amdgcn_s_dcache_inv();
+                }
                 if (prof) {
                     for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) pacc[e] = 0; // (its cycles so far stay behind)
                     wave_sync();
@@ -893,7 +902,8 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 deep_next = uniform_int(st->deep_next) != 0;
                 J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb;
                 tl_start = st->tl_start;
-                load_cst(c, a, b, l, lane); // (fills this slot's copy of the cost model's constants)
+                t_done = LOOP ? uniform_int(st->t_done) : 0;
+                load_cst<LOOP>(c, a, b, l, lane); // (fills this slot's copy of the cost model's constants)
                 if (NC) c.N = NC;
                 if (lane == 0) { *grp_cst(g_lds, N, g) = c; st->b = b; st->req = 0; }
                 seed_trial_indices(l, N, 2, lane);
@@ -908,6 +918,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 deep_next = uniform_int(st->deep_next) != 0; have_all = uniform_int(st->have_all) != 0;
                 J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb; new_J = st->new_J; dV[0] = st->dV0; dV[1] = st->dV1;
                 tl_start = st->tl_start;
+                t_done = LOOP ? uniform_int(st->t_done) : 0;
                 load_cst_lds(c, grp_cst(g_lds, N, g));
                 stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
                 GPROF_ADD(PH_TC_REF); // (grouped build: slot 10 = the segment's set-up — state, constants, lane window)
@@ -917,7 +928,11 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 if (!resume) {
                     if (phase == GP_EMPTY) {
                         unsigned nb = (unsigned)a.B;
-                        if (fresh_left) nb = sh_add_u(a.next, 1u, lane);
+                        if (LOOP && keep_b >= 0) { nb = (unsigned)keep_b; keep_b = -1; } // the next tick of the ego this slot is driving
+                        else {
+                            t_done = 0;
+                            if (fresh_left) nb = sh_add_u(a.next, 1u, lane);
+                        }
                         if (nb >= (unsigned)a.B) { fresh_left = false; phase = GP_DONE; break; }
                         b = (int)nb;
                         if (prof) {
@@ -926,7 +941,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                             t_ph = (long long)__builtin_readcyclecounter();
                         }
                         tl_start = a.timeline ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-                        if (!ids_valid(a, b)) { // as in solve_one: NaN outputs, CILQR_END_BAD_INPUT; the slot takes the next trajectory
+                        if (!ids_valid<LOOP>(a, b)) { // as in solve_one: NaN outputs, CILQR_END_BAD_INPUT; the slot takes the next trajectory
                             const double qnan = dm_from_bits(0x7ff8000000000000ULL);
                             for (int e = lane; e < 4 * (N + 1); e += CILQR_WAVE) x_out[(size_t)b * 4 * (N + 1) + e] = qnan;
                             for (int e = lane; e < 2 * N; e += CILQR_WAVE) u_out[(size_t)b * 2 * N + e] = qnan;
@@ -937,14 +952,25 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                                 res_out[b] = r;
                             }
                             if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
-                            continue;
+                            continue; // (closed loop: an ego whose routes have run out stops there)
                         }
-                        load_cst(c, a, b, l, lane);
+                        load_cst<LOOP>(c, a, b, l, lane);
                         if (NC) c.N = NC;
                         if (lane == 0) { st->dt = c.dt; st->wb = c.wb; st->rp = c.rp; st->nfb = 0; *grp_cst(g_lds, N, g) = c; }
                         lds_sync();
-                        J_cur = grp_init<NC, G>(g_lds, g, N, lane, x0[4 * b], x0[4 * b + 1], x0[4 * b + 2], x0[4 * b + 3],
-                                                last_u ? last_u + (size_t)b * N * 2 : nullptr, a.W);
+                        double xs0, xs1, xs2, xs3;
+                        const double* lu = last_u;
+                        if (LOOP) { // the ego state is advanced inside this launch: not through the read-only kernel argument
+                            xs0 = park_ld(a.loop_x0 + 4 * (size_t)b); xs1 = park_ld(a.loop_x0 + 4 * (size_t)b + 1);
+                            xs2 = park_ld(a.loop_x0 + 4 * (size_t)b + 2); xs3 = park_ld(a.loop_x0 + 4 * (size_t)b + 3);
+                            if (t_done > 0) { // a later tick: warm from the plan just stored if the ego's configuration says so (cs:88-101)
+                                const int pid = a.param_id ? a.param_id[b] : 0;
+                                lu = a.params[pid].use_last_solution ? u_out : nullptr;
+                            }
+                        } else {
+                            xs0 = x0[4 * b]; xs1 = x0[4 * b + 1]; xs2 = x0[4 * b + 2]; xs3 = x0[4 * b + 3];
+                        }
+                        J_cur = grp_init<NC, G>(g_lds, g, N, lane, xs0, xs1, xs2, xs3, lu ? lu + (size_t)b * N * 2 : nullptr, a.W);
                         idx0 = uniform_int(st->idx0);
                         J_init = J_cur;
                         lamb = c.k->init_lamb;
@@ -1067,8 +1093,14 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                                 st->cost_evals = cost_evals; st->tl = tl; st->flag = flag;
                                 st->deep_next = deep_next ? 1 : 0;
                                 st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->tl_start = tl_start;
+                                st->t_done = t_done;
                             }
                             lds_sync();
+                            // Closed loop: this wavefront has stored the ego's plan, state and result at every tick it ran, with
+                            // plain stores that sit dirty in ITS XCD's L2; whoever takes the ego over stores the same addresses
+                            // from another XCD, and the two L2s write back in no particular order (found by the loop's own test:
+                            // final states that were tick 10's).  Write this L2's lines back before the ego changes hands.
+                            if (LOOP) sh_release();
                             grp_park_copy(a.park + (size_t)b * grp_park_doubles(N), l.x, l.u, l.ridx, st, N, lane, 1);
                             rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
                             phase = GP_DONE; // (the counter is dry — or somebody would not be waiting: nothing to pull)
@@ -1108,9 +1140,30 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     tl_rec[2] = blockIdx.x;
                     tl_rec[3] = __builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (3 << 11)) & 0xf;
                 }
+                if (LOOP) {
+                    // the step after the path (mp:181,197), for this ego: ego_state = new_x.row(1), the obstacle window one tick on
+                    if (lane < 4) {
+                        const double v = l.x[4 + lane];
+                        a.loop_x0[4 * (size_t)b + lane] = v;
+                        if (a.loop_states) a.loop_states[((size_t)b * T + t_done) * 4 + lane] = v;
+                    }
+                    if (lane == 0) {
+                        // (an agent-scope add: the ego may have come from another wavefront, whose increments this CU's L1 —
+                        //  which may hold the line for a neighbouring ego's sake — has not seen)
+                        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.loop_tick + b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.loop_iters) a.loop_iters[(size_t)t_done * a.B + b] = iters;
+                    }
+                    // this wavefront's stores (plan, ego state, tick) are in L2 before it — or whoever takes the ego over — reads
+                    // them again, and not shadowed by the CU's L1 / scalar cache
+                    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    sh_acquire();
+                    __builtin_amdgcn_s_dcache_inv();
+                    t_done += 1;
+                }
                 wave_sync(); // (x, u are read before the slot's next trajectory overwrites them)
-                if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
                 phase = GP_EMPTY;
+                if (LOOP && t_done < T) { keep_b = b; continue; }
+                if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
             }
             // what the trajectory carries to its next segment
             if (lane == 0) {
@@ -1121,6 +1174,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     st->deep_next = deep_next ? 1 : 0; st->have_all = have_all ? 1 : 0;
                     st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->new_J = new_J; st->dV0 = dV[0]; st->dV1 = dV[1];
                     st->tl_start = tl_start;
+                    st->t_done = t_done;
                 }
             }
             lds_sync(); // (not wave_sync: the sweep's gain stores may still be in flight; rollout_group waits for them)

@@ -56,4 +56,8 @@ template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
 template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 3
 template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 4
+template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE; // the closed planning loop in one launch
+#elif CILQR_INST_GROUP == 2
+template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
 #endif
