@@ -85,6 +85,15 @@ def main():
                 ref = out
             else:
                 what = (wl.name, N, B, over, rollout, tune)
+                if not same(ref["u"], out["u"]) and os.environ.get("STRESS_DIAG"):
+                    bad = np.nonzero((ref["u"] != out["u"]).reshape(wl.B, -1).any(1))[0]
+                    print("MISMATCH", what, "warm" if warm is not None else "cold", "trajectories", len(bad), bad[:12])
+                    for b0 in bad[:3]:
+                        tb = np.argwhere(ref["trace"][b0] != out["trace"][b0])
+                        k0 = int(tb[0][0]) if len(tb) else -1
+                        print("  b", int(b0), "iters", ref["res"]["iters"][b0], out["res"]["iters"][b0], "first trace diff at", k0,
+                              ref["trace"][b0, k0] if k0 >= 0 else None, out["trace"][b0, k0] if k0 >= 0 else None)
+                    continue
                 assert same(ref["u"], out["u"]), what
                 assert same(ref["x"], out["x"]), what
                 assert same(ref["res"], out["res"]), what

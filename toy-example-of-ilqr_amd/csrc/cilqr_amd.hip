@@ -370,6 +370,8 @@ struct cilqr_handle {
     int win_grp = 0;           // lane window of those launches
     int group_loop = 1;        // the closed loop in one launch runs the grouped build too (0: k_solve's LOOP builds)
     int group_dual_probe = 0;  // development probe (CILQR_TUNE=grp_dual_probe=1)
+    int poison_scratch = 0;    // development library: fill the kernels' scratch before every launch (CILQR_TUNE=poison=1: NaN
+                               // patterns, 2: zeros) — results must not depend on what the scratch held
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
     int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
     int prof_B = 0;
@@ -522,6 +524,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
                 else if (k == "grp_dual_probe") h->group_dual_probe = v;
                 else if (k == "group_loop") h->group_loop = v;
+                else if (k == "poison") h->poison_scratch = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -1106,6 +1109,11 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     }
     if (h->scratch.ensure(sizeof(double) * area * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
+    if (h->poison_scratch) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(h->scratch.p, h->poison_scratch == 1 ? 0xFF : 0x00, h->scratch.cap));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
     if (!h->sh_ctl.p) {
         if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS)) return fail(CILQR_ERR_DEVICE, "hipMalloc control words");

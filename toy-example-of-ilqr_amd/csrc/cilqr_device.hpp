@@ -274,22 +274,33 @@ __device__ inline void stage_window(const Cst& c, Lds& l, int w0, int Wcap, int 
     wave_sync();
 }
 
-// scratch slab of the trial trajectories: [3 pairs][(N+1)][20 alphas][2] doubles — components in pairs (x0 x1 | x2 x3 |
-// u0 u1), alpha next, so that the 20 rollout lanes of one 16-byte store instruction write 320 contiguous bytes and a
-// row is three stores, three loads.  Components 0-3 = x', 4-5 = u'.  TR(t, c, k) with t = TRIAL_AT(slab, alpha).
-// Behind the slab, [6][(N+1)] doubles for the alpha = 1 trial alone (the "first-trial buffer"): most iterations
-// accept that trial, so they roll out, cost and accept only it — 2.4 KB written and read back contiguously,
-// L2-resident — and the slab is written only in iterations expected (or found) to search deeper.  Both are
+// scratch slab of the trial trajectories: [3 pairs][row tiles][20 alphas][4 rows][2] doubles — components in pairs (x0 x1 |
+// x2 x3 | u0 u1); rows in tiles of CILQR_SLAB_TILE = 4, so that the four rows a step size owns in a tile are ONE 64-byte
+// sector: a rollout lane fills it with four consecutive 16-byte stores (complete sectors leave L2, the 20 lanes of a store
+// instruction write 20 neighbouring sectors), and the trial costs — lane = row, one step size at a time — fetch a sector
+// per FOUR rows instead of one per row.  (Rows next to each other, alpha in between — the layout until round 4 — made every
+// 16 bytes the costs read bring a whole sector in: 4 x the slab's bytes, the largest single part of the kernel's fetch
+// traffic.)  Components 0-3 = x', 4-5 = u'.  TR(t, c, k) with t = TRIAL_AT(slab, alpha).
+// Behind the slab, the same for the alpha = 1 trial alone (the "first-trial buffer", [3 pairs][N + 1 rows, padded to whole
+// tiles][2]): most iterations accept that trial, so they roll out, cost and accept only it — 2.4 KB written and read back
+// contiguously, L2-resident — and the slab is written only in iterations expected (or found) to search deeper.  Both are
 // addressed as TRS(t, c, k, as): as = 20 inside the slab (t = TRIAL_AT(slab, alpha)), as = 1 in the first-trial buffer.
 #define CILQR_TRIAL_ROWS 6
-#define TRS(t, c, k, as) (t)[(((size_t)((c) >> 1) * R + (size_t)(k)) * (size_t)(as)) * 2 + (size_t)((c) & 1)]
-#define TRIAL_AT(base, alpha) ((base) + 2 * (alpha))
+#ifndef CILQR_SLAB_TILE
+#define CILQR_SLAB_TILE 4 // (1 = the untiled layout, kept for A/B runs)
+#endif
+#define CILQR_SLAB_RT(R) (((R) + CILQR_SLAB_TILE - 1) / CILQR_SLAB_TILE)
+#define TRS(t, c, k, as)                                                                                              \
+    (t)[(((size_t)((c) >> 1) * CILQR_SLAB_RT(R) + (size_t)((k) / CILQR_SLAB_TILE)) * (size_t)(as)) * (2 * CILQR_SLAB_TILE) + \
+        (size_t)((k) % CILQR_SLAB_TILE) * 2 + (size_t)((c) & 1)]
+#define TRIAL_AT(base, alpha) ((base) + 2 * CILQR_SLAB_TILE * (alpha))
 #define TR(t, c, k) TRS(t, c, k, CILQR_MAX_ALPHA_TRIALS)
-__host__ __device__ inline size_t slab_doubles(int N) {
-    return (size_t)CILQR_MAX_ALPHA_TRIALS * CILQR_TRIAL_ROWS * (size_t)(N + 1);
+__host__ __device__ inline size_t first_trial_doubles(int N) { // one trial: 3 pairs of whole row tiles
+    return (size_t)3 * CILQR_SLAB_RT(N + 1) * 2 * CILQR_SLAB_TILE;
 }
+__host__ __device__ inline size_t slab_doubles(int N) { return (size_t)CILQR_MAX_ALPHA_TRIALS * first_trial_doubles(N); }
 __host__ __device__ inline size_t scratch_gl_offset(int N) { // rows of the cost expansion ("lg" builds), 128-byte aligned
-    const size_t head = slab_doubles(N) + (size_t)(CILQR_TRIAL_ROWS + 3) * (size_t)(N + 1); // + first-trial buffer + parked gains
+    const size_t head = slab_doubles(N) + first_trial_doubles(N) + (size_t)3 * (size_t)(N + 1); // + first-trial buffer + parked gains
     return (head + 15) / 16 * 16;
 }
 __host__ __device__ inline size_t scratch_doubles(int N) {
@@ -1184,13 +1195,27 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 // buffer_store per value, no address arithmetic in vector registers.
 struct RollOut {
     __amdgpu_buffer_rsrc_t rsrc;
-    int ox;           // byte offset of row i + 1 of component 0
-    int ou;           // byte offset of row i of component 4
-    int csb, rowb;    // pair / row stride in bytes
+    int pairb, tileb; // pair / row-tile stride in bytes
     unsigned lane_off;
 };
+// A wave-uniform step index as the scalar unit holds it, its value hidden from the optimiser.  The rollout loops are
+// unrolled by two over two register sets, and the compiler derives the low bit of the step index from that: right in the
+// small-angle loop (it starts at step 0), WRONG in the general loop behind it, which starts wherever the first one stopped —
+// at an odd step the tile-relative offset (k % 4) * 16 lost its bit 4, a row landed on its neighbour and the trial costs
+// read the last pass's row in its place (hipcc of ROCm 7.2; found by the grouped build against the oracle on the bend
+// scenario, where the loops hand over mid-horizon: costs off in the ninth digit, only when the hand-over step was odd).
+__device__ inline int opaque_uniform(int k) {
+    int ku = __builtin_amdgcn_readfirstlane(k);
+    __asm__ volatile("" : "+s"(ku));
+    return ku;
+}
+// byte offset of row k of pair 0 for step size 0 (scalar arithmetic)
+__device__ inline int slab_row_off(const RollOut& o, int k) {
+    const int ku = opaque_uniform(k);
+    return (ku / CILQR_SLAB_TILE) * o.tileb + (ku % CILQR_SLAB_TILE) * 16;
+}
 template <int RP, bool SMALL, int PIN = DM_PIN>
-__device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], RollOut& o) {
+__device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], const RollOut& o, int i) {
     const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
     const double k0 = CQ_MADD(g.k[3], dx3, CQ_MADD(g.k[2], dx2, CQ_MADD(g.k[1], dx1, g.k[0] * dx0)));
     const double k1 = CQ_MADD(g.k[8], dx3, CQ_MADD(g.k[7], dx2, CQ_MADD(g.k[6], dx1, g.k[5] * dx0)));
@@ -1209,15 +1234,14 @@ __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn&
         const u32x2 lo_ = __builtin_bit_cast(u32x2, (v0)), hi_ = __builtin_bit_cast(u32x2, (v1));                    \
         u32x4 q_;                                                                                                    \
         q_.x = lo_.x; q_.y = lo_.y; q_.z = hi_.x; q_.w = hi_.y;                                                      \
-        __builtin_amdgcn_raw_buffer_store_b128(q_, o.rsrc, o.lane_off, (base) + (pair) * o.csb, 0);                  \
+        __builtin_amdgcn_raw_buffer_store_b128(q_, o.rsrc, o.lane_off, (base) + (pair) * o.pairb, 0);                \
     }
-    CILQR_SLAB_ST2(o.ou, 0, un[0], un[1]);
-    CILQR_SLAB_ST2(o.ox, 0, xn[0], xn[1]);
-    CILQR_SLAB_ST2(o.ox, 1, xn[2], xn[3]);
+    const int ou = slab_row_off(o, i), ox = slab_row_off(o, i + 1);
+    CILQR_SLAB_ST2(ou, 2, un[0], un[1]);
+    CILQR_SLAB_ST2(ox, 0, xn[0], xn[1]);
+    CILQR_SLAB_ST2(ox, 1, xn[2], xn[3]);
 #undef CILQR_SLAB_ST2
     xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-    o.ox += o.rowb;
-    o.ou += o.rowb;
     return true;
 }
 
@@ -1243,14 +1267,11 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
         gdouble_w* t = TRIAL_AT(scr, lane);
         double xc[4] = {l.x[0], l.x[1], l.x[2], l.x[3]};
         TRS(t, 0, 0, as) = xc[0]; TRS(t, 1, 0, as) = xc[1]; TRS(t, 2, 0, as) = xc[2]; TRS(t, 3, 0, as) = xc[3];
-        const int CS = R * as; // component stride (doubles)
         RollOut o;
-        o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)scr_in_uniform, 0, (int)(CILQR_TRIAL_ROWS * CS * sizeof(double)), 0x00020000);
-        o.ox = 2 * as * (int)sizeof(double);        // row 1 of the pair (x0, x1)
-        o.ou = 2 * 2 * CS * (int)sizeof(double);    // row 0 of the pair (u0, u1)
-        o.lane_off = 16u * (unsigned)lane;
-        o.csb = 2 * CS * (int)sizeof(double);       // pair stride
-        o.rowb = 2 * as * (int)sizeof(double);
+        o.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)scr_in_uniform, 0, (int)(first_trial_doubles(N) * as * sizeof(double)), 0x00020000);
+        o.lane_off = (unsigned)(2 * CILQR_SLAB_TILE * sizeof(double)) * (unsigned)lane;
+        o.tileb = as * 2 * CILQR_SLAB_TILE * (int)sizeof(double);
+        o.pairb = CILQR_SLAB_RT(R) * o.tileb;
         // Two loops over the steps.  The first assumes small angles on all trial lanes (the usual case:
         // yaw relative to the x axis and steering below pi/4) and runs the straight-line step; the moment
         // a step does not qualify it hands over — nothing of that step has been stored yet — to the second,
@@ -1267,11 +1288,11 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             for (;;) {
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(gb, l, i + 1);
-                if (!roll_step<RP, true, PIN>(c, pk, ga, alpha, xc, o)) break;
+                if (!roll_step<RP, true, PIN>(c, pk, ga, alpha, xc, o, i)) break;
                 ++i;
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(ga, l, i + 1);
-                if (!roll_step<RP, true, PIN>(c, pk, gb, alpha, xc, o)) break;
+                if (!roll_step<RP, true, PIN>(c, pk, gb, alpha, xc, o, i)) break;
                 ++i;
             }
         }
@@ -1280,11 +1301,11 @@ __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr
             roll_fetch(ga, l, i);
             for (;;) {
                 if (i + 1 < N) roll_fetch(gb, l, i + 1);
-                roll_step<RP, false, PIN>(c, pk, ga, alpha, xc, o);
+                roll_step<RP, false, PIN>(c, pk, ga, alpha, xc, o, i);
                 ++i;
                 if (i >= N) break;
                 if (i + 1 < N) roll_fetch(ga, l, i + 1);
-                roll_step<RP, false, PIN>(c, pk, gb, alpha, xc, o);
+                roll_step<RP, false, PIN>(c, pk, gb, alpha, xc, o, i);
                 ++i;
                 if (i >= N) break;
             }
@@ -1335,11 +1356,11 @@ __device__ inline void accept_trial(const Cst& c, const Lds& l, const double* sc
 // The head of l.kd that the lone costing of a first trial overwrites (slot 0 of the stage-cost scratch), parked
 // behind the first-trial buffer and brought back if the search goes on to a second rollout pass.
 __device__ inline void save_gains_head(const Lds& l, double* first, int N, int lane) {
-    double* park = first + CILQR_TRIAL_ROWS * (N + 1);
+    double* park = first + first_trial_doubles(N);
     for (int e = lane; e < 3 * (N + 1); e += CILQR_WAVE) park[e] = l.kd[e];
 }
 __device__ inline void restore_gains_head(const Lds& l, const double* first, int N, int lane) {
-    const double* park = first + CILQR_TRIAL_ROWS * (N + 1);
+    const double* park = first + first_trial_doubles(N);
     for (int e = lane; e < 3 * (N + 1); e += CILQR_WAVE) l.kd[e] = park[e];
     wave_sync();
 }

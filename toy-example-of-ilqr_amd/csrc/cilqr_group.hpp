@@ -74,7 +74,7 @@ __host__ __device__ inline size_t grp_lds_bytes(int N, int W, int G) {
 }
 // global scratch per trajectory slot: slab | first-trial buffer | gains, 128-byte granules
 __host__ __device__ inline size_t grp_scratch_doubles(int N) {
-    const size_t d = slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * (size_t)(N + 1) + (size_t)CILQR_KD * (size_t)N;
+    const size_t d = slab_doubles(N) + first_trial_doubles(N) + (size_t)CILQR_KD * (size_t)N;
     return (d + 15) / 16 * 16;
 }
 
@@ -574,7 +574,7 @@ struct GrpRoll {
     unsigned kaddr;        // ... of its gains when they are staged for the pass (rollout_group), else:
     unsigned goff;         // byte offset of its gains in the block's scratch area
     unsigned vrow0;        // ... of row 0, pair 0 of this lane's trial
-    unsigned csb, rowb;    // pair / row stride of the destination (slab: 20 step sizes per row, first-trial buffer: 1)
+    unsigned pairb, tileb; // pair / row-tile stride of the destination (slab: 20 step sizes per tile, first-trial buffer: 1)
 };
 
 template <bool STAGE>
@@ -602,8 +602,18 @@ __device__ inline void roll_fetch_g(RollIn& g, __amdgpu_buffer_rsrc_t rs, const 
 }
 
 struct GrpOut {
-    unsigned vx0, vx1, vu; // byte offsets: row i + 1 of the pairs (x0 x1), (x2 x3); row i of (u0 u1)
+    unsigned bx0, bx1, bu; // byte offsets of row 0 of the pairs (x0 x1), (x2 x3), (u0 u1) of this lane's trial
 };
+// row k of a pair: its tile (a per-lane stride: the lanes of a pass write slabs and first-trial buffers side by side) in the
+// vector offset, its place inside the tile — the same for every lane — in the scalar offset
+__device__ inline void slab_st2_row(__amdgpu_buffer_rsrc_t rs, unsigned b, unsigned tileb, int k, double v0, double v1) {
+    const u32x2 lo_ = __builtin_bit_cast(u32x2, v0), hi_ = __builtin_bit_cast(u32x2, v1);
+    u32x4 q_;
+    q_.x = lo_.x; q_.y = lo_.y; q_.z = hi_.x; q_.w = hi_.y;
+    const int ku = opaque_uniform(k); // (see slab_row_off)
+    const unsigned voff = __umul24((unsigned)(ku / CILQR_SLAB_TILE), tileb) + b;
+    __builtin_amdgcn_raw_buffer_store_b128(q_, rs, voff, (ku % CILQR_SLAB_TILE) * 16, 0);
+}
 __device__ inline void slab_st2(__amdgpu_buffer_rsrc_t rs, unsigned voff, double v0, double v1) {
     const u32x2 lo_ = __builtin_bit_cast(u32x2, v0), hi_ = __builtin_bit_cast(u32x2, v1);
     u32x4 q_;
@@ -612,7 +622,7 @@ __device__ inline void slab_st2(__amdgpu_buffer_rsrc_t rs, unsigned voff, double
 }
 template <int RP, bool SMALL, int PIN>
 __device__ inline bool roll_step_g(const GrpRoll& q, __amdgpu_buffer_rsrc_t rs, const DmPinned& pk, const RollIn& g, double xc[4],
-                                   GrpOut& o) {
+                                   const GrpOut& o, int i) {
     const double dx0 = xc[0] - g.x[0], dx1 = xc[1] - g.x[1], dx2 = xc[2] - g.x[2], dx3 = xc[3] - g.x[3];
     const double k0 = CQ_MADD(g.k[3], dx3, CQ_MADD(g.k[2], dx2, CQ_MADD(g.k[1], dx1, g.k[0] * dx0)));
     const double k1 = CQ_MADD(g.k[8], dx3, CQ_MADD(g.k[7], dx2, CQ_MADD(g.k[6], dx1, g.k[5] * dx0)));
@@ -626,13 +636,10 @@ __device__ inline bool roll_step_g(const GrpRoll& q, __amdgpu_buffer_rsrc_t rs, 
     } else {
         propagate_v<RP, PIN | DM_NOSHORT>(q.dt, q.wb, xc, un, xn, &pk);
     }
-    slab_st2(rs, o.vu, un[0], un[1]);
-    slab_st2(rs, o.vx0, xn[0], xn[1]);
-    slab_st2(rs, o.vx1, xn[2], xn[3]);
+    slab_st2_row(rs, o.bu, q.tileb, i, un[0], un[1]);
+    slab_st2_row(rs, o.bx0, q.tileb, i + 1, xn[0], xn[1]);
+    slab_st2_row(rs, o.bx1, q.tileb, i + 1, xn[2], xn[3]);
     xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
-    o.vu += q.rowb;
-    o.vx0 += q.rowb;
-    o.vx1 += q.rowb;
     return true;
 }
 
@@ -643,11 +650,11 @@ __device__ inline int rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const G
     const f64x2 b0 = *(lds_cf64x2*)(size_t)(q.xaddr + 16u);
     double xc[4] = {a0.x, a0.y, b0.x, b0.y};
     slab_st2(rs, q.vrow0, xc[0], xc[1]);
-    slab_st2(rs, q.vrow0 + q.csb, xc[2], xc[3]);
+    slab_st2(rs, q.vrow0 + q.pairb, xc[2], xc[3]);
     GrpOut o;
-    o.vx0 = q.vrow0 + q.rowb;
-    o.vx1 = o.vx0 + q.csb;
-    o.vu = q.vrow0 + 2u * q.csb;
+    o.bx0 = q.vrow0;
+    o.bx1 = q.vrow0 + q.pairb;
+    o.bu = q.vrow0 + 2u * q.pairb;
     // as in rollout_trials_rp: a straight-line small-angle loop that hands over to the general loop at the first step that
     // does not qualify on some lane; gains and nominal point of step i + 1 fetched while step i computes; two register sets
     DmPinned pk;
@@ -659,11 +666,11 @@ __device__ inline int rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const G
         for (;;) {
             if (i >= N) break;
             if (i + 1 < N) roll_fetch_g<STAGE>(gb, rs, q, i + 1);
-            if (!roll_step_g<RP, true, PIN>(q, rs, pk, ga, xc, o)) break;
+            if (!roll_step_g<RP, true, PIN>(q, rs, pk, ga, xc, o, i)) break;
             ++i;
             if (i >= N) break;
             if (i + 1 < N) roll_fetch_g<STAGE>(ga, rs, q, i + 1);
-            if (!roll_step_g<RP, true, PIN>(q, rs, pk, gb, xc, o)) break;
+            if (!roll_step_g<RP, true, PIN>(q, rs, pk, gb, xc, o, i)) break;
             ++i;
         }
     }
@@ -673,11 +680,11 @@ __device__ inline int rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const G
         roll_fetch_g<STAGE>(ga, rs, q, i);
         for (;;) {
             if (i + 1 < N) roll_fetch_g<STAGE>(gb, rs, q, i + 1);
-            roll_step_g<RP, false, PIN>(q, rs, pk, ga, xc, o);
+            roll_step_g<RP, false, PIN>(q, rs, pk, ga, xc, o, i);
             ++i;
             if (i >= N) break;
             if (i + 1 < N) roll_fetch_g<STAGE>(ga, rs, q, i + 1);
-            roll_step_g<RP, false, PIN>(q, rs, pk, gb, xc, o);
+            roll_step_g<RP, false, PIN>(q, rs, pk, gb, xc, o, i);
             ++i;
             if (i >= N) break;
         }
@@ -694,7 +701,11 @@ __device__ inline int rollout_group_rp(int N, __amdgpu_buffer_rsrc_t rs, const G
 // STAGE: the gains of the pass are copied into the wavefront's shared LDS area first (two trajectories fit); otherwise the
 // lanes read them from global memory one step ahead.
 template <int G, int PIN, bool STAGE>
-__device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double* scr_blk, int N, int lane) {
+__device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double* scr_blk, int N_arg, int lane) {
+    // (arguments of an out-of-line function arrive in vector registers: without this the horizon — and with it the loop
+    //  counters and the buffer descriptor built from it — counts as divergent, and every slab store becomes a loop over the
+    //  distinct descriptors of the lanes)
+    const int N = uniform_int(N_arg);
     const int R = N + 1;
     int start = 0, gl = -1, al = 0, rq = 0;
 #pragma unroll
@@ -717,7 +728,7 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
 #pragma unroll
     for (int g = 0; STAGE && g < G; ++g) {
         if (uniform_int(grp_state(lds_base, N, g)->req) == 0) continue;
-        const double* src = scr_blk + (size_t)g * grp_scratch_doubles(N) + slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * R;
+        const double* src = scr_blk + (size_t)g * grp_scratch_doubles(N) + slab_doubles(N) + first_trial_doubles(N);
         const f64x2* s2 = reinterpret_cast<const f64x2*>(src);
         f64x2* d2 = reinterpret_cast<f64x2*>(stage + (size_t)g * CILQR_KD * N);
         for (int e = lane; e < CILQR_KD * N / 2; e += CILQR_WAVE) d2[e] = s2[e];
@@ -736,10 +747,11 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
         const unsigned as = (rq == 2) ? (unsigned)CILQR_MAX_ALPHA_TRIALS : 1u;
         const unsigned gbase = (unsigned)gl * (unsigned)(grp_scratch_doubles(N) * sizeof(double));
         q.kaddr = lds_addr(stage + (size_t)gl * CILQR_KD * N);
-        q.goff = gbase + (unsigned)((slab_doubles(N) + (size_t)CILQR_TRIAL_ROWS * R) * sizeof(double));
-        q.rowb = as * 16u;
-        q.csb = (unsigned)R * as * 16u;
-        q.vrow0 = gbase + ((rq == 2) ? 0u : (unsigned)(slab_doubles(N) * sizeof(double))) + 16u * (unsigned)al;
+        q.goff = gbase + (unsigned)((slab_doubles(N) + first_trial_doubles(N)) * sizeof(double));
+        q.tileb = as * (unsigned)(2 * CILQR_SLAB_TILE * sizeof(double));
+        q.pairb = (unsigned)CILQR_SLAB_RT(R) * q.tileb;
+        q.vrow0 = gbase + ((rq == 2) ? 0u : (unsigned)(slab_doubles(N) * sizeof(double))) +
+                  (unsigned)(2 * CILQR_SLAB_TILE * sizeof(double)) * (unsigned)al;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)uniform_ptr(scr_blk), 0, (int)(G * grp_scratch_doubles(N) * sizeof(double)), 0x00020000);
         // one loop pair per vehicle model: only that model's polynomial constants are live inside it

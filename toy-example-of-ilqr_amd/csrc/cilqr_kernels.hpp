@@ -861,7 +861,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             if (phase == GP_DONE) continue;
             double* const scr = scr_blk + (size_t)g * grp_scratch_doubles(N);
             double* const first = scr + slab_doubles(N);
-            double* const gains = first + (size_t)CILQR_TRIAL_ROWS * (N + 1);
+            double* const gains = first + first_trial_doubles(N);
             long long* const pacc = grp_prof(g_lds, N, g);
             const bool prof = CILQR_GPROF && a.prof != nullptr;
             long long t_ph = prof ? (long long)__builtin_readcyclecounter() : 0;
