@@ -1198,12 +1198,16 @@ struct RollOut {
     int pairb, tileb; // pair / row-tile stride in bytes
     unsigned lane_off;
 };
-// A wave-uniform step index as the scalar unit holds it, its value hidden from the optimiser.  The rollout loops are
-// unrolled by two over two register sets, and the compiler derives the low bit of the step index from that: right in the
-// small-angle loop (it starts at step 0), WRONG in the general loop behind it, which starts wherever the first one stopped —
-// at an odd step the tile-relative offset (k % 4) * 16 lost its bit 4, a row landed on its neighbour and the trial costs
-// read the last pass's row in its place (hipcc of ROCm 7.2; found by the grouped build against the oracle on the bend
-// scenario, where the loops hand over mid-horizon: costs off in the ninth digit, only when the hand-over step was odd).
+// A wave-uniform step index as the scalar unit holds it, its value hidden from the optimiser.
+// Why: the first tiled build of the grouped rollout pass (out of line, its horizon argument arriving in a VECTOR register, so
+// that the compiler treated the loop exits, the step index behind the first loop and the buffer descriptor as divergent and
+// wrapped every slab store in a loop over the lanes' distinct descriptors and offsets) sporadically left rows of a deep pass
+// unwritten where the trial costs read them — the last pass's values instead, costs off in the ninth digit, depending on
+// which two trajectories shared the wavefront.  The oracle caught it on the bend scenario, scripts/stress_grouped.py within
+// seconds.  It went away with ANY of: the tile-relative offset added into the vector offset, this opaque scalar copy, or the
+// horizon made scalar on entry (rollout_group) — the last two are both in.  The instruction at fault was not found (the
+// disassembly of the failing loop reads correct: profiles/r04_experiments/tiled_slab_lost_rows.txt); the stress run and the
+// oracle comparison at scale are the guard.
 __device__ inline int opaque_uniform(int k) {
     int ku = __builtin_amdgcn_readfirstlane(k);
     __asm__ volatile("" : "+s"(ku));
