@@ -684,7 +684,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B,
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
-                       "parallelism": f"trajectory-sharded x{world}, one wavefront per trajectory"},
+                       "parallelism": f"trajectory-sharded x{world}, "
+                                      + {1: "one wavefront per trajectory", 2: "two trajectories per wavefront",
+                                         3: "three trajectories per wavefront"}.get(
+                                             (launch_info_main or {}).get("trajectories_per_wavefront", 1), "one wavefront per trajectory")},
             "roofline": roofline_block(pkg, wl, res, kernel_ms, world, launch_info_main),
             "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
                       "line_search_trials_per_step": float(stats[1]),

@@ -188,8 +188,11 @@ TPL = ("DBG", "NCH", "ALM", "HELP", "PROF", "WPS", "NTP", "NC", "LG", "SHARE", "
 
 def describe(variant):
     if variant.startswith("grp:"):
-        nc, g = [p.strip() for p in variant[4:].split(",")]
-        return f"grouped: {g} trajectories per wavefront, waves/SIMD=2" + (f" N={nc}" if nc != "0" else "")
+        parts = [p.strip() for p in variant[4:].split(",")]
+        nc, g = parts[0], parts[1]
+        loop = len(parts) > 2 and parts[2] == "true"
+        return (f"grouped: {g} trajectories per wavefront, waves/SIMD=2" + (f" N={nc}" if nc != "0" else "")
+                + (" closed-loop" if loop else ""))
     parts = [p.strip() for p in variant.split(",")]
     kv = dict(zip(TPL, parts))
     tags = []

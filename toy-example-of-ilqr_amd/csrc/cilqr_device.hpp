@@ -1205,7 +1205,7 @@ struct RollOut {
 // unwritten where the trial costs read them — the last pass's values instead, costs off in the ninth digit, depending on
 // which two trajectories shared the wavefront.  The oracle caught it on the bend scenario, scripts/stress_grouped.py within
 // seconds.  It went away with ANY of: the tile-relative offset added into the vector offset, this opaque scalar copy, or the
-// horizon made scalar on entry (rollout_group) — the last two are both in.  The instruction at fault was not found (the
+// horizon made scalar on entry (rollout_group) — the last two are both in (grouped pass only, see slab_row_off).  The instruction at fault was not found (the
 // disassembly of the failing loop reads correct: profiles/r04_experiments/tiled_slab_lost_rows.txt); the stress run and the
 // oracle comparison at scale are the guard.
 __device__ inline int opaque_uniform(int k) {
@@ -1214,9 +1214,11 @@ __device__ inline int opaque_uniform(int k) {
     return ku;
 }
 // byte offset of row k of pair 0 for step size 0 (scalar arithmetic)
+// (k_solve's step index is a clean scalar register — its loops have scalar bounds — and its tiled stores were right from the
+//  first build on, checked against the oracle and, launch by launch, against both cured forms of the grouped pass; the opaque
+//  copy costs configs[3]'s kernel 1.6 % here, so it stays with the grouped pass: slab_st2_row)
 __device__ inline int slab_row_off(const RollOut& o, int k) {
-    const int ku = opaque_uniform(k);
-    return (ku / CILQR_SLAB_TILE) * o.tileb + (ku % CILQR_SLAB_TILE) * 16;
+    return (k / CILQR_SLAB_TILE) * o.tileb + (k % CILQR_SLAB_TILE) * 16;
 }
 template <int RP, bool SMALL, int PIN = DM_PIN>
 __device__ inline bool roll_step(const Cst& c, const DmPinned& pk, const RollIn& g, double alpha, double xc[4], const RollOut& o, int i) {
