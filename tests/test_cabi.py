@@ -204,6 +204,20 @@ int main(int argc, char** argv) {
     assert a.split()[0] == "30" and a.split()[3] == "barrier" and a.split()[4] == "gravity_center"
 
 
+def test_no_buffer_store_inside_a_per_descriptor_loop(built):
+    """Round 4: a 16-byte buffer store that the compiler had wrapped in a loop over the lanes' "distinct" descriptors (the
+    horizon the descriptor was built from had arrived in a vector register) lost the first dword of lanes 12-15 to a value
+    written into its data register six instructions later — gfx950, XNACK off; profiles/r04_experiments/tiled_slab_lost_rows.txt.
+    Every descriptor of the shipped kernels is built from scalars: the disassembly must hold no such loop around any buffer
+    access."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("descriptor_loop_scan", ROOT / "scripts" / "descriptor_loop_scan.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hits = mod.scan(str(ROOT / "toy-example-of-ilqr_amd" / "libcilqr_amd.so"))
+    assert hits == [], hits[:5]
+
+
 def test_register_budget_of_the_shipped_kernels(pkg, tmp_path):
     """scripts/kernel_metadata.py on the library as built: the headline build of the solve kernel (lone wavefronts, two
     per SIMD, horizon 50) stays under the 30 spilled vector registers VERDICT r02 asked for, no one-row-per-lane production

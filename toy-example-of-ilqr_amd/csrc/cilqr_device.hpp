@@ -1199,15 +1199,17 @@ struct RollOut {
     unsigned lane_off;
 };
 // A wave-uniform step index as the scalar unit holds it, its value hidden from the optimiser.
-// Why: the first tiled build of the grouped rollout pass (out of line, its horizon argument arriving in a VECTOR register, so
-// that the compiler treated the loop exits, the step index behind the first loop and the buffer descriptor as divergent and
-// wrapped every slab store in a loop over the lanes' distinct descriptors and offsets) sporadically left rows of a deep pass
-// unwritten where the trial costs read them — the last pass's values instead, costs off in the ninth digit, depending on
-// which two trajectories shared the wavefront.  The oracle caught it on the bend scenario, scripts/stress_grouped.py within
-// seconds.  It went away with ANY of: the tile-relative offset added into the vector offset, this opaque scalar copy, or the
-// horizon made scalar on entry (rollout_group) — the last two are both in (grouped pass only, see slab_row_off).  The instruction at fault was not found (the
-// disassembly of the failing loop reads correct: profiles/r04_experiments/tiled_slab_lost_rows.txt); the stress run and the
-// oracle comparison at scale are the guard.
+// Why (profiles/r04_experiments/tiled_slab_lost_rows.txt has the whole story): the first tiled build of the grouped rollout
+// pass took its horizon as an argument — out of line, so in a VECTOR register — and the compiler, counting loop exits, step
+// index and buffer descriptor as divergent, wrapped every slab store in a loop over the lanes' "distinct" descriptors
+// (v_readfirstlane, compare, s_and_saveexec, store, s_xor exec, s_cbranch_execnz).  On gfx950 with XNACK off a 16-byte store
+// in that shape read the first dword of its data for lanes 12-15 LATE: six instructions behind the store the register held
+// the next store's offset already, and that is what landed in the slab (u0's low half; found with a shadow copy written by a
+// second pass and compared lane by lane; HSA_XNACK=1 makes it vanish).  Costs off in the ninth digit, depending on which two
+// trajectories shared a wavefront.  The cause removed: every descriptor is built from scalars (rollout_group and
+// rollout_trials_rp take the horizon through v_readfirstlane; tests/test_cabi.py scans the shipped disassembly for such loops).
+// This opaque copy changes nothing about that — it was one of the first day's "cures", by way of a different register
+// allocation — and stays in the grouped pass because it is free there and keeps the offset's arithmetic on the scalar unit.
 __device__ inline int opaque_uniform(int k) {
     int ku = __builtin_amdgcn_readfirstlane(k);
     __asm__ volatile("" : "+s"(ku));
@@ -1263,7 +1265,10 @@ __device__ inline gdouble_w* uniform_ptr(double* p) {
 
 template <int RP, int PIN = DM_PIN>
 __device__ inline void rollout_trials_rp(const Cst& c, const Lds& l, double* scr_in, int lane, int n_alpha, int as_in) {
-    const int N = c.N;
+    // (scalar whatever the compiler thinks of where it came from — in the closed-loop builds the horizon descends from a table
+    //  lookup by an index the loop carries, counted as divergent, the buffer descriptor built from it too, and every slab
+    //  store became a loop over the lanes' "distinct" descriptors: the shape that lost store data in round 4, see opaque_uniform)
+    const int N = __builtin_constant_p(c.N) ? c.N : uniform_int(c.N); // (the compile-time horizons stay compile-time)
     const int R = N + 1;
     const int as = uniform_int(as_in);
     gdouble_w* scr = uniform_ptr(scr_in);

@@ -408,7 +408,7 @@ __device__ inline unsigned backward_sweep_lanes_multi(const Cst* c, const Lds* l
 template <int NC, int G>
 __device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g, int n_rt, int lane, double lamb, double* gains,
                                                                long long* prof, int dual_probe = 0) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve_group(l, lds, N, G, g);
     Cst c;
@@ -461,7 +461,7 @@ __device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g
 template <int NC, int G>
 __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, int n_rt, int lane, const double* src, int t, int as,
                                                             int w0, int W) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve_group(l, lds, N, G, g);
     l.w0 = w0;
@@ -485,7 +485,7 @@ __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, i
 template <int NC, int G>
 __device__ __attribute__((noinline)) double grp_cost_trials2(double* lds, int g, int n_rt, int lane, const double* src, int t,
                                                               int w0, int W) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve_group(l, lds, N, G, g);
     l.w0 = w0;
@@ -512,7 +512,7 @@ __device__ __attribute__((noinline)) double grp_cost_trials2(double* lds, int g,
 template <int NC, int G>
 __device__ __attribute__((noinline)) double grp_init(double* lds, int g, int n_rt, int lane, double xs0, double xs1, double xs2,
                                                       double xs3, const double* last_u, int Wcap) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve_group(l, lds, N, G, g);
     Cst c;

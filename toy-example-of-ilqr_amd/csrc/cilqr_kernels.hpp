@@ -267,7 +267,7 @@ __device__ __attribute__((noinline)) void park_copy(double* pk, double* lx, doub
 template <int NCH, int NC, bool LG>
 __device__ __attribute__((noinline)) bool ool_expand_sweep(double* lds, int n_rt, int Wcap, double* gl, int w0, int Wcur, double lamb,
                                                             int lane, int expand) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve(l, lds, N, Wcap, 0, 1, LG ? 1 : 0);
     l.gl = gl;
@@ -289,7 +289,7 @@ __device__ __attribute__((noinline)) bool ool_expand_sweep(double* lds, int n_rt
 template <int NCH, int NC, bool LG>
 __device__ __attribute__((noinline)) double ool_cost_trial(double* lds, int n_rt, int Wcap, int w0, int Wcur, const double* src, int t,
                                                             int as, int idx0, int lane) {
-    const int N = NC ? NC : n_rt;
+    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve(l, lds, N, Wcap, 0, 1, LG ? 1 : 0);
     l.w0 = w0;
