@@ -1689,7 +1689,7 @@ def test_pairs_at_scale_equal_the_single_build(pkg):
     for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
         eq_bits(a["trace"][f], b["trace"][f], "trace." + f)
     # which two trajectories share a wavefront is a matter of timing and differs from launch to launch (the first launch of a
-    # process most of all): the bits must not.  (Round 4's first tiled slab lost rows of a deep pass depending on the
+    # process most of all): the bits must not.  (Round 4's first tiled slab lost store data of a deep pass depending on the
     # pairing — costs off in the ninth digit; lone wavefronts, helpers off, are the reference then.)
     eng.set_helper_mode(0)
     eng.set_group_mode(0)
