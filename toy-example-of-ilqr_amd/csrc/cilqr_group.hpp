@@ -112,7 +112,9 @@ __device__ inline void load_cst_lds(Cst& c, const Cst* p) {
 // carries on with it from the next expansion.  Whoever runs an iteration computes the same bits.  One ticket, one parked
 // trajectory; at most CILQR_GRP_MAX_WAITING wavefronts wait at a time (the others leave: a few polled lines must not be
 // hammered by two thousand wavefronts); every wait is bounded.
+#ifndef CILQR_GRP_MAX_WAITING
 #define CILQR_GRP_MAX_WAITING 256
+#endif
 __host__ __device__ inline size_t grp_park_doubles(int N) { // x | u | GrpSt | lane indices
     return (size_t)(4 * (N + 1) + 2 * N + CILQR_GRPST_DOUBLES + (N + 2) / 2 + 1);
 }
