@@ -477,9 +477,9 @@ static int check_ready(cilqr_handle* h) {
 
 extern "C" const char* cilqr_last_error(void) { return g_err.c_str(); }
 #ifdef CILQR_DEV_BUILD
-extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.3-dev (gfx950, wave64, fp64; testing aids + cycle accounting)"; }
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.4-dev (gfx950, wave64, fp64; testing aids + cycle accounting)"; }
 #else
-extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.3 (gfx950, wave64, fp64)"; }
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.4 (gfx950, wave64, fp64)"; }
 #endif
 
 extern "C" int cilqr_create(int device, cilqr_handle** out) {
