@@ -30,6 +30,8 @@ def same(a, b):
 
 
 def engine(wl, tune):
+    if tune and os.environ.get("STRESS_POISON"):  # every launch on scratch pre-filled with NaN patterns (1) or zeros (2)
+        tune = tune + ",poison=" + os.environ["STRESS_POISON"]
     if tune:
         os.environ["CILQR_TUNE"] = tune
     else:
