@@ -1700,3 +1700,31 @@ def test_pairs_at_scale_equal_the_single_build(pkg):
         eq_bits(lone["u"], again["u"], f"u, launch {rep}")
         assert (lone["res"] == again["res"]).all()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_what_the_scratch_held(pkg, monkeypatch):
+    """The kernels' scratch (trial slab, first-trial buffers, gains, expansion rows) is written before it is read, every
+    iteration: filling it with NaN patterns or zeros before each launch (development library, CILQR_TUNE=poison) changes no
+    bit — for lone wavefronts, helper wavefronts and pairs, horizons 50 and 100."""
+    import os
+    W = pkg.workloads
+    for wl, modes in ((W.config3(B=2100), (0, 2)), (W.config2(B=700), (0,)), (W.config4(B=600), (0,))):
+        outs = []
+        for tune in ("", "poison=1", "poison=2"):
+            if tune:
+                monkeypatch.setenv("CILQR_TUNE", tune)
+            else:
+                monkeypatch.delenv("CILQR_TUNE", raising=False)
+            eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True)  # (the switch is read when the handle is made)
+            per_mode = []
+            for mode in modes:
+                eng.set_group_mode(mode)
+                per_mode.append(eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick))
+            outs.append(per_mode)
+            eng.close()
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                eq_bits(a["u"], b["u"], wl.name + " u")
+                eq_bits(a["x"], b["x"], wl.name + " x")
+                assert (a["res"] == b["res"]).all()
