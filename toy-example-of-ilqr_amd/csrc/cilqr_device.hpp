@@ -1203,9 +1203,9 @@ struct RollOut {
 // pass took its horizon as an argument — out of line, so in a VECTOR register — and the compiler, counting loop exits, step
 // index and buffer descriptor as divergent, wrapped every slab store in a loop over the lanes' "distinct" descriptors
 // (v_readfirstlane, compare, s_and_saveexec, store, s_xor exec, s_cbranch_execnz).  On gfx950 with XNACK off a 16-byte store
-// in that shape read the first dword of its data for lanes 12-15 LATE: six instructions behind the store the register held
-// the next store's offset already, and that is what landed in the slab (u0's low half; found with a shadow copy written by a
-// second pass and compared lane by lane; HSA_XNACK=1 makes it vanish).  Costs off in the ninth digit, depending on which two
+// in that shape delivered, for lanes 12-15, the content its first data register received six instructions LATER (the next
+// store's offset: that is what landed in u0's low half; found with a shadow copy written by a second pass and compared lane by
+// lane; wait states or s_waitcnt vmcnt(0) in between change nothing, HSA_XNACK=1 makes it vanish — the mechanism is open).  Costs off in the ninth digit, depending on which two
 // trajectories shared a wavefront.  The cause removed: every descriptor is built from scalars (rollout_group and
 // rollout_trials_rp take the horizon through v_readfirstlane; tests/test_cabi.py scans the shipped disassembly for such loops).
 // This opaque copy changes nothing about that — it was one of the first day's "cures", by way of a different register
