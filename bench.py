@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline workload (profiling passes: every k_solve launch is then the headline's)")
+    ap.add_argument("--in-flight", type=int, default=3, dest="in_flight",
+                    help="batches in flight inside the handle (cilqr_set_batches_in_flight): the K timed steps go round robin to "
+                         "this many launch slots and output buffer sets, so that the next batch's blocks fill the tail of the "
+                         "previous launch; 1 = one launch at a time (what rounds 1-4 reported).  The line states it.")
     ap.add_argument("--streams", type=int, default=1,
                     help="> 1: also measure the same steps with that many batches in flight (one handle and HIP stream "
                          "each) and report it under extra.pipelined — never the headline value.  Off by default so that "
@@ -216,23 +220,74 @@ class GpuRun:
                              self.d_tick.data_ptr(), 0, ou.data_ptr(), ox.data_ptr(), orr.data_ptr(), 0, 0,
                              st.cuda_stream)
 
-    def timed(self, steps, warmup, barrier):
-        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; HIP events on
-        the launch stream around every launch give the kernel's own duration."""
+    def timed(self, steps, warmup, barrier, in_flight=1, seq_steps=0):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides.
+        in_flight = 1: one launch at a time; HIP events on the launch stream around every launch give the kernel's own
+        duration.  in_flight > 1 (cilqr_set_batches_in_flight): the K steps go round robin to that many launch slots of
+        the handle and output buffer sets; the launches overlap, so the kernel time of the region is taken with two
+        events around ALL of it (first launch enqueued ... every slot joined), per-launch durations from the slots' own
+        events, and `seq_steps` further launches are timed one at a time afterwards (not part of the timed region)."""
         torch = self.torch
-        for _ in range(warmup):
-            self.step()
+        self.in_flight = K = max(1, int(in_flight))
+        outs = [(self.d_u, self.d_x, self.d_res)]
+        if K > 1:
+            self.eng.set_batches_in_flight(K)
+            self.eng.set_timing(True)
+            outs += [(torch.empty_like(self.d_u), torch.empty_like(self.d_x), torch.zeros_like(self.d_res)) for _ in range(K - 1)]
+        for i in range(max(warmup, K if K > 1 else 0)):
+            self.step(outs=outs[i % K])
+        if K > 1:
+            self.eng.join_device(self.stream.cuda_stream)
         barrier()
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        t0 = time.perf_counter()
-        for i in range(steps):
-            ev0[i].record(self.stream)
-            self.step()
-            ev1[i].record(self.stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        extra = {}
+        if K == 1:
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ev0[i].record(self.stream)
+                self.step()
+                ev1[i].record(self.stream)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(self.stream)
+            for i in range(steps):
+                self.step(outs=outs[i % K])
+            self.eng.join_device(self.stream.cuda_stream)
+            e1.record(self.stream)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            region_ms = float(e0.elapsed_time(e1))
+            kernel_ms = region_ms / steps  # effective: the launches overlap
+            per_launch = [self.eng.slot_kernel_ms(k) for k in range(K)]
+            ident = all(bool(torch.equal(o[0], outs[0][0])) and bool(torch.equal(o[1], outs[0][1])) and bool(torch.equal(o[2], outs[0][2]))
+                        for o in outs[1:])
+            extra = {"in_flight": K, "kernel_region_ms": region_ms,
+                     "kernel_ms_of_one_launch_while_overlapped (last launch of each slot)": per_launch,
+                     "mean_launches_overlapping": float(np.mean(per_launch)) * steps / region_ms if region_ms > 0 else None,
+                     "buffer_sets_identical": ident}
+            if seq_steps > 0:
+                # the same launches one at a time (what rounds 1-4 timed): not part of the timed region above
+                self.eng.set_batches_in_flight(1)
+                ref = (torch.empty_like(self.d_u), torch.empty_like(self.d_x), torch.zeros_like(self.d_res))
+                ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(seq_steps)]
+                ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(seq_steps)]
+                ts = time.perf_counter()
+                for i in range(seq_steps):
+                    ev0[i].record(self.stream)
+                    self.step(outs=ref)
+                    ev1[i].record(self.stream)
+                barrier()
+                ts = time.perf_counter() - ts
+                extra["sequential"] = {"steps": seq_steps, "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])),
+                                       "ms_per_step": ts / seq_steps * 1e3,
+                                       "results_identical_to_in_flight": bool(torch.equal(ref[0], outs[0][0])) and bool(torch.equal(ref[1], outs[0][1]))
+                                       and bool(torch.equal(ref[2], outs[0][2]))}
+        self.flight = extra
         res = np.frombuffer(self.d_res.cpu().numpy().tobytes(), dtype=self.pkg.RESULT_DTYPE)
         try:
             self.launch_info = self.eng.last_launch_info()
@@ -279,15 +334,37 @@ def counters_for(workload):
         return None
 
 
-def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None):
+def csrc_fingerprint():
+    """sha256 over the kernel sources (csrc/*, include/cilqr_amd.h): what the counter passes were collected on vs. what runs"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "toy-example-of-ilqr_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".hpp", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(base, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cilqr_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None, flight=None):
     N, M_of = wl.N, wl.M_of
     alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
     pmc = counters_for(wl.name) if world == 1 else None
     traffic = traffic_src = valu = None
+    traffic_meta = None
     if pmc:
         traffic = pmc.get("hbm_bytes_per_launch_corrected")
         traffic_src = pmc.get("source")
+        try:
+            meta = json.load(open(PMC_FILE)).get("_collected", {})
+        except Exception:  # noqa: BLE001
+            meta = {}
+        now = csrc_fingerprint()
+        traffic_meta = {"collected_at_git": meta.get("git"), "collected_on_csrc_sha16": meta.get("csrc_sha16"),
+                        "this_run_csrc_sha16": now, "collected_with_in_flight": meta.get("in_flight", 1),
+                        "stale": (meta.get("csrc_sha16") != now)}
         if pmc.get("SQ_INSTS_VALU"):
             # the bound that actually applies: vector-instruction issue.  Wave instructions per launch from the
             # SQ counter pass, 4 cycles of a SIMD each at best, against all SIMD-cycles of the live kernel time
@@ -318,12 +395,19 @@ def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None):
                             "computes them (dense 4x4 products, transcendentals NOT weighted), T from this run, over "
                             "the 78.6 TFLOP/s FP64 vector peak"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_collected": traffic_meta,
             "traffic_is": "bytes crossing the L2 <-> fabric boundary per launch (Infinity Cache + HBM; the counters cannot "
                           "tell the two apart: profiles/r03_traffic_calibration.json), from the counter passes of the same "
                           "command — a static file, not this run",
             "kernel": ("k_solve_grp" if (launch_info or {}).get("trajectories_per_wavefront", 1) > 1 else "k_solve"),
             "launch": launch_info, "kernel_ms": kernel_ms,
+            "kernel_ms_is": ("average duration of a launch, one launch at a time (HIP events around every launch)" if not flight else
+                             "EFFECTIVE duration of a launch: kernel time of the whole timed region (two HIP events: first launch enqueued "
+                             "... every launch slot joined) / launches — the launches of the region overlap (batches in flight inside the "
+                             "handle), so achieved = the region's algorithmic bytes / the region's kernel time; rocprofv3's average "
+                             "duration of the kernel in the same command is the OVERLAPPED duration of one launch (next field), "
+                             "`sequential` has the one-at-a-time figure of rounds 1-4"),
+            "in_flight": flight or {"in_flight": 1},
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",
             "valu_issue": valu,
@@ -569,8 +653,10 @@ def main():
     wl, B = make_workload(pkg, cfg_id, args.batch, args.horizon, rank)
     N = wl.N
     run = GpuRun(pkg, torch, wl, B, local_rank)
-    elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier)
+    elapsed, kernel_ms, res = run.timed(args.steps, args.warmup, barrier, in_flight=args.in_flight,
+                                        seq_steps=max(3, args.steps // 4) if args.in_flight > 1 else 0)
     launch_info_main = getattr(run, "launch_info", None)
+    flight_main = getattr(run, "flight", None) or None
     stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, red_dev)
     value = stats[0] * args.steps / tmax
     # every rank's own clock and kernel time: a straggler rank (or a GPU that throttles) is visible in the line
@@ -585,14 +671,16 @@ def main():
 
     # the other workloads of the default command: config 2 (1024 trajectories per GPU), a latency measurement, and —
     # on several GPUs — BASELINE configs[3] (8192 trajectories of horizon 100 per rank)
-    def side_run(cfg, steps_side, note, alm=False, cpu_check_rows=0):
+    def side_run(cfg, steps_side, note, alm=False, cpu_check_rows=0, in_flight=1):
         wl_s, B_s = _make_workload(pkg, cfg, 0, 0, rank)
         if alm:
             wl_s = pkg.workloads.Workload(wl_s.name + "_alm", [pkg.copy_params(q, solve_type=1) for q in wl_s.params],
                                           wl_s.scenes, wl_s.x0, wl_s.scenario_id, wl_s.param_id, wl_s.tick)
         run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
-        el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier)
+        el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier, in_flight=in_flight,
+                                         seq_steps=max(3, steps_side // 3) if in_flight > 1 else 0)
         li_s = getattr(run_s, "launch_info", None)
+        fl_s = getattr(run_s, "flight", None) or None
         st_s, tmax_s = st_mod.reduce_stats(st_mod.local_stats(res_s, wl_s.N, wl_s.M_of), el_s, dist, red_dev)
         chk = None
         if rank == 0 and cpu_check_rows and not args.no_cpu_baseline:
@@ -602,7 +690,7 @@ def main():
         pr_s = gather_objects(dist, kms_s, world)
         if rank != 0:
             return None
-        rl = roofline_block(pkg, wl_s, res_s, kms_s, world, li_s)
+        rl = roofline_block(pkg, wl_s, res_s, kms_s, world, li_s, fl_s)
         cpu_chk = None
         if chk is not None:  # the launch that was just timed against the oracle's libm build (checker only)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -621,7 +709,7 @@ def main():
                                    "the bit-identity with the oracle's detmath build in this object")
         return {"cpu_check": cpu_chk, "workload": wl_s.name, "baseline_config": cfg, "batch_per_gpu": B_s, "global_batch": int(st_s[8]),
                 "horizon": wl_s.N, "steps": steps_side, "value": st_s[0] * steps_side / tmax_s, "unit": "iLQR iterations/s",
-                "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": kms_s,
+                "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": kms_s, "in_flight": rl["in_flight"],
                 "kernel_ms_min_max_over_ranks": [float(min(pr_s)), float(max(pr_s))],
                 "iterations_per_launch_rank0": float(res_s["iters"].sum()),
                 "slowest_trajectory_iterations": int(res_s["iters"].max()),
@@ -663,13 +751,16 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported in the line
             return {"error": f"{type(e).__name__}: {e}"[:500]} if rank == 0 else None
 
-    second = fourth = closed = alm5 = None
+    second = third = fourth = closed = alm5 = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
+        third = guarded(side_run, 3, max(args.steps, 20), "BASELINE configs[2]: 8192 three_bend trajectories = two rounds of the "
+                        "chip's trajectory slots; one launch at a time a third of it is tail (`in_flight.sequential`)",
+                        in_flight=args.in_flight)
         second = guarded(side_run, 2, max(args.steps, 20), "one launch of 1024 trajectories occupies a quarter of the chip's "
                          "wave slots; its wall time is the slowest trajectory's (DESIGN.md)")
         fourth = guarded(side_run, 4, max(3, args.steps // 4), "BASELINE configs[3]: 65 536 mixed scenarios of horizon 100 "
                          "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs; at fewer, the "
-                         "first ranks' shards)", cpu_check_rows=512)
+                         "first ranks' shards)", cpu_check_rows=512, in_flight=args.in_flight)
         closed = guarded(closed_loop_extra)
         alm5 = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm (cs:88-93, 253-261, "
                        "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True,
@@ -682,13 +773,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B,
+            "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B, "batches_in_flight": args.in_flight,
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
                        "parallelism": f"trajectory-sharded x{world}, "
                                       + {1: "one wavefront per trajectory", 2: "two trajectories per wavefront",
                                          3: "three trajectories per wavefront"}.get(
                                              (launch_info_main or {}).get("trajectories_per_wavefront", 1), "one wavefront per trajectory")},
-            "roofline": roofline_block(pkg, wl, res, kernel_ms, world, launch_info_main),
+            "roofline": roofline_block(pkg, wl, res, kernel_ms, world, launch_info_main, flight_main),
             "extra": {"iterations_per_step_rank0": my_iters, "iterations_per_solve_mean": my_iters / B,
                       "line_search_trials_per_step": float(stats[1]),
                       "solves_per_s": stats[8] * args.steps / tmax,
@@ -697,7 +788,7 @@ def main():
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
                       ("config2_latency" if world == 1 else "config2_weak_scaling"): second,
-                      "config4_sharded": fourth, "closed_loop": closed, "config5_alm": alm5,
+                      "config3": third, "config4_sharded": fourth, "closed_loop": closed, "config5_alm": alm5,
                       "ranks": ranks, "distinct_devices": distinct, "per_rank": per_rank,
                       "kernel_ms_min_max_over_ranks": [float(min(r["kernel_ms"] for r in per_rank)),
                                                        float(max(r["kernel_ms"] for r in per_rank))]},

@@ -195,6 +195,27 @@ int cilqr_closed_loop_batch_device(cilqr_handle* h, int32_t B, int32_t ticks, do
                                    double* d_x_out, cilqr_result* d_res_out, double* d_states, int32_t* d_iters,
                                    void* stream);
 
+/* Batches in flight (round 5).  k = 1 (default): the behaviour described above — one launch of the handle at a time, on the
+ * caller's stream.  k = 2 ... 4: the handle owns k LAUNCH SLOTS, each with an internal stream, trial slabs, control words and
+ * parked-solve state of its own (the parameter and scenario tables are shared), and consecutive cilqr_solve_batch_device /
+ * cilqr_closed_loop_batch_device calls go to the slots round robin.  A launch ends with its longest solves on a chip that is
+ * emptying (the tail: 5 % of a 65 536-trajectory launch, a third of an 8 192-trajectory one); with batches in flight the
+ * persistent blocks of the next batch move into the wave slots the tail frees.  Semantics in this mode:
+ *   - a launch starts after everything that was enqueued on `stream` before the call (an event: the caller's copies into
+ *     x0 / tick are seen), after the previous launch of its slot, and after every launch still in flight whose buffers
+ *     overlap its own with a write on either side (address ranges of x0, ids, tick, last_u, u_out, x_out, res, trace,
+ *     states, iters: a warm start from the previous call's u_out, or the same output arrays, orders the two automatically);
+ *   - `stream` does NOT wait for the launch: results are complete on a stream after cilqr_join_device(h, that stream), on the
+ *     host after cilqr_wait(h).  Every other entry point of the handle (host-buffer calls, cilqr_advance_batch_device,
+ *     piecewise calls, cilqr_set_params / _scenarios) joins first, by itself;
+ *   - handles in "alm" mode (multipliers per trajectory live in the handle) and the development aids keep one launch at a
+ *     time whatever k.
+ * Results do not depend on k.  cilqr_slot_kernel_ms: duration of slot k's last launch when cilqr_set_timing is on. */
+int cilqr_set_batches_in_flight(cilqr_handle* h, int32_t k);
+int cilqr_join_device(cilqr_handle* h, void* stream);
+int cilqr_wait(cilqr_handle* h);
+int cilqr_slot_kernel_ms(cilqr_handle* h, int32_t k, float* ms);
+
 /* Wall time of the most recent solve kernel measured with HIP events on its own stream (ms). */
 int cilqr_last_kernel_ms(cilqr_handle* h, float* ms);
 /* Shape of the most recent fused launch: out = { trajectories per wavefront (1: k_solve, 2 or 3: k_solve_grp), blocks in the

@@ -37,6 +37,36 @@ int orc_math_mode(void) { return 1; }
 int orc_math_mode(void) { return 0; }
 #endif
 
+/* Optional recorder of the ARGUMENTS the path hands to its elementary functions (liboracle_rec.so only, -DORC_RECORD: the
+ * libm flavour plus this): tests/test_pins.py dumps them from real solves and measures detmath against glibc exactly
+ * there.  Single-threaded use only. */
+#ifdef ORC_RECORD
+static double* orc_rec_buf = 0; /* [cap][3] = (function code 0..5, x, y) */
+static long orc_rec_cap = 0, orc_rec_n = 0;
+void orc_record_math(double* buf, long cap) { orc_rec_buf = buf; orc_rec_cap = cap; orc_rec_n = 0; }
+long orc_record_count(void) { return orc_rec_n; }
+static inline double orc_rec(int f, double x, double y, double r) {
+    if (orc_rec_buf && orc_rec_n < orc_rec_cap) {
+        double* o = orc_rec_buf + 3 * orc_rec_n;
+        o[0] = (double)f; o[1] = x; o[2] = y;
+    }
+    orc_rec_n++;
+    return r;
+}
+#undef M_EXP
+#undef M_SIN
+#undef M_COS
+#undef M_TAN
+#undef M_ATAN
+#undef M_HYPOT
+#define M_EXP(x) orc_rec(0, (x), 0.0, exp(x))
+#define M_SIN(x) orc_rec(1, (x), 0.0, sin(x))
+#define M_COS(x) orc_rec(2, (x), 0.0, cos(x))
+#define M_TAN(x) orc_rec(3, (x), 0.0, tan(x))
+#define M_ATAN(x) orc_rec(4, (x), 0.0, atan(x))
+#define M_HYPOT(x, y) orc_rec(5, (x), (y), hypot((x), (y)))
+#endif
+
 #define ORC_EPS 1e-5 /* include/utils.hpp:28 */
 
 /* The FUSED flavour (round 4, an experiment the review of round 3 asked for: what does bit-identity with an unfused
@@ -60,6 +90,20 @@ double orc_m_cos(double x) { return M_COS(x); }
 double orc_m_tan(double x) { return M_TAN(x); }
 double orc_m_atan(double x) { return M_ATAN(x); }
 double orc_m_hypot(double x, double y) { return M_HYPOT(x, y); }
+/* the same, n at a time: func 0 exp, 1 sin, 2 cos, 3 tan, 4 atan, 5 hypot(x, y) */
+void orc_m_vec(int32_t func, const double* x, const double* y, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = x[i], b = y ? y[i] : 0.0;
+        switch (func) {
+            case 0: out[i] = M_EXP(a); break;
+            case 1: out[i] = M_SIN(a); break;
+            case 2: out[i] = M_COS(a); break;
+            case 3: out[i] = M_TAN(a); break;
+            case 4: out[i] = M_ATAN(a); break;
+            default: out[i] = M_HYPOT(a, b); break;
+        }
+    }
+}
 
 struct orc_solver {
     orc_params p;
@@ -284,6 +328,13 @@ static void lagrangian_derivative_and_Hessian(double c, const double* c_dot, int
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) b_ddot[i * n + j] = b_dot[i] * c_dot[j];
     }
+}
+
+/* the two ALM leaf functions, exported for tests/test_pins.py */
+double orc_alm_item(double c, double rho, double mu) { return augmented_lagrangian_item(c, rho, mu); }
+void orc_lagrangian_derivative_and_Hessian(double c, const double* c_dot, int32_t n, double rho, double mu, double* b_dot,
+                                           double* b_ddot) {
+    lagrangian_derivative_and_Hessian(c, c_dot, n, rho, mu, b_dot, b_ddot);
 }
 
 /* ---------- cs:316-324 get_bound_constr ---------- */

@@ -110,8 +110,8 @@ typedef struct orc_margin_rec {
 } orc_margin_rec;
 void orc_set_margin_buffer(orc_solver* s, orc_margin_rec* buf, int32_t cap);
 
-int orc_math_mode(void);
-int orc_fused(void); /* 1 in the fused-flavour build (-DORC_FUSED: an experiment, see cilqr_oracle.c) */ /* 0 = libm, 1 = detmath */
+int orc_math_mode(void); /* 0 = libm, 1 = detmath */
+int orc_fused(void);     /* 1 in the fused-flavour build (-DORC_FUSED: an experiment, see cilqr_oracle.c) */
 
 orc_solver* orc_create(const orc_params* p);
 void orc_destroy(orc_solver* s);
@@ -178,6 +178,14 @@ double orc_m_cos(double x);
 double orc_m_tan(double x);
 double orc_m_atan(double x);
 double orc_m_hypot(double x, double y);
+void orc_m_vec(int32_t func, const double* x, const double* y, int64_t n, double* out);
+double orc_alm_item(double c, double rho, double mu);                       /* hpp:81-83 */
+void orc_lagrangian_derivative_and_Hessian(double c, const double* c_dot, int32_t n, double rho, double mu, double* b_dot,
+                                           double* b_ddot);                  /* cs:701-713 */
+#ifdef ORC_RECORD
+void orc_record_math(double* buf, long cap); /* liboracle_rec.so: record (function, x, y) of every elementary-function call */
+long orc_record_count(void);
+#endif
 
 #ifdef __cplusplus
 }

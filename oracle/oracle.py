@@ -103,12 +103,15 @@ class Scene:
 
 class Oracle:
     def __init__(self, mode="det"):
-        assert mode in ("det", "libm", "fused")
+        assert mode in ("det", "libm", "fused", "rec", "det!")
         # round-4 experiment: CILQR_ORACLE_FUSED=1 makes "det" mean the fused-flavour build (detmath + explicit fma at four
-        # named groups of sites), the checker of a device library compiled with -DCILQR_FUSED
+        # named groups of sites), the checker of a device library compiled with -DCILQR_FUSED; "det!" = the detmath build
+        # whatever the environment says (the test that compares the two flavours)
         import os
         if mode == "det" and os.environ.get("CILQR_ORACLE_FUSED") == "1":
             mode = "fused"
+        if mode == "det!":
+            mode = "det"
         path = HERE / f"liboracle_{mode}.so"
         if not path.exists():
             ensure_built()
@@ -144,13 +147,19 @@ class Oracle:
             "orc_forward_pass": (None, [C.POINTER(OrcParams), V, V, V, V, D, V, V]),
             "orc_m_exp": (D, [D]), "orc_m_sin": (D, [D]), "orc_m_cos": (D, [D]), "orc_m_tan": (D, [D]),
             "orc_m_atan": (D, [D]), "orc_m_hypot": (D, [D, D]),
+            "orc_m_vec": (None, [I, V, V, C.c_int64, V]),
+            "orc_alm_item": (D, [D, D, D]),
+            "orc_lagrangian_derivative_and_Hessian": (None, [D, V, I, D, D, V, V]),
         }
+        if mode == "rec":
+            sig["orc_record_math"] = (None, [V, C.c_long])
+            sig["orc_record_count"] = (C.c_long, [])
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
         self.lib = lib
-        assert lib.orc_math_mode() == (0 if mode == "libm" else 1)
+        assert lib.orc_math_mode() == (0 if mode in ("libm", "rec") else 1)
         lib.orc_fused.restype = C.c_int
         assert lib.orc_fused() == (1 if mode == "fused" else 0)
 
@@ -255,13 +264,34 @@ class Oracle:
         self.lib.orc_forward_pass(C.byref(p), _p(_f64(u)), _p(_f64(x)), _p(_f64(d)), _p(_f64(K)), alpha, _p(nu), _p(nx))
         return nu, nx
 
+    MATH_CODES = {"exp": 0, "sin": 1, "cos": 2, "tan": 3, "atan": 4, "hypot": 5}
+
     def math(self, name, x, y=None):
-        fn = getattr(self.lib, "orc_m_" + name)
-        x = np.asarray(x, dtype=np.float64).ravel()
-        if y is None:
-            return np.array([fn(float(v)) for v in x])
-        y = np.asarray(y, dtype=np.float64).ravel()
-        return np.array([fn(float(a), float(b)) for a, b in zip(x, y)])
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        y = None if y is None else np.ascontiguousarray(y, dtype=np.float64).ravel()
+        out = np.empty_like(x)
+        self.lib.orc_m_vec(self.MATH_CODES[name], _p(x), _p(y), x.shape[0], _p(out))
+        return out
+
+    def alm_item(self, c, rho, mu):
+        return self.lib.orc_alm_item(float(c), float(rho), float(mu))
+
+    def lagrangian_dH(self, c, c_dot, rho, mu):
+        c_dot = _f64(c_dot)
+        n = c_dot.shape[0]
+        bd, bdd = np.empty(n), np.empty((n, n))
+        self.lib.orc_lagrangian_derivative_and_Hessian(float(c), _p(c_dot), n, float(rho), float(mu), _p(bd), _p(bdd))
+        return bd, bdd
+
+    def record_math(self, cap):
+        """liboracle_rec.so: start recording (function, x, y) of every elementary-function call; returns the buffer"""
+        buf = np.zeros((cap, 3))
+        self._rec_buf = buf
+        self.lib.orc_record_math(_p(buf), cap)
+        return buf
+
+    def record_count(self):
+        return int(self.lib.orc_record_count())
 
 
 class OracleSolver:

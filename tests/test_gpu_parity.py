@@ -1728,3 +1728,132 @@ def test_results_do_not_depend_on_what_the_scratch_held(pkg, monkeypatch):
                 eq_bits(a["u"], b["u"], wl.name + " u")
                 eq_bits(a["x"], b["x"], wl.name + " x")
                 assert (a["res"] == b["res"]).all()
+
+
+
+_IN_FLIGHT_SCRIPT = r"""
+import sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import cilqr_amd as pkg
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream(dev).cuda_stream
+to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+RES = pkg.RESULT_DTYPE
+def res_of(t):
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=RES)
+def bufs(B, N):
+    return (torch.zeros((B, N, 2), dtype=torch.float64, device=dev), torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev),
+            torch.zeros((B, RES.itemsize), dtype=torch.uint8, device=dev))
+def same(a, b):
+    return bool(torch.equal(a[0], b[0])) and bool(torch.equal(a[1], b[1])) and bool(torch.equal(a[2], b[2]))
+
+for wl_of, what in ((lambda f: pkg.workloads.config3(B=3000, first=f), "config 3 geometry (pairs per wavefront, persistent blocks, hand-over at the tail)"),
+                    (lambda f: pkg.workloads.config4(B=2400, N=100, first=f), "horizon 100 (work sharing between blocks, resumable solves)"),
+                    (lambda f: pkg.workloads.config2(B=700, first=f), "helper wavefronts")):
+    wls = [wl_of(f) for f in (0, 5000, 10000, 15000, 20000)]
+    B, N = wls[0].B, wls[0].N
+    eng = pkg.BatchedCILQR(wls[0].params, wls[0].scenes)
+    ins = [(to(w.x0), to(w.scenario_id), to(w.param_id), to(w.tick)) for w in wls]
+    def solve(i, out, last_u=0):
+        eng.solve_batch_device(B, ins[i][0].data_ptr(), ins[i][1].data_ptr(), ins[i][2].data_ptr(), ins[i][3].data_ptr(), last_u,
+                               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), 0, 0, st)
+    # the reference: one launch at a time
+    ref = [bufs(B, N) for _ in wls]
+    for i in range(len(wls)):
+        solve(i, ref[i])
+    torch.cuda.synchronize(dev)
+    assert res_of(ref[0][2])["iters"].sum() > B
+    for K in (2, 3, 4):
+        eng.set_batches_in_flight(K)
+        out = [bufs(B, N) for _ in wls]
+        for rep in range(2):
+            for i in range(len(wls)):
+                solve(i, out[i])
+        eng.join_device(st)
+        torch.cuda.synchronize(dev)
+        for i in range(len(wls)):
+            assert same(out[i], ref[i]), (what, K, i)
+        # hazards: every call into the SAME output arrays (write after write: ordered, the last one stays) ...
+        one = bufs(B, N)
+        for i in range(len(wls)):
+            solve(i, one)
+        eng.wait()
+        assert same(one, ref[-1]), (what, K, "same outputs")
+        # ... and a chain of warm starts, each from the previous call's plan (read after write)
+        chain = [bufs(B, N) for _ in range(3)]
+        solve(0, chain[0])
+        solve(0, chain[1], chain[0][0].data_ptr())
+        solve(0, chain[2], chain[1][0].data_ptr())
+        eng.wait()
+        eng.set_batches_in_flight(1)
+        seq = [bufs(B, N) for _ in range(3)]
+        solve(0, seq[0])
+        solve(0, seq[1], seq[0][0].data_ptr())
+        solve(0, seq[2], seq[1][0].data_ptr())
+        torch.cuda.synchronize(dev)
+        for a, b in zip(chain, seq):
+            assert same(a, b), (what, K, "warm-start chain")
+    # launches in flight, then a host-buffer call and the step after the path: both join by themselves
+    eng.set_batches_in_flight(3)
+    out = [bufs(B, N) for _ in range(3)]
+    for i in range(3):
+        solve(i, out[i])
+    host = eng.solve_batch(wls[3].x0, wls[3].scenario_id, wls[3].param_id, wls[3].tick)
+    assert np.array_equal(host["u"], ref[3][0].cpu().numpy()) and (host["res"] == res_of(ref[3][2])).all()
+    x0n = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    for i in range(3):
+        solve(i, out[i])
+    eng.advance_batch_device(B, out[2][1].data_ptr(), x0n.data_ptr(), 0, st)
+    torch.cuda.synchronize(dev)
+    assert bool(torch.equal(x0n, ref[2][1][:, 1, :]))
+    for i in range(3):
+        assert same(out[i], ref[i])
+    eng.close()
+
+# the closed loop in one launch, two fleets in flight
+cfg = pkg.GlobalConfig.get_instance("three_straight")
+sc = pkg.build_scenario(cfg, "three_straight")
+p = pkg.params_from_config(cfg, N=30, use_last_solution=1)
+B, ticks, N = 2500, 6, 30
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+def fleet(seed):
+    x0 = to(pkg.workloads.perturbed_starts(sc.ego_state, B, seed))
+    tick = torch.zeros(B, dtype=torch.int32, device=dev)
+    o = bufs(B, N)
+    states = torch.zeros((B, ticks, 4), dtype=torch.float64, device=dev)
+    return [x0, tick, o, states]
+def run(f):
+    eng.closed_loop_batch_device(B, ticks, f[0].data_ptr(), 0, 0, f[1].data_ptr(), 0, f[2][0].data_ptr(), f[2][1].data_ptr(),
+                                 f[2][2].data_ptr(), f[3].data_ptr(), 0, st)
+seq = [fleet(1), fleet(2), fleet(3)]
+for f in seq:
+    run(f)
+torch.cuda.synchronize(dev)
+eng.set_batches_in_flight(3)
+par = [fleet(1), fleet(2), fleet(3)]
+for f in par:
+    run(f)
+eng.wait()
+for a, b in zip(seq, par):
+    assert same(a[2], b[2]) and bool(torch.equal(a[3], b[3])) and bool(torch.equal(a[0], b[0])) and bool(torch.equal(a[1], b[1]))
+eng.close()
+print("IN-FLIGHT-OK")
+"""
+
+
+def test_batches_in_flight_inside_one_handle():
+    """cilqr_set_batches_in_flight (round 5): k launch slots inside one handle — internal streams, scratch and control
+    words per slot, tables shared.  Five different batches through 2, 3 and 4 slots equal the same batches one launch at
+    a time, bit for bit, on the three launch shapes (pairs per wavefront with the hand-over at the tail; horizon 100 with
+    work sharing and resumable solves; helper wavefronts); calls that share output arrays or chain warm starts are
+    ordered by the library's own hazard tracking; host-buffer calls and cilqr_advance_batch_device join by themselves;
+    the closed loop in one launch with three fleets in flight."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _IN_FLIGHT_SCRIPT, root], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "IN-FLIGHT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -186,7 +186,7 @@ def test_fused_flavour_of_the_oracle_is_a_different_but_close_arithmetic(pkg_cpu
     p = pkg.params_from_config(cfg, N=50, use_last_solution=0)
     scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity)
     x0 = pkg.workloads.perturbed_starts(sc.ego_state, 16, 99)
-    det = Oracle("det").solve_batch(p, scene, x0, n_threads=2)
+    det = Oracle("det!").solve_batch(p, scene, x0, n_threads=2)  # (the detmath build whatever CILQR_ORACLE_FUSED says)
     fus = Oracle("fused").solve_batch(p, scene, x0, n_threads=2)
     assert (det["res"]["iters"] == fus["res"]["iters"]).all()
     assert not np.array_equal(det["x"], fus["x"])

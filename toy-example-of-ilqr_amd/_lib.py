@@ -104,6 +104,10 @@ SIGNATURES = {
     "cilqr_advance_batch_device": (C.c_int, [_P, _I, _P, _P, _P, _P]),
     "cilqr_closed_loop_batch_device": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cilqr_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "cilqr_set_batches_in_flight": (C.c_int, [_P, _I]),
+    "cilqr_join_device": (C.c_int, [_P, _P]),
+    "cilqr_wait": (C.c_int, [_P]),
+    "cilqr_slot_kernel_ms": (C.c_int, [_P, _I, C.POINTER(C.c_float)]),
     "cilqr_set_timing": (C.c_int, [_P, _I]),
     "cilqr_set_phase_profiling": (C.c_int, [_P, _I]),
     "cilqr_set_block_timeline": (C.c_int, [_P, _I]),

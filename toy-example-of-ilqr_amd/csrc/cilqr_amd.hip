@@ -287,13 +287,39 @@ struct DevBuf {
     }
 };
 
+// What belongs to ONE launch in flight: the trial slabs, the control words (trajectory counter of the persistent blocks,
+// work-sharing counters and slots), the parked-solve state, the timing events.  A handle has one such set by default —
+// its launches are then ordered, one at a time — and up to CILQR_MAX_IN_FLIGHT of them after
+// cilqr_set_batches_in_flight(): independent batches then overlap on the device, the tables shared (round 5).
+#define CILQR_MAX_IN_FLIGHT 4
+struct MemRange { const char* p; size_t n; bool w; };
+struct LaunchSlot {
+    hipStream_t stream = nullptr;       // internal stream of the slot (in-flight mode only; null: the caller's stream carries the launch)
+    hipEvent_t done = nullptr;          // recorded behind the slot's last launch (or behind anything else that used its buffers)
+    hipStream_t last_stream = nullptr;  // the stream `done` was recorded on
+    bool launched = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed_pending = false;
+    float last_ms = 0.f;
+    DevBuf scratch;
+    DevBuf park, rq;
+    int park_B = 0, park_N = 0;
+    DevBuf sh_ctl, sh_req, sh_hints;
+    int sh_B = 0, sh_N = 0;
+    std::vector<MemRange> ranges;       // the caller's buffers the slot's last solve reads / writes (in-flight mode: hazards)
+};
+#define SL(h) ((h)->slot[(h)->cur])
+
 struct cilqr_handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LaunchSlot slot[CILQR_MAX_IN_FLIGHT];
+    int cur = 0;        // the slot the call in progress uses / the last launch used
+    int in_flight = 1;  // cilqr_set_batches_in_flight
+    int next_slot = 0;
+    bool force_seq = false; // the call in progress is a host-buffer entry point: slot 0 on the handle's stream, ordered
+    hipEvent_t ev_in = nullptr; // in-flight mode: marks the caller's stream at the call (its earlier work = the launch's inputs)
     bool timing = false;
-    bool timed_pending = false;
-    float last_ms = 0.f;
     // tables
     std::vector<cilqr_params> params;
     DevBuf d_params;
@@ -306,7 +332,6 @@ struct cilqr_handle {
     int win = 0;      // LDS lane-window capacity in samples (derived from the tables)
     int win_occ = 0;  // the same when two wavefronts per SIMD are wanted (large batches), one stage-cost slot
     int win_occ2 = 0; // ... with two stage-cost slots (paired passes)
-    DevBuf scratch;
     DevBuf alm_mu, alm_mu_next, alm_rho; // ALM solve type: per-trajectory multipliers carried across calls
     int alm_B = 0, alm_C = 0, alm_N = 0; // rows, columns and horizon the multiplier arrays were laid out for
     // cilqr_solve (one ego per call, the reference's own call shape): host copy of the tables that are in HBM,
@@ -351,13 +376,9 @@ struct cilqr_handle {
     // resumable solves (k_solve's RES: the two-row builds in persistent launches): iterations per slice, 0 = off.  A
     // launch whose batch fits the chip at once (no second round of trajectories) has nothing to reorder and runs whole.
     int resume_iters = 32;
-    DevBuf park, rq;
-    int park_B = 0, park_N = 0;
     unsigned last_parked = 0;
     bool fused_call = false;   // the call in progress is a fused solve (not a piecewise entry point)
     bool looping = false;      // the call in progress is a closed loop in one launch: the plain builds (see the dispatch)
-    DevBuf sh_ctl, sh_req, sh_hints;
-    int sh_B = 0, sh_N = 0;
     int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
                                // two-wavefronts-per-SIMD range (barrier mode), 0 = never, 1 = wherever a build exists
     int win_lg = 0;            // lane window of those builds
@@ -379,11 +400,6 @@ struct cilqr_handle {
     // resident blocks per CU of each persistent build (asked once per kernel and LDS size, not on every launch)
     struct Occ { const void* kern; size_t shm; int per_cu; };
     std::vector<Occ> occ;
-    // one launch per handle at a time: the control words, the scratch areas and the work-sharing state belong to the
-    // launch in flight.  A launch on another stream than the previous one waits for it (event, device side).
-    hipEvent_t ev_launch = nullptr;
-    hipStream_t last_stream = nullptr;
-    bool launched = false;
 };
 
 // Persistent launches use one scratch area per resident block: never more than this many per CU, whatever the
@@ -452,17 +468,42 @@ static void update_window(cilqr_handle* h) {
     }
 }
 
-// One launch per handle at a time (scratch areas, control words, timeline and staging buffers belong to the launch in
-// flight): work enqueued on another stream than the handle's previous launch first waits for it, on the device.  Called
-// before ANY asynchronous work that touches handle buffers.
-static int order_after_last_launch(cilqr_handle* h, hipStream_t s) {
-    if (h->launched && h->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, h->ev_launch, 0));
+// One launch per SLOT at a time (scratch areas, control words and parked-solve state belong to the launch in flight; a handle
+// has one slot unless cilqr_set_batches_in_flight() gave it more): work enqueued on another stream than the slot's previous
+// launch first waits for it, on the device.
+static int order_after_slot(cilqr_handle* h, int k, hipStream_t s) {
+    LaunchSlot& sl = h->slot[k];
+    if (sl.launched && sl.last_stream != s) HIP_TRY(hipStreamWaitEvent(s, sl.done, 0));
     return CILQR_OK;
 }
-// Host-side wait for the handle's own last launch (before its arrays are replaced): the other handles of the process and
+// ... and after EVERY launch of the handle in flight: called before any asynchronous work that touches handle-wide buffers
+// (staging, timeline, multipliers) or the caller's arrays outside the solve entry points' own hazard tracking.
+static int order_after_last_launch(cilqr_handle* h, hipStream_t s) {
+    for (int k = 0; k < CILQR_MAX_IN_FLIGHT; ++k) {
+        int rc = order_after_slot(h, k, s);
+        if (rc) return rc;
+    }
+    return CILQR_OK;
+}
+// Host-side wait for the handle's own launches (before its arrays are replaced): the other handles of the process and
 // their streams are left alone — a hipDeviceSynchronize() here stalled every batch in flight.
+static int wait_slot(cilqr_handle* h, int k) {
+    if (h->slot[k].launched) HIP_TRY(hipEventSynchronize(h->slot[k].done));
+    return CILQR_OK;
+}
 static int wait_last_launch(cilqr_handle* h) {
-    if (h->launched) HIP_TRY(hipEventSynchronize(h->ev_launch));
+    for (int k = 0; k < CILQR_MAX_IN_FLIGHT; ++k) {
+        int rc = wait_slot(h, k);
+        if (rc) return rc;
+    }
+    return CILQR_OK;
+}
+// `s` has just been given work that used slot k's buffers (or, slot 0, the handle-wide ones)
+static int mark_slot(cilqr_handle* h, int k, hipStream_t s) {
+    LaunchSlot& sl = h->slot[k];
+    HIP_TRY(hipEventRecord(sl.done, s));
+    sl.last_stream = s;
+    sl.launched = true;
     return CILQR_OK;
 }
 
@@ -538,9 +579,12 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
         if (prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     }
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&h->ev0));
-    HIP_TRY(hipEventCreate(&h->ev1));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_launch, hipEventDisableTiming));
+    for (auto& sl : h->slot) {
+        HIP_TRY(hipEventCreate(&sl.ev0));
+        HIP_TRY(hipEventCreate(&sl.ev1));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     *out = h;
     return CILQR_OK;
 }
@@ -559,12 +603,22 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     if (!h) return CILQR_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)wait_last_launch(h);
+    for (auto& sl : h->slot)
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     free_scenes(h);
     h->d_params.release();
     h->d_scenes.release();
-    h->scratch.release();
-    h->sh_ctl.release(); h->sh_req.release(); h->sh_hints.release();
-    h->park.release(); h->rq.release();
+    for (auto& sl : h->slot) {
+        sl.scratch.release();
+        sl.sh_ctl.release(); sl.sh_req.release(); sl.sh_hints.release();
+        sl.park.release(); sl.rq.release();
+        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     h->tl.release();
     h->alm_mu.release();
     h->alm_mu_next.release();
@@ -573,9 +627,6 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     for (auto& s : h->st) s.release();
     if (h->one.pinned) (void)hipHostFree(h->one.pinned);
     if (h->one.dev) (void)hipFree(h->one.dev);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ev_launch) (void)hipEventDestroy(h->ev_launch);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CILQR_OK;
@@ -676,11 +727,11 @@ extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
     h->last_parked = 0;
     // the control words are zeroed by persistent launches only: after any other launch they still hold an earlier
     // launch's counts, which are not this handle's last launch's — report zeros then
-    if (!h->sh_ctl.p || !h->last_launch_reset_ctl) return CILQR_OK;
+    if (!SL(h).sh_ctl.p || !h->last_launch_reset_ctl) return CILQR_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     unsigned w[SH_SLOT0];
-    HIP_TRY(hipMemcpy(w, h->sh_ctl.p, sizeof(w), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(w, SL(h).sh_ctl.p, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = w[SH_ANNOUNCED]; out[1] = w[SH_HELPED]; out[2] = w[SH_HELPERS]; out[3] = w[SH_ERROR];
     h->last_parked = w[SH_PARKED];
     return CILQR_OK;
@@ -708,6 +759,54 @@ extern "C" int cilqr_set_group_mode(cilqr_handle* h, int32_t mode) {
     return CILQR_OK;
 }
 
+// Batches in flight (include/cilqr_amd.h): k launch slots, each with a stream of its own
+extern "C" int cilqr_set_batches_in_flight(cilqr_handle* h, int32_t k) {
+    if (!h || k < 1 || k > CILQR_MAX_IN_FLIGHT) return fail(CILQR_ERR_BAD_ARG, "batches in flight must be in [1, 4]");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = wait_last_launch(h); // (slots change hands: nothing of this handle may be in flight)
+    if (rc) return rc;
+    // The slots' streams are created at the HIGHEST stream priority: the runtime keeps one pool of hardware queues per
+    // priority level and spreads the streams of a level over its (four) queues, so these get queues of their own instead of
+    // sharing one with the caller's stream.  Measured with three slots at normal priority: the third slot's stream landed on
+    // the hardware queue of the caller's stream, the per-call event record the launches wait for (`ev_in`) queued up behind
+    // that slot's 65 ms kernel, and every third launch waited for it — 9.8 ms per 8 192-trajectory batch against 8.9 with two
+    // or four slots (profiles/r05_experiments/in_flight_stream_priority.txt).
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    for (int i = 0; i < k; ++i)
+        if (k > 1 && !h->slot[i].stream)
+            HIP_TRY(hipStreamCreateWithPriority(&h->slot[i].stream, hipStreamNonBlocking, prio_greatest));
+    h->in_flight = k;
+    h->next_slot = 0;
+    h->cur = 0;
+    return CILQR_OK;
+}
+
+extern "C" int cilqr_join_device(cilqr_handle* h, void* stream) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return order_after_last_launch(h, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cilqr_wait(cilqr_handle* h) {
+    if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return wait_last_launch(h);
+}
+
+extern "C" int cilqr_slot_kernel_ms(cilqr_handle* h, int32_t k, float* ms) {
+    if (!h || !ms || k < 0 || k >= CILQR_MAX_IN_FLIGHT) return fail(CILQR_ERR_BAD_ARG, "bad argument");
+    LaunchSlot& sl = h->slot[k];
+    if (sl.timed_pending) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipEventSynchronize(sl.ev1));
+        HIP_TRY(hipEventElapsedTime(&sl.last_ms, sl.ev0, sl.ev1));
+        sl.timed_pending = false;
+    }
+    *ms = sl.last_ms;
+    return CILQR_OK;
+}
+
 extern "C" int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B) {
     if (!h || !out || B < 1 || B > h->prof_B || !h->prof.p) return fail(CILQR_ERR_BAD_ARG, "no phase profile available");
     HIP_TRY(hipSetDevice(h->device));
@@ -718,13 +817,13 @@ extern "C" int cilqr_get_phase_cycles(cilqr_handle* h, int64_t* out, int32_t B) 
 
 extern "C" int cilqr_last_kernel_ms(cilqr_handle* h, float* ms) {
     if (!h || !ms) return fail(CILQR_ERR_BAD_ARG, "null argument");
-    if (h->timed_pending) {
+    if (SL(h).timed_pending) {
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipEventSynchronize(h->ev1));
-        HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-        h->timed_pending = false;
+        HIP_TRY(hipEventSynchronize(SL(h).ev1));
+        HIP_TRY(hipEventElapsedTime(&SL(h).last_ms, SL(h).ev0, SL(h).ev1));
+        SL(h).timed_pending = false;
     }
-    *ms = h->last_ms;
+    *ms = SL(h).last_ms;
     return CILQR_OK;
 }
 
@@ -746,6 +845,10 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
         if (p.max_iter < 0) return fail(CILQR_ERR_BAD_ARG, "max_iter < 0");
     }
     HIP_TRY(hipSetDevice(h->device));
+    {
+        int rcw = wait_last_launch(h); // (launches in flight read the table that is about to be rewritten)
+        if (rcw) return rcw;
+    }
     if (!h->params.empty() && (h->params[0].N != params[0].N || h->params[0].solve_type != params[0].solve_type)) {
         // the multiplier arrays are [B][N][C]: another horizon (or leaving ALM mode) makes their contents
         // meaningless and their size wrong — the next ALM solve allocates and zeroes them afresh
@@ -1006,7 +1109,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.scenario_id = ids.sid;
     a.param_id = ids.pid;
     a.tick = ids.tick;
-    a.scratch = static_cast<double*>(h->scratch.p);
+    a.scratch = static_cast<double*>(SL(h).scratch.p);
     a.prof = nullptr;
     a.B = B;
     a.N = h->params[0].N;
@@ -1034,7 +1137,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.next = nullptr;
     a.park = nullptr;
     a.rq = nullptr;
-    a.ctl = static_cast<unsigned*>(h->sh_ctl.p);
+    a.ctl = static_cast<unsigned*>(SL(h).sh_ctl.p);
     a.rq_cap = 0;
     a.res_iters = 0;
     a.loop_ticks = 0;
@@ -1107,61 +1210,75 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
         area = std::max(area, (size_t)grp_n(h) * grp_scratch_doubles(N));
         areas = std::min<size_t>(areas, (size_t)CILQR_MAX_BLOCKS_PER_CU_G1 * (size_t)h->num_cus);
     }
-    if (h->scratch.ensure(sizeof(double) * area * areas))
+    if (SL(h).scratch.ensure(sizeof(double) * area * areas))
         return fail(CILQR_ERR_DEVICE, "hipMalloc scratch");
     if (h->poison_scratch) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemset(h->scratch.p, h->poison_scratch == 1 ? 0xFF : 0x00, h->scratch.cap));
+        HIP_TRY(hipMemset(SL(h).scratch.p, h->poison_scratch == 1 ? 0xFF : 0x00, SL(h).scratch.cap));
         HIP_TRY(hipDeviceSynchronize());
     }
     // the launch's control words: the persistent blocks' trajectory counter, the counters and slots of the work sharing
-    if (!h->sh_ctl.p) {
-        if (h->sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS)) return fail(CILQR_ERR_DEVICE, "hipMalloc control words");
-        HIP_TRY(hipMemset(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
+    if (!SL(h).sh_ctl.p) {
+        if (SL(h).sh_ctl.ensure(sizeof(unsigned) * CILQR_SH_WORDS)) return fail(CILQR_ERR_DEVICE, "hipMalloc control words");
+        HIP_TRY(hipMemset(SL(h).sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS));
     }
     // resumable solves: only the launches that can park — two rows per lane, barrier mode, persistent blocks (lone
     // wavefronts two per SIMD, no closed loop), more trajectories than resident blocks
     const bool can_park = fused && two_rows(h) && h->resume_iters > 0 && h->params[0].solve_type == 0 && !h->looping &&
                           h->persistent_blocks && lone_two_per_simd(h, B) && h->debug_flags == 0 && !h->profiling &&
                           (size_t)B > (size_t)h->num_cus; // (more than one round of resident blocks is possible)
-    if (can_park && (B > h->park_B || N != h->park_N || !h->park.p)) {
-        int rcw = wait_last_launch(h); // (this handle's previous launch may be using the old arrays)
+    if (can_park && (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p)) {
+        int rcw = wait_slot(h, h->cur); // (this handle's previous launch may be using the old arrays)
         if (rcw) return rcw;
-        h->park.release(); h->rq.release();
-        if (h->park.ensure(sizeof(double) * park_doubles(N) * (size_t)B) || h->rq.ensure(sizeof(unsigned long long) * (size_t)B))
+        SL(h).park.release(); SL(h).rq.release();
+        if (SL(h).park.ensure(sizeof(double) * park_doubles(N) * (size_t)B) || SL(h).rq.ensure(sizeof(unsigned long long) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
-        h->park_B = B;
-        h->park_N = N;
+        SL(h).park_B = B;
+        SL(h).park_N = N;
     }
     // the grouped build hands trajectories from wavefronts that hold two to wavefronts that have run dry (cilqr_group.hpp)
     if (fused && grouped(h, B) && h->group_steal) {
         const size_t need = sizeof(double) * grp_park_doubles(N) * (size_t)B;
-        if (B > h->park_B || N != h->park_N || !h->park.p || h->park.cap < need || h->rq.cap < sizeof(unsigned long long) * (size_t)B) {
-            int rcw = wait_last_launch(h);
+        if (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p || SL(h).park.cap < need || SL(h).rq.cap < sizeof(unsigned long long) * (size_t)B) {
+            int rcw = wait_slot(h, h->cur);
             if (rcw) return rcw;
-            h->park.release(); h->rq.release();
-            if (h->park.ensure(need) || h->rq.ensure(sizeof(unsigned long long) * (size_t)B))
+            SL(h).park.release(); SL(h).rq.release();
+            if (SL(h).park.ensure(need) || SL(h).rq.ensure(sizeof(unsigned long long) * (size_t)B))
                 return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
-            h->park_B = B;
-            h->park_N = N;
+            SL(h).park_B = B;
+            SL(h).park_N = N;
         }
     }
     // work sharing between blocks (builds of horizons above 63): one request and one row of hints per trajectory
-    if (two_rows(h) && (B > h->sh_B || N != h->sh_N || !h->sh_req.p)) {
-        int rcw = wait_last_launch(h);
+    if (two_rows(h) && (B > SL(h).sh_B || N != SL(h).sh_N || !SL(h).sh_req.p)) {
+        int rcw = wait_slot(h, h->cur);
         if (rcw) return rcw;
-        h->sh_req.release(); h->sh_hints.release();
-        if (h->sh_req.ensure(sizeof(ShareReq) * (size_t)B) || h->sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
+        SL(h).sh_req.release(); SL(h).sh_hints.release();
+        if (SL(h).sh_req.ensure(sizeof(ShareReq) * (size_t)B) || SL(h).sh_hints.ensure(sizeof(int) * (size_t)(N + 2) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc work-sharing state");
-        HIP_TRY(hipMemset(h->sh_req.p, 0xff, sizeof(ShareReq) * (size_t)B)); // every request closed (next = 255)
-        h->sh_B = B;
-        h->sh_N = N;
+        HIP_TRY(hipMemset(SL(h).sh_req.p, 0xff, sizeof(ShareReq) * (size_t)B)); // every request closed (next = 255)
+        SL(h).sh_B = B;
+        SL(h).sh_N = N;
     }
     return CILQR_OK;
 }
 
 #define DL(slot, ptr, bytes) \
     HIP_TRY(hipMemcpyAsync((ptr), h->st[slot].p, (bytes), hipMemcpyDeviceToHost, h->stream))
+
+// do two launches touch a common byte with a write on either side?
+static bool ranges_conflict(const std::vector<MemRange>& a, const std::vector<MemRange>& b) {
+    for (const auto& x : a)
+        for (const auto& y : b)
+            if ((x.w || y.w) && x.p < y.p + y.n && y.p < x.p + x.n) return true;
+    return false;
+}
+
+struct SeqScope {
+    cilqr_handle* h;
+    explicit SeqScope(cilqr_handle* hh) : h(hh) { h->force_seq = true; h->cur = 0; }
+    ~SeqScope() { h->force_seq = false; }
+};
 
 struct LoopArgs {
     int ticks = 0;
@@ -1193,6 +1310,33 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     } fused_scope(h);
     if (loop.ticks >= 1 && (h->debug_flags != 0 || h->profiling))
         return fail(CILQR_ERR_UNSUPPORTED, "the closed loop has no testing-aid / cycle-accounting builds");
+    // Which launch slot: slot 0 on the caller's stream, one launch of the handle at a time — or, after
+    // cilqr_set_batches_in_flight(k > 1), the next of k slots round robin, each with a stream, scratch areas and control words
+    // of its own.  Not for the augmented Lagrangian (its multipliers live in the handle, indexed by trajectory: two launches
+    // would share them) and not with the development aids (one timeline / cycle-accounting buffer per handle).
+    const bool slots_apply = h->in_flight > 1 && !h->force_seq && h->params[0].solve_type == 0 && !h->profiling && !h->timeline &&
+                             !h->poison_scratch && h->debug_flags == 0;
+    std::vector<MemRange> ranges;
+    if (slots_apply) {
+        h->cur = h->next_slot;
+        h->next_slot = (h->next_slot + 1) % h->in_flight;
+        const int N_ = h->params[0].N;
+        const bool lp = loop.ticks >= 1;
+        auto add = [&](const void* p, size_t n, bool w) { if (p && n) ranges.push_back({static_cast<const char*>(p), n, w}); };
+        add(d_x0, sizeof(double) * 4 * (size_t)B, lp);
+        add(d_scenario_id, sizeof(int32_t) * (size_t)B, false);
+        add(d_param_id, sizeof(int32_t) * (size_t)B, false);
+        add(d_tick, sizeof(int32_t) * (size_t)B, lp);
+        add(d_last_u, sizeof(double) * 2 * N_ * (size_t)B, false);
+        add(d_u_out, sizeof(double) * 2 * N_ * (size_t)B, true);
+        add(d_x_out, sizeof(double) * 4 * (N_ + 1) * (size_t)B, true);
+        add(d_res_out, sizeof(cilqr_result) * (size_t)B, true);
+        add(d_trace_out, sizeof(cilqr_trace_rec) * (size_t)B * (size_t)trace_cap, true);
+        add(loop.states, sizeof(double) * 4 * (size_t)B * (size_t)(lp ? loop.ticks : 0), true);
+        add(loop.iters, sizeof(int32_t) * (size_t)B * (size_t)(lp ? loop.ticks : 0), true);
+    } else {
+        h->cur = 0;
+    }
     rc = ensure_scratch(h, B, true);
     if (rc) return rc;
     Staged ids;
@@ -1204,8 +1348,26 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     a.loop_states = loop.states;
     a.loop_iters = loop.iters;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = order_after_last_launch(h, s); // before the first asynchronous touch of a handle buffer (timeline, control words, ...)
-    if (rc) return rc;
+    if (slots_apply) {
+        // in-flight mode: the launch goes to the slot's own stream, behind (a) everything the caller's stream holds so far — the
+        // launch's inputs —, (b) the slot's previous launch (stream order; an event if something else used its buffers since)
+        // and (c) every launch in flight whose buffers overlap this one's with a write on either side
+        HIP_TRY(hipEventRecord(h->ev_in, s));
+        s = SL(h).stream;
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_in, 0));
+        rc = order_after_slot(h, h->cur, s);
+        if (rc) return rc;
+        for (int k = 0; k < CILQR_MAX_IN_FLIGHT; ++k)
+            if (k != h->cur && h->slot[k].launched && ranges_conflict(h->slot[k].ranges, ranges)) {
+                rc = order_after_slot(h, k, s);
+                if (rc) return rc;
+            }
+        SL(h).ranges.swap(ranges);
+    } else {
+        rc = order_after_last_launch(h, s); // before the first asynchronous touch of a handle buffer (timeline, control words, ...)
+        if (rc) return rc;
+        SL(h).ranges.clear();
+    }
     if (h->profiling) {
         if (h->prof.ensure(sizeof(long long) * CILQR_PROF_SLOTS * (size_t)B)) return fail(CILQR_ERR_DEVICE, "hipMalloc prof");
         a.prof = static_cast<long long*>(h->prof.p);
@@ -1217,7 +1379,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         a.timeline = static_cast<long long*>(h->tl.p);
         h->tl_B = B;
     }
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev0, s));
+    if (h->timing) HIP_TRY(hipEventRecord(SL(h).ev0, s));
     if (grouped(h, B)) {
         // CILQR_GROUP trajectories per wavefront, one rollout pass for all of them (cilqr_group.hpp): persistent blocks
         const int G = (loop.ticks >= 1) ? 2 : grp_n(h);
@@ -1231,17 +1393,17 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         const int cap = per_cu * h->num_cus, want = (B + G - 1) / G;
         const int grid = want < cap ? want : cap;
         h->last_launch_shared = false;
-        a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
-        HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+        a.next = static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_NEXT;
+        HIP_TRY(hipMemsetAsync(SL(h).sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
         h->last_launch_reset_ctl = true;
-        if (h->group_steal && h->park.p && h->park_B >= B && h->park_N == a.N) {
-            a.park = static_cast<double*>(h->park.p);
-            a.rq = static_cast<unsigned long long*>(h->rq.p);
-            HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
-            a.rq_cap = h->park_B;
+        if (h->group_steal && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N) {
+            a.park = static_cast<double*>(SL(h).park.p);
+            a.rq = static_cast<unsigned long long*>(SL(h).rq.p);
+            HIP_TRY(hipMemsetAsync(SL(h).rq.p, 0, sizeof(unsigned long long) * (size_t)SL(h).park_B, s));
+            a.rq_cap = SL(h).park_B;
             h->last_launch_shared = true; // (the host-buffer entry point then checks the launch's error word: a bounded wait that expired)
         }
-        if (h->scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
+        if (SL(h).scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kg, dim3(grid), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out, d_res_out, d_trace_out,
                            d_trace_out ? trace_cap : 0);
@@ -1278,10 +1440,10 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
                 if (global_expansion(h, B)) { kern = k_solve<CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false>; lg = true; }
                 one = true;
                 persistent = true;
-                if (h->share && lg && h->sh_req.p) { // (the ALM build with work sharing is the two-row one)
-                    a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
-                    a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
-                    a.sh_hints = static_cast<int*>(h->sh_hints.p);
+                if (h->share && lg && SL(h).sh_req.p) { // (the ALM build with work sharing is the two-row one)
+                    a.sh_ctl = static_cast<unsigned*>(SL(h).sh_ctl.p);
+                    a.sh_req = static_cast<ShareReq*>(SL(h).sh_req.p);
+                    a.sh_hints = static_cast<int*>(SL(h).sh_hints.p);
                     h->last_launch_shared = true;
                 }
             }
@@ -1317,10 +1479,10 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             }
             one = true;
             persistent = true;
-            if (h->share && two && h->sh_req.p) {
-                a.sh_ctl = static_cast<unsigned*>(h->sh_ctl.p);
-                a.sh_req = static_cast<ShareReq*>(h->sh_req.p);
-                a.sh_hints = static_cast<int*>(h->sh_hints.p);
+            if (h->share && two && SL(h).sh_req.p) {
+                a.sh_ctl = static_cast<unsigned*>(SL(h).sh_ctl.p);
+                a.sh_req = static_cast<ShareReq*>(SL(h).sh_req.p);
+                a.sh_hints = static_cast<int*>(SL(h).sh_hints.p);
                 h->last_launch_shared = true;
             }
         } else {
@@ -1337,16 +1499,16 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             if (rc) return rc;
             const int cap = per_cu * h->num_cus;
             grid = B < cap ? B : cap;
-            a.next = static_cast<unsigned*>(h->sh_ctl.p) + SH_NEXT;
-            HIP_TRY(hipMemsetAsync(h->sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
+            a.next = static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_NEXT;
+            HIP_TRY(hipMemsetAsync(SL(h).sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
             h->last_launch_reset_ctl = true;
             // resumable solves: the builds that carry them (two rows per lane, persistent), batches that take more than
             // one round of the resident blocks
-            if (two && !a.alm && loop.ticks < 1 && h->resume_iters > 0 && B > grid && h->park.p && h->park_B >= B && h->park_N == a.N) {
-                a.park = static_cast<double*>(h->park.p);
-                a.rq = static_cast<unsigned long long*>(h->rq.p);
-                HIP_TRY(hipMemsetAsync(h->rq.p, 0, sizeof(unsigned long long) * (size_t)h->park_B, s));
-                a.rq_cap = h->park_B;
+            if (two && !a.alm && loop.ticks < 1 && h->resume_iters > 0 && B > grid && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N) {
+                a.park = static_cast<double*>(SL(h).park.p);
+                a.rq = static_cast<unsigned long long*>(SL(h).rq.p);
+                HIP_TRY(hipMemsetAsync(SL(h).rq.p, 0, sizeof(unsigned long long) * (size_t)SL(h).park_B, s));
+                a.rq_cap = SL(h).park_B;
                 a.res_iters = h->resume_iters;
             }
         } else {
@@ -1355,7 +1517,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             a.sh_hints = nullptr;
             h->last_launch_shared = false;
         }
-        if (h->scratch.cap < sizeof(double) * scratch_doubles(a.N) * (size_t)(a.next ? grid : B))
+        if (SL(h).scratch.cap < sizeof(double) * scratch_doubles(a.N) * (size_t)(a.next ? grid : B))
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
@@ -1363,13 +1525,10 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) {
-        HIP_TRY(hipEventRecord(h->ev1, s));
-        h->timed_pending = true;
+        HIP_TRY(hipEventRecord(SL(h).ev1, s));
+        SL(h).timed_pending = true;
     }
-    HIP_TRY(hipEventRecord(h->ev_launch, s));
-    h->last_stream = s;
-    h->launched = true;
-    return CILQR_OK;
+    return mark_slot(h, h->cur, s);
 }
 
 extern "C" int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
@@ -1408,9 +1567,11 @@ extern "C" int cilqr_advance_batch_device(cilqr_handle* h, int32_t B, const doub
     hipLaunchKernelGGL(k_advance, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), B, h->params[0].N, d_x,
                        d_x0, d_tick);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_launch, static_cast<hipStream_t>(stream)));
-    h->last_stream = static_cast<hipStream_t>(stream);
-    h->launched = true;
+    // (x0 / tick are inputs of the handle's next solve wherever it runs: the launch counts as a use of every slot)
+    for (int k = 0; k < h->in_flight; ++k) {
+        rc = mark_slot(h, k, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     return CILQR_OK;
 }
 
@@ -1426,6 +1587,7 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     rc = validate_ids(h, B, scenario_id, param_id, tick);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    SeqScope seq_scope(h); // (host buffers: the handle's staging buffers and stream; never a launch slot of its own)
     rc = order_after_last_launch(h, h->stream); // (the staging buffers are the handle's)
     if (rc) return rc;
     const int N = h->params[0].N;
@@ -1459,8 +1621,8 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     if (res_out) DL(7, res_out, sizeof(cilqr_result) * B);
     if (d_tr) DL(8, trace_out, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap);
     unsigned sh_err = 0;
-    if (h->sh_ctl.p && h->last_launch_shared)
-        HIP_TRY(hipMemcpyAsync(&sh_err, static_cast<unsigned*>(h->sh_ctl.p) + SH_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    if (SL(h).sh_ctl.p && h->last_launch_shared)
+        HIP_TRY(hipMemcpyAsync(&sh_err, static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (sh_err) return fail(CILQR_ERR_DEVICE, "a bounded wait inside the launch expired (work sharing between blocks / trajectories handed over at the tail)");
     return CILQR_OK;
@@ -1482,6 +1644,7 @@ extern "C" int cilqr_solve(cilqr_handle* h, const double* x0, const cilqr_scenar
     if (!sc->lane_x || !sc->lane_y || !sc->lane_yaw || sc->L < 1 || sc->M < 0 || (sc->M > 0 && (!sc->obs || sc->T < 1)))
         return fail(CILQR_ERR_BAD_ARG, "bad scenario");
     HIP_TRY(hipSetDevice(h->device));
+    SeqScope seq_scope(h);
     auto& o = h->one;
     const int N = h->params[0].N;
     const size_t L = (size_t)sc->L;
@@ -1588,6 +1751,7 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     rc = validate_ids(h, B, scenario_id, param_id, tick);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    h->cur = 0;
     rc = order_after_last_launch(h, h->stream); // (they share the handle's scratch areas and staging buffers)
     if (rc) return rc;
     rc = ensure_scratch(h, B);

@@ -163,6 +163,25 @@ class BatchedCILQR:
                                                              d_res or None, d_states or None, d_iters or None, stream or None),
                     "cilqr_closed_loop_batch_device")
 
+    def set_batches_in_flight(self, k):
+        """k launch slots (1 = default: launches of the handle are ordered): up to k solve_batch_device /
+        closed_loop_batch_device calls in flight at once, each on an internal stream with scratch of its own, the tables
+        shared; the caller's stream sees the results after join_device(stream) (or wait())."""
+        self._check(self._lib.cilqr_set_batches_in_flight(self._h, int(k)), "cilqr_set_batches_in_flight")
+
+    def join_device(self, stream=0):
+        """make `stream` wait for every launch of this handle that is in flight"""
+        self._check(self._lib.cilqr_join_device(self._h, stream or None), "cilqr_join_device")
+
+    def wait(self):
+        """block the host until every launch of this handle has finished"""
+        self._check(self._lib.cilqr_wait(self._h), "cilqr_wait")
+
+    def slot_kernel_ms(self, k):
+        ms = C.c_float(0)
+        self._check(self._lib.cilqr_slot_kernel_ms(self._h, int(k), C.byref(ms)), "cilqr_slot_kernel_ms")
+        return float(ms.value)
+
     def set_timing(self, on=True):
         self._check(self._lib.cilqr_set_timing(self._h, 1 if on else 0), "cilqr_set_timing")
 
