@@ -717,8 +717,8 @@ def main():
                 "kernel": rl["kernel"], "launch": rl["launch"], "hbm_frac": rl["frac"], "traffic": rl["traffic"], "valu_issue": rl["valu_issue"], "fp64_useful": rl["fp64_useful"],
                 "note": note}
 
-    def closed_loop_extra():
-        cl = closed_loop_run(pkg, torch, local_rank, rank, barrier)
+    def closed_loop_extra(N_loop=50):
+        cl = closed_loop_run(pkg, torch, local_rank, rank, barrier, N=N_loop)
         vec = np.array([cl["iters_total"], cl["B"] * cl["ticks"]], dtype=np.float64)
         red, tmax_c = st_mod.reduce_stats(vec, cl["elapsed"], dist, red_dev)
         _, tmax_t = st_mod.reduce_stats(vec, cl["elapsed_tick_by_tick"], dist, red_dev)
@@ -751,7 +751,7 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported in the line
             return {"error": f"{type(e).__name__}: {e}"[:500]} if rank == 0 else None
 
-    second = third = fourth = closed = alm5 = None
+    second = third = fourth = closed = closed30 = alm5 = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
         third = guarded(side_run, 3, max(args.steps, 20), "BASELINE configs[2]: 8192 three_bend trajectories = two rounds of the "
                         "chip's trajectory slots; one launch at a time a third of it is tail (`in_flight.sequential`)",
@@ -762,6 +762,7 @@ def main():
                          "sharded 8 x 8192; every rank solves 8192 (the full configuration at 8 GPUs; at fewer, the "
                          "first ranks' shards)", cpu_check_rows=512, in_flight=args.in_flight)
         closed = guarded(closed_loop_extra)
+        closed30 = guarded(closed_loop_extra, 30)  # the horizon the reference's own YAMLs use (config/scenario_*.yaml:5)
         alm5 = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm (cs:88-93, 253-261, "
                        "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True,
                        cpu_check_rows=1024)
@@ -788,7 +789,7 @@ def main():
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
                       ("config2_latency" if world == 1 else "config2_weak_scaling"): second,
-                      "config3": third, "config4_sharded": fourth, "closed_loop": closed, "config5_alm": alm5,
+                      "config3": third, "config4_sharded": fourth, "closed_loop": closed, "closed_loop_N30": closed30, "config5_alm": alm5,
                       "ranks": ranks, "distinct_devices": distinct, "per_rank": per_rank,
                       "kernel_ms_min_max_over_ranks": [float(min(r["kernel_ms"] for r in per_rank)),
                                                        float(max(r["kernel_ms"] for r in per_rank))]},

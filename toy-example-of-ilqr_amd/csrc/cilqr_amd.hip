@@ -22,10 +22,10 @@
 CILQR_SOLVE_VARIANTS(CILQR_X_EXTERN)
 #undef CILQR_X_EXTERN
 extern template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<30, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
-extern template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
-extern template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<30, 2, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
@@ -382,9 +382,9 @@ struct cilqr_handle {
     int global_expansion = -1; // cost expansion in global memory (k_solve's LG): -1 = for horizons above 63 in batches of the
                                // two-wavefronts-per-SIMD range (barrier mode), 0 = never, 1 = wherever a build exists
     int win_lg = 0;            // lane window of those builds
-    int occ2_min_batch = 1024; // above this (and above the helper range) the 2-waves-per-SIMD build of the solve kernel
-                               // is used; it costs line-search trials one per pass (paired passes were measured again
-                               // in round 2 at B = 2048 ... 3584, straight and bend: they no longer pay anywhere)
+                               // (round 5: every batch beyond the helper range runs the two-wavefronts-per-SIMD register build,
+                               //  one trial per pass: the one-per-SIMD lone builds could only be reached through tuning switches
+                               //  and are gone from the library)
     int prof_two_per_simd = 0; // development library: cycle accounting in the two-per-SIMD headline build (CILQR_TUNE=prof2=1)
     int group_mode = -1;       // trajectories per wavefront in the large-batch launches of horizons up to 63, barrier mode
                                // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
@@ -406,8 +406,10 @@ struct cilqr_handle {
 // occupancy query says (8 = two wavefronts per SIMD; ensure_scratch sizes the areas with the same number)
 #define CILQR_MAX_BLOCKS_PER_CU 8
 #define CILQR_MAX_BLOCKS_PER_CU_G1 8
-#define CILQR_GROUP_MAX 3 /* trajectories per wavefront of the grouped builds (k_solve_grp): 2 or 3 */
-static int grp_n(const cilqr_handle* h); // (2 unless cilqr_set_group_mode asked for 3)
+#define CILQR_GROUP_MAX 2 /* trajectories per wavefront of the grouped builds (k_solve_grp).  Three per wavefront were built and
+                             measured in round 4 (-6 %: profiles/r04_experiments/three_trajectories_per_wavefront_ab.txt) and are no
+                             longer instantiated; the templates still take G */
+static int grp_n(const cilqr_handle* h);
 static int blocks_per_cu(cilqr_handle* h, const void* kern, size_t shm, int* out) {
     for (const auto& e : h->occ)
         if (e.kern == kern && e.shm == shm) { *out = e.per_cu; return CILQR_OK; }
@@ -507,7 +509,7 @@ static int mark_slot(cilqr_handle* h, int k, hipStream_t s) {
     return CILQR_OK;
 }
 
-static int grp_n(const cilqr_handle* h) { return h->group_mode == 3 ? 3 : 2; }
+static int grp_n(const cilqr_handle*) { return 2; }
 
 static int check_ready(cilqr_handle* h) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
@@ -517,10 +519,15 @@ static int check_ready(cilqr_handle* h) {
 }
 
 extern "C" const char* cilqr_last_error(void) { return g_err.c_str(); }
-#ifdef CILQR_DEV_BUILD
-extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.4-dev (gfx950, wave64, fp64; testing aids + cycle accounting)"; }
+#ifdef CILQR_COMPILER_VALIDATED
+#define CILQR_VERSION_TAIL ")"
 #else
-extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.4 (gfx950, wave64, fp64)"; }
+#define CILQR_VERSION_TAIL "; compiler NOT the validated one: one trajectory per wavefront by default)"
+#endif
+#ifdef CILQR_DEV_BUILD
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.5-dev (gfx950, wave64, fp64; testing aids + cycle accounting" CILQR_VERSION_TAIL; }
+#else
+extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.5 (gfx950, wave64, fp64" CILQR_VERSION_TAIL; }
 #endif
 
 extern "C" int cilqr_create(int device, cilqr_handle** out) {
@@ -550,7 +557,6 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 known = true;
                 if (k == "helper_max_batch") h->helper_max_batch = v;
                 else if (k == "helper_max_batch_two_rows") h->helper_max_batch_two_rows = v;
-                else if (k == "occ2_min_batch") h->occ2_min_batch = v;
                 else if (k == "occ_floor_pct") h->occ_floor_pct = v;
                 else if (k == "global_expansion") h->global_expansion = v;
                 else if (k == "share") h->share = v;
@@ -753,7 +759,7 @@ extern "C" int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode) {
 }
 
 extern "C" int cilqr_set_group_mode(cilqr_handle* h, int32_t mode) {
-    if (!h || mode < -1 || mode > CILQR_GROUP_MAX) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0, 1, 2 or 3");
+    if (!h || mode < -1 || mode > CILQR_GROUP_MAX) return fail(CILQR_ERR_BAD_ARG, "mode must be -1, 0, 1 or 2");
     h->group_mode = mode;
     update_window(h);
     return CILQR_OK;
@@ -1065,8 +1071,8 @@ static bool lone_two_per_simd(const cilqr_handle* h, int B) {
     if (wants_helper(h, B)) return false;
     if (h->looping) return true; // (closed loop: helper wavefronts or lone wavefronts two per SIMD, nothing else)
     const bool alm = h->params[0].solve_type == 1;
-    if (two_rows(h) && !alm && h->share) return true; // (the work-sharing builds, whatever the batch)
-    return B > h->occ2_min_batch;
+    (void)alm;
+    return true; // (everything beyond the helper range: the register build that lets two wavefronts share a SIMD)
 }
 
 // does the solve-kernel variant for this batch cost one trial per pass without a helper (one stage-cost slot)?
@@ -1099,6 +1105,9 @@ static bool grouped(const cilqr_handle* h, int B) {
     if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
     if (!h->persistent_blocks) return false;
     if (h->group_mode >= 2) return true;
+#ifndef CILQR_COMPILER_VALIDATED
+    return false; // (built with a compiler other than the validated one, build.py: pairs only when asked for explicitly)
+#endif
     return lone_two_per_simd(h, B);
 }
 
@@ -1383,9 +1392,9 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     if (grouped(h, B)) {
         // CILQR_GROUP trajectories per wavefront, one rollout pass for all of them (cilqr_group.hpp): persistent blocks
         const int G = (loop.ticks >= 1) ? 2 : grp_n(h);
-        auto kg = (a.N == 50) ? k_solve_grp<50, 2> : k_solve_grp<0, 2>;
-        if (G == 3) kg = (a.N == 50) ? k_solve_grp<50, 3> : k_solve_grp<0, 3>;
-        if (loop.ticks >= 1) kg = (a.N == 50) ? k_solve_grp<50, 2, true> : k_solve_grp<0, 2, true>;
+        // compile-time horizons: BASELINE's 50 and the 30 of the reference's own YAMLs (config/scenario_*.yaml:5)
+        auto kg = (a.N == 50) ? k_solve_grp<50, 2> : (a.N == 30 ? k_solve_grp<30, 2> : k_solve_grp<0, 2>);
+        if (loop.ticks >= 1) kg = (a.N == 50) ? k_solve_grp<50, 2, true> : (a.N == 30 ? k_solve_grp<30, 2, true> : k_solve_grp<0, 2, true>);
         const size_t shm = grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
@@ -1413,7 +1422,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         // helper wavefronts pay off while one wavefront per trajectory leaves SIMDs idle
         const bool help = wants_helper(h, B);
         // `one` = the variant costs one trial per pass without a helper: one stage-cost slot in LDS (k_solve's SLOTS)
-        auto kern = k_solve<false, 1, false, false, false>;
+        auto kern = k_solve<false, 1, false, true, false>;
         bool one = false, lg = false, persistent = false;
         h->last_launch_shared = false;
         h->last_launch_reset_ctl = false;
@@ -1429,7 +1438,6 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
                                      : k_solve<false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true>;
                 else kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, false, false, true>
                                 : k_solve<false, 1, false, false, false, 2, 1, 0, false, false, false, true>;
-                if (!help && a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50, false, false, false, true>;
             }
             one = !help;
             persistent = !help;
@@ -1447,7 +1455,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
                     h->last_launch_shared = true;
                 }
             }
-            else kern = two ? k_solve<CILQR_ALM_DBG, 2, true, false, false> : k_solve<CILQR_ALM_DBG, 1, true, false, false>;
+            else return fail(CILQR_ERR_DEVICE, "internal: no build for this launch shape");
 #ifdef CILQR_DEV_BUILD
         } else if (a.flags != 0) {
             kern = two ? k_solve<true, 2, false, false, false> : k_solve<true, 1, false, false, false>;
@@ -1464,14 +1472,12 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         } else if (help) {
             kern = two ? k_solve<false, 2, false, true, false> : k_solve<false, 1, false, true, false>;
             if (a.N == 50) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 50>;
-            if (a.N == 100) kern = k_solve<false, 2, false, true, false, 1, CILQR_NT, 100>;
+            if (a.N == 30) kern = k_solve<false, 1, false, true, false, 1, CILQR_NT, 30>; // (the reference's own horizon)
         } else if (lone_two_per_simd(h, B)) {
             // (two rows per lane: built with work sharing between blocks, which a.sh_ctl switches on.  Shorter horizons
             //  are not: a trial costs 5 us there, the hand-over of a search about 10, and the build costs the solve loop
             //  3 % in spilled registers — measured: config 5 -5 %, config 3 -33 % with it, config 4 +25 %)
             kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, true, true> : k_solve<false, 1, false, false, false, 2, 1>;
-            if (a.N == 50) kern = k_solve<false, 1, false, false, false, 2, 1, 50>;
-            if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, false, true, true>;
             if (global_expansion(h, B)) {
                 kern = k_solve<false, 2, false, false, false, 2, 1, 0, true, true, true>;
                 if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true, true, true>;
@@ -1486,7 +1492,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
                 h->last_launch_shared = true;
             }
         } else {
-            kern = two ? k_solve<false, 2, false, false, false> : k_solve<false, 1, false, false, false>;
+            return fail(CILQR_ERR_DEVICE, "internal: no build for this launch shape");
         }
         const bool helped = help && (a.alm || a.flags == 0 || loop.ticks >= 1);
         if (one != single_slot(h, B)) return fail(CILQR_ERR_DEVICE, "internal: kernel variant / LDS layout mismatch");

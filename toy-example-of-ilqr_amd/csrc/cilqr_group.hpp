@@ -612,7 +612,11 @@ __device__ inline void slab_st2_row(__amdgpu_buffer_rsrc_t rs, unsigned b, unsig
     const u32x2 lo_ = __builtin_bit_cast(u32x2, v0), hi_ = __builtin_bit_cast(u32x2, v1);
     u32x4 q_;
     q_.x = lo_.x; q_.y = lo_.y; q_.z = hi_.x; q_.w = hi_.y;
+#ifdef CILQR_LOSTROWS_REPRO
+    const int ku = k; // (the form that lost rows, see rollout_group)
+#else
     const int ku = opaque_uniform(k); // (see slab_row_off)
+#endif
     const unsigned voff = __umul24((unsigned)(ku / CILQR_SLAB_TILE), tileb) + b;
     __builtin_amdgcn_raw_buffer_store_b128(q_, rs, voff, (ku % CILQR_SLAB_TILE) * 16, 0);
 }
@@ -707,7 +711,15 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
     // (arguments of an out-of-line function arrive in vector registers: without this the horizon — and with it the loop
     //  counters and the buffer descriptor built from it — counts as divergent, and every slab store becomes a loop over the
     //  distinct descriptors of the lanes)
+#ifdef CILQR_LOSTROWS_REPRO
+    // EXPERIMENT ONLY (-DCILQR_LOSTROWS_REPRO, never in a shipped library): the pass as round 4's first tiled build had it —
+    // the horizon left in its vector register, so that the descriptor built from it counts as divergent and every slab store
+    // sits in a waterfall loop — the shape that delivered a later content of a store's data register on gfx950 with XNACK off
+    // (profiles/r04_experiments/tiled_slab_lost_rows.txt; scripts/probes/lost_rows_failing_pass.s is this function's code)
+    const int N = N_arg;
+#else
     const int N = uniform_int(N_arg);
+#endif
     const int R = N + 1;
     int start = 0, gl = -1, al = 0, rq = 0;
 #pragma unroll

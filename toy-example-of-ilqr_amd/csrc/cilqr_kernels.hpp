@@ -1230,36 +1230,38 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
 #else
 #define CILQR_ALM_DBG false
 #endif
+// Round 5: the production table holds what the dispatcher in cilqr_amd.hip reaches with default settings, nothing else (the
+// builds that only tuning switches could select — lone wavefronts one per SIMD, the lone N = 50 / N = 100 builds that the
+// grouped kernel and the global-expansion build replaced, the helper build of N = 100 — are gone; DESIGN.md lists the
+// survivors with the reason each exists).
 #define CILQR_SOLVE_VARIANTS_PROD(X)                                            \
-    X(0, false, 1, false, false, false, 1, CILQR_NT, 0, false, false, false, false)           \
-    X(0, false, 2, false, false, false, 1, CILQR_NT, 0, false, false, false, false)           \
-    X(1, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
+    /* small batches: main + helper wavefront; any horizon (one / two rows per lane), BASELINE's 50, the reference YAMLs' 30 */ \
+    X(0, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
     X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
     X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false, false, false)           \
-    X(2, false, 2, false, true, false, 1, CILQR_NT, 100, false, false, false, false)          \
-    X(3, false, 1, false, false, false, 2, 1, 0, false, false, false, false)                  \
-    X(3, false, 2, false, false, false, 2, 1, 0, false, true, true, false)                   \
-    X(4, false, 1, false, false, false, 2, 1, 50, false, false, false, false)                 \
-    X(4, false, 2, false, false, false, 2, 1, 100, false, true, true, false)                 \
-    X(5, false, 2, false, false, false, 2, 1, 0, true, true, true, false)                    \
-    X(5, false, 2, false, false, false, 2, 1, 100, true, true, true, false)                  \
-    X(6, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
-    X(6, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
-    X(7, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, false)           \
-    X(7, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, false)           \
-    X(0, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false, false)             \
-    X(1, CILQR_ALM_DBG, 1, true, false, false, 1, CILQR_NT, 0, false, false, false, false)    \
-    X(2, CILQR_ALM_DBG, 2, true, false, false, 1, CILQR_NT, 0, false, false, false, false)    \
+    X(3, false, 1, false, true, false, 1, CILQR_NT, 30, false, false, false, false)           \
+    /* large batches, lone wavefronts two per SIMD: N <= 63 when the grouped kernel is switched off (cilqr_set_group_mode(0), \
+       a compiler other than the validated one); N 64 ... 75 with work sharing + resumable solves; N >= 76 with the expansion \
+       in global memory, any horizon and BASELINE's 100 */ \
+    X(4, false, 1, false, false, false, 2, 1, 0, false, false, false, false)                  \
+    X(5, false, 2, false, false, false, 2, 1, 0, false, true, true, false)                   \
+    X(6, false, 2, false, false, false, 2, 1, 0, true, true, true, false)                    \
+    X(7, false, 2, false, false, false, 2, 1, 100, true, true, true, false)                  \
+    /* augmented Lagrangian: helper wavefronts, lone two per SIMD, long horizons with the expansion in global memory */ \
+    X(0, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
+    X(1, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
+    X(2, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, false)           \
+    X(3, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, false)           \
+    X(4, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, true, true, false, false)             \
     /* closed planning loop in one launch: the plain builds (helper wavefront / lone, two per SIMD), both solve types */ \
-    X(3, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
-    X(4, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
-    X(5, false, 1, false, false, false, 2, 1, 0, false, false, false, true)                   \
-    X(3, false, 1, false, false, false, 2, 1, 50, false, false, false, true)                  \
-    X(6, false, 2, false, false, false, 2, 1, 0, false, false, false, true)                   \
-    X(7, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
-    X(0, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
-    X(1, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, true)            \
-    X(2, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, true)
+    X(5, false, 1, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
+    X(6, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, true)             \
+    X(7, false, 1, false, false, false, 2, 1, 0, false, false, false, true)                   \
+    X(0, false, 2, false, false, false, 2, 1, 0, false, false, false, true)                   \
+    X(1, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
+    X(2, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, true)      \
+    X(3, CILQR_ALM_DBG, 1, true, false, false, 2, 1, 0, false, false, false, true)            \
+    X(4, CILQR_ALM_DBG, 2, true, false, false, 2, 1, 0, false, false, false, true)
 #ifdef CILQR_DEV_BUILD
 #define CILQR_SOLVE_VARIANTS_DEV(X)                                             \
     X(3, true, 1, false, false, false, 1, CILQR_NT, 0, false, false, false, false)            \

@@ -47,17 +47,17 @@
 #endif
 CILQR_SOLVE_VARIANTS(CILQR_X_INST)
 
-// the grouped builds (k_solve_grp: G trajectories per wavefront), spread over the lighter groups
+// the grouped builds (k_solve_grp: two trajectories per wavefront): compile-time horizons 50 (BASELINE) and 30 (the reference's
+// own YAMLs), any horizon up to 63; each also as the closed planning loop in one launch.  The two kernels of a horizon share
+// a compilation: their phases (expansion + sweep, trial costs, rollout pass, initial trajectory) are out-of-line functions of
+// the horizon alone, 190 KB of code that would otherwise be in the library twice.
 #if CILQR_INST_GROUP == 6
 template __global__ void k_solve_grp<50, 2> CILQR_GRP_SIGNATURE;
+template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 7
 template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
-#elif CILQR_INST_GROUP == 5
-template __global__ void k_solve_grp<50, 3> CILQR_GRP_SIGNATURE;
-#elif CILQR_INST_GROUP == 3
-template __global__ void k_solve_grp<0, 3> CILQR_GRP_SIGNATURE;
-#elif CILQR_INST_GROUP == 4
-template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE; // the closed planning loop in one launch
-#elif CILQR_INST_GROUP == 2
 template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 5
+template __global__ void k_solve_grp<30, 2> CILQR_GRP_SIGNATURE;
+template __global__ void k_solve_grp<30, 2, true> CILQR_GRP_SIGNATURE;
 #endif
