@@ -5,9 +5,17 @@
 //
 //   headless_planner <scenario.json> [ticks] [N]
 // prints one line per tick: tick index, ego state, first control, iterations, J_final.
+//
+//   headless_planner <scenario.json> --batch B [--devices G] [--share] [--horizon N]
+// the batch form of the first tick: B perturbed egos of the scenario (cilqr_perturbed_starts), one cold solve each, the batch
+// sharded over G devices by cilqr_amd::ShardedSolver (contiguous blocks, tables replicated, statistics summed on the host:
+// SURVEY.md 8(e) without torch; G = 0: every visible device; --share: shards share the visible devices, a rehearsal).
+// Prints the summed statistics and a checksum over every output bit — the same for every G.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
+#include <string>
 #include <vector>
 
 #include "cilqr_config.hpp"
@@ -51,6 +59,44 @@ int main(int argc, char** argv) {
                        max_simulation_time, delta_t, routes.data(), T, &T, nullptr, nullptr);
 
     cilqr_params p = params_from_config(cfg);
+    // ---- batch mode: B egos of this scenario, sharded over the devices ----
+    long long batch = 0;
+    int devices = 0, share = 0, horizon = 0;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--batch" && i + 1 < argc) batch = std::atoll(argv[++i]);
+        else if (a == "--devices" && i + 1 < argc) devices = std::atoi(argv[++i]);
+        else if (a == "--horizon" && i + 1 < argc) horizon = std::atoi(argv[++i]);
+        else if (a == "--share") share = 1;
+    }
+    if (batch > 0) {
+        if (horizon > 0) p.N = horizon;
+        p.use_last_solution = 0;
+        const int Nb = p.N, Mb = V - 1;
+        cilqr_scenario_desc sc{};
+        sc.lane_x = lx.data(); sc.lane_y = ly.data(); sc.lane_yaw = lyaw.data(); sc.L = L;
+        sc.M = Mb; sc.obs = routes.data() + static_cast<size_t>(T) * 3; sc.T = T; // (vehicle 0 is the ego)
+        sc.road_borders[0] = road_borders[0]; sc.road_borders[1] = road_borders[1];
+        sc.ref_velo = target_velocity;
+        std::vector<double> x0(static_cast<size_t>(batch) * 4), ub(static_cast<size_t>(batch) * 2 * Nb), xb(static_cast<size_t>(batch) * 4 * (Nb + 1));
+        std::vector<cilqr_result> res(static_cast<size_t>(batch));
+        const double base[4] = {init[0][0], init[0][1], init[0][2], init[0][3]};
+        cilqr_perturbed_starts(base, static_cast<int32_t>(batch), 0xC11A0B5ULL, 0, x0.data());
+        ShardedSolver sh(&p, 1, &sc, 1, devices, share != 0);
+        const ShardStats st = sh.solve_batch(batch, x0.data(), nullptr, nullptr, nullptr, nullptr, ub.data(), xb.data(), res.data());
+        unsigned long long hsh = 1469598103934665603ULL; // FNV-1a over every output bit
+        auto mix = [&hsh](const void* ptr, size_t n) {
+            const unsigned char* c = static_cast<const unsigned char*>(ptr);
+            for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ULL; }
+        };
+        mix(ub.data(), ub.size() * sizeof(double));
+        mix(xb.data(), xb.size() * sizeof(double));
+        for (const auto& r : res) { mix(&r.J_final, sizeof(double)); mix(&r.iters, sizeof(int)); mix(&r.ls_trials, sizeof(int)); mix(&r.end_reason, sizeof(int)); }
+        std::printf("batch %lld horizon %d devices %d iters %lld ls_trials %lld converged %lld max_lamb %lld max_iter %lld bad_input %lld nan %lld "
+                    "sum_J_final %.17g checksum %016llx\n", batch, Nb, sh.devices(), st.iters, st.ls_trials, st.converged, st.max_lamb,
+                    st.max_iter, st.bad_input, st.nan_costs, st.sum_J_final, hsh);
+        return 0;
+    }
     if (argc > 3) p.N = std::atoi(argv[3]);
     CILQRSolver solver(p);
     const int N = p.N, M = V - 1;

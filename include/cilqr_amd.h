@@ -125,6 +125,8 @@ typedef struct cilqr_handle cilqr_handle;
 /* device = HIP device ordinal.  Fails with CILQR_ERR_NO_DEVICE when no GPU is visible: there
  * is no CPU fallback in this library. */
 int cilqr_create(int device, cilqr_handle** out);
+/* HIP devices visible to the process (one handle per device shards a batch: cilqr_amd::ShardedSolver, cilqr_solver_shim.hpp) */
+int cilqr_device_count(int32_t* n);
 int cilqr_destroy(cilqr_handle* h);
 const char* cilqr_last_error(void);
 const char* cilqr_version(void);

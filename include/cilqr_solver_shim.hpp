@@ -17,8 +17,12 @@
 // like the reference class it is not re-entrant.
 #pragma once
 #include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -148,6 +152,93 @@ class CILQRSolver {
     cilqr_handle* h_ = nullptr;
     bool is_first_solve_ = true;
     std::vector<double> last_solve_u_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ShardedSolver — a batch over several GPUs from ONE host process, without torch (SURVEY.md 8(e) as a product feature; the
+// benchmark's `torchrun bench.py --gpus N` is the other way to get there: one process per GPU).  The path shards by
+// trajectory with no exchange step: device g of G solves the contiguous block [first_g, first_g + count_g) of the batch —
+// ceil(B / G) trajectories each, the last device the remainder — on a handle of its own (cilqr_create(device)), the
+// parameter and scenario tables replicated to every device; results come back into the caller's arrays in place; the only
+// "collective" is the sum of eight statistics on the host.  One host thread per device drives its handle (a handle is not
+// thread-safe; cilqr_last_error is per thread), so the devices run concurrently.  Results do not depend on G: a trajectory's
+// solve is a function of its own inputs alone (tests: --devices 1 equals the plain call; shard arithmetic on the CPU).
+struct ShardStats {
+    long long trajectories = 0, iters = 0, ls_trials = 0, converged = 0, max_lamb = 0, max_iter = 0, bad_input = 0, nan_costs = 0;
+    double sum_J_final = 0.0;
+};
+
+class ShardedSolver {
+  public:
+    // devices = 0: every visible device (cilqr_device_count).  share_devices: shard g runs on device g mod (visible devices) —
+    // a REHEARSAL of G > 1 shards on a box with fewer GPUs (the shards' launches then share a GPU), not a way to go faster
+    ShardedSolver(const cilqr_params* params, int n_params, const cilqr_scenario_desc* scen, int n_scen, int devices = 0,
+                  bool share_devices = false) {
+        int visible = 0;
+        check(cilqr_device_count(&visible), "cilqr_device_count");
+        const int G = devices > 0 ? devices : visible;
+        if (G < 1 || visible < 1 || (G > visible && !share_devices))
+            throw std::runtime_error("ShardedSolver: asked for " + std::to_string(G) + " devices, " + std::to_string(visible) + " visible");
+        N_ = params[0].N;
+        for (int g = 0; g < G; ++g) {
+            cilqr_handle* h = nullptr;
+            check(cilqr_create(g % visible, &h), "cilqr_create");
+            handles_.emplace_back(h, &cilqr_destroy);
+            check(cilqr_set_params(h, params, n_params), "cilqr_set_params");
+            check(cilqr_set_scenarios(h, scen, n_scen), "cilqr_set_scenarios");
+        }
+    }
+    int devices() const { return static_cast<int>(handles_.size()); }
+
+    // trajectories [first, first + count) of a batch of B go to device g of G: contiguous blocks of ceil(B / G)
+    static void shard_bounds(long long B, int G, int g, long long* first, long long* count) {
+        const long long per = (B + G - 1) / G;
+        const long long f = std::min<long long>(B, per * g);
+        *first = f;
+        *count = std::max<long long>(0, std::min<long long>(B, f + per) - f);
+    }
+
+    // cilqr_solve_batch for the whole batch (host arrays; any of scenario_id / param_id / tick / last_u / res may be null)
+    ShardStats solve_batch(long long B, const double* x0, const int32_t* scenario_id, const int32_t* param_id, const int32_t* tick,
+                           const double* last_u, double* u_out, double* x_out, cilqr_result* res_out) {
+        const int G = devices(), N = N_;
+        std::vector<cilqr_result> res_local;
+        if (!res_out) { res_local.resize(static_cast<size_t>(B)); res_out = res_local.data(); }
+        std::vector<std::string> errors(G);
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g) {
+            long long first = 0, count = 0;
+            shard_bounds(B, G, g, &first, &count);
+            if (count <= 0) continue;
+            th.emplace_back([=, &errors]() {
+                const int rc = cilqr_solve_batch(handles_[g].get(), static_cast<int32_t>(count), x0 + 4 * first,
+                                                 scenario_id ? scenario_id + first : nullptr, param_id ? param_id + first : nullptr,
+                                                 tick ? tick + first : nullptr, last_u ? last_u + 2 * N * first : nullptr,
+                                                 u_out + 2 * N * first, x_out + 4 * (N + 1) * first, res_out + first, nullptr, 0);
+                if (rc != CILQR_OK) errors[g] = std::string("device ") + std::to_string(g) + ": " + cilqr_last_error();
+            });
+        }
+        for (auto& t : th) t.join();
+        for (const auto& e : errors)
+            if (!e.empty()) throw std::runtime_error("ShardedSolver::solve_batch: " + e);
+        ShardStats s;
+        s.trajectories = B;
+        for (long long b = 0; b < B; ++b) { // the sum a multi-process run all-reduces (stats.py): here on the host
+            const cilqr_result& r = res_out[b];
+            s.iters += r.iters; s.ls_trials += r.ls_trials;
+            s.converged += r.end_reason == CILQR_END_CONVERGED; s.max_lamb += r.end_reason == CILQR_END_MAX_LAMB;
+            s.max_iter += r.end_reason == CILQR_END_MAX_ITER; s.bad_input += r.end_reason == CILQR_END_BAD_INPUT;
+            if (std::isnan(r.J_final)) s.nan_costs += 1; else s.sum_J_final += r.J_final;
+        }
+        return s;
+    }
+
+  private:
+    static void check(int rc, const char* where) {
+        if (rc != CILQR_OK) throw std::runtime_error(std::string(where) + ": " + cilqr_last_error());
+    }
+    std::vector<std::unique_ptr<cilqr_handle, int (*)(cilqr_handle*)>> handles_;
+    int N_ = 0;
 };
 
 }  // namespace cilqr_amd

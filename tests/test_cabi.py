@@ -315,3 +315,36 @@ def test_register_budget_of_the_shipped_kernels(pkg, tmp_path):
         assert all(lp["scratch"] == 0 for lp in hit[0]["innermost_loops"]), (name, hit[0]["innermost_loops"])
     sweep = [f for n, f in fns.items() if n.endswith("cilqr::grp_expand_backward<50, 2>")][0]
     assert any(lp["kind"] == "backward_step" and lp["instructions"] <= 160 for lp in sweep["innermost_loops"]), sweep
+
+
+
+def test_sharded_solver_shard_arithmetic(tmp_path):
+    """cilqr_amd::ShardedSolver (include/cilqr_solver_shim.hpp): contiguous blocks of ceil(B / G), every trajectory exactly once,
+    for batch sizes around the block boundaries — host logic, no GPU."""
+    import subprocess
+    src = tmp_path / "sh.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include "cilqr_solver_shim.hpp"
+int main() {
+  const long long Bs[] = {1, 2, 7, 8, 9, 63, 64, 65, 1000, 8191, 8192, 65536, 65537};
+  for (long long B : Bs)
+    for (int G = 1; G <= 8; ++G) {
+      long long next = 0, biggest = 0;
+      for (int g = 0; g < G; ++g) {
+        long long f, c;
+        cilqr_amd::ShardedSolver::shard_bounds(B, G, g, &f, &c);
+        if (c < 0 || (c > 0 && f != next) || f > B) { std::printf("BAD %lld %d %d %lld %lld\n", B, G, g, f, c); return 1; }
+        if (c > 0) next = f + c;
+        if (c > biggest) biggest = c;
+      }
+      if (next != B || biggest != (B + G - 1) / G) { std::printf("BAD cover %lld %d\n", B, G); return 1; }
+    }
+  long long f, c;
+  cilqr_amd::ShardedSolver::shard_bounds(65536, 8, 3, &f, &c);
+  std::printf("OK %lld %lld\n", f, c);
+  return 0; }""")
+    exe = tmp_path / "sh"
+    subprocess.run(["g++", "-std=c++17", "-pthread", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == "OK 24576 8192", out  # BASELINE configs[3]: rank 3 of 8 gets trajectories 24576 ... 32767

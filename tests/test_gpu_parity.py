@@ -1604,7 +1604,7 @@ def test_trajectories_in_pairs_per_wavefront_are_transparent(pkg, orc_det, engin
         eng.set_group_mode(0)
         base = eng.solve_batch(x0, trace_cap=128)
         compare_solves(base, refs, f"{name} N={N} one per wavefront")
-        for gm, rollout in ((2, -1), (2, 0), (2, 1), (3, -1), (3, 0), (3, 1)):  # two / three trajectories per wavefront
+        for gm, rollout in ((2, -1), (2, 0), (2, 1)):  # two trajectories per wavefront (three: measured slower in round 4, no longer built)
             eng.set_group_mode(gm)
             eng.set_rollout_mode(rollout)
             g = eng.solve_batch(x0, trace_cap=128)
@@ -1615,8 +1615,9 @@ def test_trajectories_in_pairs_per_wavefront_are_transparent(pkg, orc_det, engin
             assert (base["res"] == g["res"]).all(), what
             for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
                 eq_bits(base["trace"][f], g["trace"][f], what + " trace." + f)
-        if B > 40:  # wavefronts that ran dry took trajectories over from wavefronts that still held two (the launch's tail)
-            assert eng.resume_stats() > 0, (name, "no trajectory changed wavefronts")
+        # (whether a wavefront that ran dry took a trajectory over at the tail of such a small launch is a matter of timing —
+        #  ADVICE r04 — and not asserted here; test_pairs_at_scale_equal_the_single_build sees ~1 000 hand-overs per launch)
+        print(what, "trajectories handed over at the tail:", eng.resume_stats())
         eng.set_rollout_mode(-1)
         eng.set_helper_mode(-1)
         eng.set_group_mode(-1)
@@ -1682,6 +1683,7 @@ def test_pairs_at_scale_equal_the_single_build(pkg):
     for mode in (0, -1):
         eng.set_group_mode(mode)
         outs[mode] = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, trace_cap=64)
+    assert eng.resume_stats() > 0, "no trajectory changed wavefronts at the tail of an 8192-trajectory launch in pairs"
     a, b = outs[0], outs[-1]
     eq_bits(a["u"], b["u"], "u")
     eq_bits(a["x"], b["x"], "x")
@@ -1857,3 +1859,79 @@ def test_batches_in_flight_inside_one_handle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _IN_FLIGHT_SCRIPT, root], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "IN-FLIGHT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+
+def test_lost_rows_shape_is_still_what_loses_rows():
+    """Round 5 (VERDICT r04 task 5): the real instruction stream of round 4's lost-store anomaly.  ab/libLR.so — the library
+    built with -DCILQR_LOSTROWS_REPRO: the grouped rollout pass with its 16-byte slab stores inside waterfall loops — against
+    the shipped library, pairs per wavefront against lone wavefronts (scripts/lost_rows_repro.py), with XNACK off (how this
+    pool runs) and with HSA_XNACK=1.  ASSERTED: the shipped library is clean in both modes.  RECORDED (printed, and in
+    profiles/r05_experiments/lost_rows_time_box.txt: 12 of 12 launches, ~290 of 4 100 trajectories with XNACK off, none with
+    XNACK on): what the excluded shape does on this box — a hardware / firmware revision that stops losing rows shows up here.
+    Skipped where the experiment library has not been built (it is not part of build())."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "ab", "libLR.so")
+    if not os.path.exists(lib):
+        pytest.skip("ab/libLR.so (build.build_library(out=..., extra_defs=('-DCILQR_LOSTROWS_REPRO',))) is not here")
+    seen = {}
+    for which in ("shipped", "repro"):
+        for xnack in (None, "1"):
+            env = dict(os.environ)
+            env.pop("HSA_XNACK", None)
+            env.pop("CILQR_AMD_LIB", None)
+            if xnack:
+                env["HSA_XNACK"] = xnack
+            if which == "repro":
+                env["CILQR_AMD_LIB"] = lib
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "lost_rows_repro.py"), "4"], capture_output=True,
+                               text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            seen[(which, xnack)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print({f"{k[0]} xnack={k[1]}": v["mismatching_trajectories_per_launch"] for k, v in seen.items()})
+    assert seen[("shipped", None)]["launches_with_mismatch"] == 0
+    assert seen[("shipped", "1")]["launches_with_mismatch"] == 0
+
+
+
+def test_sharded_solver_in_one_process(pkg, orc_det, scenarios):
+    """cilqr_amd::ShardedSolver through examples/headless_planner --batch: the batch over G handles in one process (one host
+    thread per shard), statistics summed on the host.  --devices 1 equals the plain cilqr_solve_batch call (and the oracle);
+    G = 2, 3 and 5 shards — sharing the one GPU of this box: a rehearsal of the multi-GPU path — give the same checksum over
+    every output bit: results do not depend on the shard count."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "headless_planner")
+    cfgp = str(pkg.config.SCENARIO_DIR / "three_bend.json")
+    B, N = 333, 30
+    lines = {}
+    for args in (["--devices", "1"], ["--devices", "2", "--share"], ["--devices", "3", "--share"], ["--devices", "5", "--share"]):
+        r = subprocess.run([exe, cfgp, "--batch", str(B), "--horizon", str(N)] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines[" ".join(args)] = r.stdout.strip().split()
+    one = lines["--devices 1"]
+    field = lambda ln, name: ln[ln.index(name) + 1]
+    for k, ln in lines.items():
+        assert field(ln, "checksum") == field(one, "checksum"), (k, ln, one)
+        for name in ("iters", "ls_trials", "converged", "max_lamb", "max_iter", "sum_J_final"):
+            assert field(ln, name) == field(one, name), (k, name)
+    assert [field(lines[k], "devices") for k in lines] == ["1", "2", "3", "5"]
+    # the same batch through the Python binding (one handle) and the oracle
+    cfg, sc = scenarios["three_bend"]
+    p = pkg.params_from_config(cfg, N=N, use_last_solution=0)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC11A0B5)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc))
+    out = eng.solve_batch(x0)
+    eng.close()
+    assert int(field(one, "iters")) == int(out["res"]["iters"].sum()) and int(field(one, "ls_trials")) == int(out["res"]["ls_trials"].sum())
+    acc = 0.0
+    for v in out["res"]["J_final"]:
+        acc += float(v)
+    assert float(field(one, "sum_J_final")) == acc
+    ref = orc_det.solve_batch(p, oracle_scene(sc), x0, n_threads=4)
+    eq_bits(out["x"], ref["x"], "x vs oracle")

@@ -92,6 +92,7 @@ _D = C.c_double
 # name -> (restype, argtypes); mirrors include/cilqr_amd.h one to one
 SIGNATURES = {
     "cilqr_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "cilqr_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
     "cilqr_destroy": (C.c_int, [_P]),
     "cilqr_last_error": (C.c_char_p, []),
     "cilqr_version": (C.c_char_p, []),

@@ -530,6 +530,14 @@ extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.5-dev (gfx950, 
 extern "C" const char* cilqr_version(void) { return "cilqr_amd 0.5 (gfx950, wave64, fp64" CILQR_VERSION_TAIL; }
 #endif
 
+extern "C" int cilqr_device_count(int32_t* n) {
+    if (!n) return fail(CILQR_ERR_BAD_ARG, "null argument");
+    int c = 0;
+    const hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess && c > 0) ? c : 0;
+    return CILQR_OK;
+}
+
 extern "C" int cilqr_create(int device, cilqr_handle** out) {
     if (!out) return fail(CILQR_ERR_BAD_ARG, "out is null");
     int n = 0;
