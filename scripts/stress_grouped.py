@@ -69,7 +69,7 @@ def main():
             warm = np.cumsum(rng.normal(0, 0.05, (wl.B, wl.N, 2)), axis=1) * np.array([1.0, 0.05])
         rollout = int(rng.choice([-1, -1, 0, 1]))
         ref = None
-        for tune in ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0"):
+        for tune in ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0", "group=2,pair_sweep=0"):
             eng = engine(wl, tune)
             eng.set_helper_mode(0)
             eng.set_rollout_mode(rollout)

@@ -1890,6 +1890,8 @@ def test_lost_rows_shape_is_still_what_loses_rows():
                 env["CILQR_AMD_LIB"] = lib
             r = subprocess.run([sys.executable, os.path.join(root, "scripts", "lost_rows_repro.py"), "4"], capture_output=True,
                                text=True, timeout=600, env=env)
+            if which == "repro" and r.returncode != 0 and "undefined symbol" in r.stderr:
+                pytest.skip("ab/libLR.so is older than the C-ABI (rebuild it with -DCILQR_LOSTROWS_REPRO)")
             assert r.returncode == 0, r.stderr[-2000:]
             seen[(which, xnack)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print({f"{k[0]} xnack={k[1]}": v["mismatching_trajectories_per_launch"] for k, v in seen.items()})
@@ -1935,3 +1937,51 @@ def test_sharded_solver_in_one_process(pkg, orc_det, scenarios):
     assert float(field(one, "sum_J_final")) == acc
     ref = orc_det.solve_batch(p, oracle_scene(sc), x0, n_threads=4)
     eq_bits(out["x"], ref["x"], "x vs oracle")
+
+
+
+def test_sweeps_of_two_trajectories_in_one_instruction_stream(pkg, orc_det, scenarios, monkeypatch):
+    """Round 5: backward_sweep_pair — the backward sweeps (cs:383-440) of a wavefront's two trajectories on two 4 x 8 lane
+    grids in ONE instruction stream, the second trajectory's Jacobians and expansion streamed from rows in global memory.
+    Against round 4's turn (development library, CILQR_TUNE=pair_sweep=0: one sweep after the other) and the oracle: every
+    output and the whole decision trace, on workloads whose solves include failed backward passes (a negative control
+    weight: non-PD Q_uu, cs:415-420 — one trajectory of a pair fails while the other goes on), both vehicle models, odd
+    batches, a horizon that is not a compile-time one, mixed parameter sets (different dt in the two halves)."""
+    cases = []
+    cfg, sc = scenarios["three_bend"]
+    cases.append(("three_bend N=50", [pkg.params_from_config(cfg, N=50, use_last_solution=0)], sc, 301, 50))
+    cases.append(("three_bend N=37, two parameter sets with different dt",
+                  [pkg.params_from_config(cfg, N=37, use_last_solution=0), pkg.params_from_config(cfg, N=37, use_last_solution=0, dt=0.08)],
+                  sc, 150, 37))
+    cfg2, sc2 = scenarios["two_straight"]
+    cases.append(("two_straight N=30, w_acc < 0 (non-PD Q_uu)", [pkg.params_from_config(cfg2, N=30, use_last_solution=0, w_acc=-40.0),
+                                                               pkg.params_from_config(cfg2, N=30, use_last_solution=0)], sc2, 97, 30))
+    bpf = 0
+    for what, plist, scn, B, N in cases:
+        x0 = pkg.workloads.perturbed_starts(scn.ego_state, B, 777 + N)
+        pid = (np.arange(B) % len(plist)).astype(np.int32)
+        outs = {}
+        for tune in ("group=2", "group=2,pair_sweep=0"):
+            monkeypatch.setenv("CILQR_TUNE", tune)
+            eng = pkg.BatchedCILQR(plist, pkg.SceneTable.from_scenario(scn), dev=True)
+            outs[tune] = eng.solve_batch(x0, param_id=pid, trace_cap=128)
+            assert eng.last_launch_info()["trajectories_per_wavefront"] == 2
+            eng.close()
+        a, b = outs["group=2"], outs["group=2,pair_sweep=0"]
+        eq_bits(a["u"], b["u"], what + " u")
+        eq_bits(a["x"], b["x"], what + " x")
+        assert (a["res"] == b["res"]).all(), what
+        for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+            eq_bits(a["trace"][f], b["trace"][f], what + " trace." + f)
+        scene = oracle_scene(scn)
+        for bb in range(0, B, 7):
+            s_ = orc_det.solver(plist[pid[bb]])
+            r = s_.solve(x0[bb], scene)
+            eq_bits(a["u"][bb], r["u"], f"{what} u[{bb}] vs oracle")
+            eq_bits(a["x"][bb], r["x"], f"{what} x[{bb}] vs oracle")
+            assert a["res"]["iters"][bb] == r["res"]["iters"] and a["res"]["J_final"][bb] == r["res"]["J_final"] or (
+                np.isnan(a["res"]["J_final"][bb]) and np.isnan(r["res"]["J_final"]))
+        for bb in range(B):
+            bpf += int((a["trace"]["status"][bb][:a["res"]["trace_len"][bb]] == 2).sum())
+    monkeypatch.delenv("CILQR_TUNE", raising=False)
+    assert bpf > 0, "no backward pass failed: the second pass of a turn was not exercised"

@@ -19,6 +19,9 @@ OBJ = PKG / "build"
 GROUPS = 8
 
 HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result"]
+# (--offload-compress would store the code objects zstd-compressed: 4.1 MB -> 1.7 MB on disk — but llvm-readelf cannot read what
+#  llvm-objdump --offloading then extracts from a library of several bundles, i.e. scripts/kernel_metadata.py and the
+#  disassembly scans of tests/test_cabi.py would go blind.  Not used.)
 
 # The compiler the shipped kernels were validated with (bit-exact parity at scale, pairing invariance, the disassembly scans of
 # tests/test_cabi.py).  Round 4 met a gfx950 anomaly that depends on the instruction shape the compiler emits (a 16-byte

@@ -390,7 +390,7 @@ struct cilqr_handle {
                                // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
     int win_grp = 0;           // lane window of those launches
     int group_loop = 1;        // the closed loop in one launch runs the grouped build too (0: k_solve's LOOP builds)
-    int group_dual_probe = 0;  // development probe (CILQR_TUNE=grp_dual_probe=1)
+    int group_pair_sweep = 1;  // ... the sweeps of a wavefront's two trajectories in one instruction stream (CILQR_TUNE=pair_sweep=0: round 4's turn)
     int poison_scratch = 0;    // development library: fill the kernels' scratch before every launch (CILQR_TUNE=poison=1: NaN
                                // patterns, 2: zeros) — results must not depend on what the scratch held
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
@@ -577,7 +577,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "prof2") h->prof_two_per_simd = v;
                 else if (k == "group_steal") h->group_steal = v;
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
-                else if (k == "grp_dual_probe") h->group_dual_probe = v;
+                else if (k == "pair_sweep") h->group_pair_sweep = v;
                 else if (k == "group_loop") h->group_loop = v;
                 else if (k == "poison") h->poison_scratch = v;
                 else known = false;
@@ -1163,7 +1163,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.loop_states = nullptr;
     a.loop_iters = nullptr;
     a.pair_costs = h->group_pair_costs;
-    a.dual_probe = h->group_dual_probe;
+    a.pair_sweep = h->group_pair_sweep;
     return a;
 }
 

@@ -1624,9 +1624,10 @@ __device__ inline double alm_next_mu(const Cst& c, double mu, double rho, double
 
 // model Jacobians of step k (ut:285-342) into l.kd: a02 a03 a12 a13 a32 | b01 b11 b31.
 // sy, cy = dm_sincos(yaw) of row k (the caller has them already).
-__device__ inline void model_jacobians_row(const Cst& c, const Lds& l, int k, double v, double yaw, double sy, double cy) {
+__device__ inline void model_jacobians_row(const Cst& c, const Lds& l, int k, double v, double yaw, double sy, double cy,
+                                           int kds = CILQR_KD) {
     const double delta = l.u[2 * k + 1];
-    double* A = l.kd + CILQR_KD * k;
+    double* A = l.kd + kds * k; // (kds: doubles per step — CILQR_KD in LDS, the row length when l.kd points into global rows)
     double* B = A + CILQR_KD_B;
     if (c.rp == 0) {
         double td = dm_tan(delta);
@@ -1677,9 +1678,15 @@ __device__ inline void model_jacobians(const Cst& c, const Lds& l, int lane) {
 // terms (cs:581-643, 665-680), l_xx dense (b_dot c_dot^T is not bitwise symmetric), and the
 // multiplier proposal alm_mu_next is written.
 // LG = true (barrier mode only): the expansion goes to the 128-byte rows of l.gl in global memory (CILQR_GL_ROW)
-template <bool ALM, bool LG = false>
+// GROW (LG, barrier mode): doubles per row — CILQR_GL_ROW, or CILQR_GRP_ROW = 32 for the rows of a trajectory whose whole sweep
+// input streams from global memory (cilqr_group.hpp, backward_sweep_pair): the same 16 slots, then the step's eight
+// Jacobian entries at slot 16 (l.kd then points at slot 16 of row 0)
+#define CILQR_GRP_ROW 32
+#define CILQR_GRP_ROW_JAC 16
+template <bool ALM, bool LG = false, int GROW = CILQR_GL_ROW>
 __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
     const int N = c.N;
+    static_assert(GROW == CILQR_GL_ROW || (LG && !ALM), "wide rows: barrier mode, expansion in global memory");
     gdouble_w* const grows = LG ? (gdouble_w*)l.gl : nullptr;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
@@ -1784,7 +1791,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             double luub1 = (q22 * b_su) + (q22 * b_sl);
             // l_u = 2 (u R) + barrier, l_uu = 2 R + barrier (cs:491-492, 686-687)
             if (LG) {
-                gdouble_w* rm = grows + (size_t)CILQR_GL_ROW * (k - 1);
+                gdouble_w* rm = grows + (size_t)GROW * (k - 1);
                 rm[CILQR_GL_LU] = 2 * (um0 * c.k->w_acc) + lub0;
                 rm[CILQR_GL_LU + 1] = 2 * (um1 * c.k->w_stl) + lub1;
                 rm[CILQR_GL_LUU] = 2 * c.k->w_acc + luub0;
@@ -1856,7 +1863,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             continue;
         }
         if (LG) {
-            gdouble_w* r = grows + (size_t)CILQR_GL_ROW * k;
+            gdouble_w* r = grows + (size_t)GROW * k;
             r[CILQR_GL_LX] = lx0 + b0;
             r[CILQR_GL_LX + 1] = lx1 + b1;
             r[CILQR_GL_LX + 2] = lx2 + b2;
@@ -1869,7 +1876,7 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             r[CILQR_GL_LXX + 5] = 2 * c.k->w_yaw + h33;
             r[CILQR_GL_LXX22] = 2 * c.k->w_vel + h22;
             r[CILQR_GL_ZERO] = 0.0;
-            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
+            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy, GROW == CILQR_GL_ROW ? CILQR_KD : GROW);
             continue;
         }
         l.lx[4 * k] = lx0 + b0;

@@ -37,7 +37,9 @@ namespace cilqr {
 #define CILQR_GRP_QLDS false /* true: Q_uu to the lanes through the LDS crossbar instead of v_readlane — measured 1 % slower (r04_experiments) */
 #endif
 
-enum { GP_EMPTY = 0, GP_ITER = 1, GP_SEARCH = 2, GP_DONE = 3, GP_STOLEN = 4 /* b names a parked trajectory to take over */ };
+enum { GP_EMPTY = 0, GP_ITER = 1, GP_SEARCH = 2, GP_DONE = 3, GP_STOLEN = 4 /* b names a parked trajectory to take over */,
+       GP_EXPAND = 5 /* at the head of an iteration: its expansion and sweep run after every trajectory's segment (grp_expand, grp_sweep) */,
+       GP_BPF = 6 /* that sweep met a non-PD Q_uu: back in solve with BACKWARD_PASS_FAIL */ };
 
 // the scalars cs:110-141 carries from one iteration to the next, plus where the line search stands
 struct GrpSt {
@@ -64,7 +66,9 @@ __host__ __device__ inline int grp_pg_doubles(int N) { // per trajectory
 // constants) from the expansion to the end of the backward sweep and the LANE WINDOW the rest of the time — the window is
 // used where the expansion is dead (initial trajectory, line-search costs); the expansion's own single lane lookup per
 // row goes to global memory next to the lane record it needs from there anyway.
-__host__ __device__ inline int grp_expansion_doubles(int N) { return (4 * (N + 1) + 2 * N + 7 * (N + 1) + 2 * N) + CILQR_XCH; }
+// (+ the ring through which the OTHER trajectory's rows stream during a sweep of both, see backward_sweep_pair: it sits behind the
+//  expansion, inside the room the lane window uses the rest of the time)
+__host__ __device__ inline int grp_expansion_doubles(int N) { return (4 * (N + 1) + 2 * N + 7 * (N + 1) + 2 * N) + CILQR_XCH + CILQR_GL_RING; }
 __host__ __device__ inline int grp_shared_doubles(int N, int W) {
     const int e = grp_expansion_doubles(N), w = 2 * W;
     return kd_doubles(N, 1) + (e > w ? e : w);
@@ -73,9 +77,13 @@ __host__ __device__ inline size_t grp_lds_bytes(int N, int W, int G) {
     return sizeof(double) * ((size_t)G * grp_pg_doubles(N) + (size_t)grp_shared_doubles(N, W));
 }
 // global scratch per trajectory slot: slab | first-trial buffer | gains, 128-byte granules
-__host__ __device__ inline size_t grp_scratch_doubles(int N) {
+// ... | rows of the expansion + Jacobians when the trajectory's sweep input streams from global memory (backward_sweep_pair)
+__host__ __device__ inline size_t grp_rows_offset(int N) {
     const size_t d = slab_doubles(N) + first_trial_doubles(N) + (size_t)CILQR_KD * (size_t)N;
-    return (d + 15) / 16 * 16;
+    return (d + 31) / 32 * 32;
+}
+__host__ __device__ inline size_t grp_scratch_doubles(int N) {
+    return grp_rows_offset(N) + (size_t)CILQR_GRP_ROW * (size_t)(N + 1);
 }
 
 typedef double __attribute__((ext_vector_type(2))) f64x2;
@@ -187,7 +195,7 @@ __device__ inline void carve_group(Lds& l, double* base, int N, int G, int g) {
     l.xch = s; s += CILQR_XCH;
     l.win = l.lx; // (shares the expansion's area, see grp_shared_doubles)
     l.gl = nullptr;
-    l.ring = nullptr;
+    l.ring = s; s += CILQR_GL_RING;
     l.ctld = nullptr;
     l.ctli = nullptr;
     l.prof = nullptr;
@@ -196,266 +204,358 @@ __device__ inline void carve_group(Lds& l, double* base, int N, int G, int g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward_sweep_lanes (cilqr_device.hpp) for NS trajectories AT ONCE: the same step body, once per trajectory, on register
-// sets of its own inside one loop, so that the wavefront has NS independent dependent chains to issue from (a step of one
-// sweep is ~145 instructions on one chain: W gather, two 4-term passes, the 2 x 2 inverse with its IEEE division, the rank-2
-// update — a lone wavefront keeps its SIMD half busy with it).  Every element is the expression backward_sweep_lanes
-// evaluates, in its order: same bits.  base[s] = the trajectory's Lds::x (its arrays are addressed relative to it, as in
-// make_lane_map), gains[s] = where its gains go (global memory), alive: a sweep that meets a non-PD Q_uu (cs:415-420) stops
-// there — its later steps keep their Jacobians, as in the one-trajectory form — while the others go on.
-// Returns the mask of the sweeps that completed.  (A sweep that fails — non-PD Q_uu, cs:415-420 — is only marked.)
-template <int NS>
-__device__ inline unsigned backward_sweep_lanes_multi(const Cst* c, const Lds* l, const double* lamb, int lane, double (*dV)[2],
-                                                      double* const* gains) {
-    const int N = c[0].N; // (one horizon per handle)
-    const int rp = (lane >> 3) % 6, cc = lane & 7;
-    LaneMap mp[NS];
-    __amdgpu_buffer_rsrc_t ggr[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        make_lane_map<false>(l[s], lane, mp[s]);
-        if (lane == 0) {
-            l[s].xch[CILQR_XCH_CONST + 0] = 0.0;
-            l[s].xch[CILQR_XCH_CONST + 1] = 1.0;
-            l[s].xch[CILQR_XCH_CONST + 2] = c[s].dt;
-            l[s].xch[CILQR_XCH_CONST + 3] = 0.0;
-        }
-        ggr[s] = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(gains[s]), 0, N * CILQR_KD * (int)sizeof(double), 0x00020000);
+// Round 5: the backward sweeps (cs:383-440) of BOTH trajectories of a wavefront in ONE instruction stream.
+//
+// backward_sweep_lanes lays the step's 34 useful elements out on a 6 x 8 grid, 48 of 64 lanes, and the grouped kernel ran
+// it once per trajectory: two sweeps of ~144 instructions a step on a vector unit that two wavefronts keep busy (the sweep
+// is the phase that is bound by issue slots: round 4's dual-chain probe, two sweeps interleaved in one loop, took 1.95-2.11 x
+// one).  Here a trajectory gets HALF the wavefront — 32 lanes, a 4 x 8 grid — and both halves execute the same instructions:
+//   (r, c), c < 4   pass 1: X[r][c]      pass 2: Y[r][c] -> Q_xx[r][c]          owns W[r][c] = V_xx[r][c]
+//   (r, 4)          pass 1: X[r][4] -> Q_x[r] = l_x[r] + X[r][4]               owns W[r][4] = V_x[r]
+//   (k, 5)          pass 1: X[4][k]      pass 2: Y[4][k] -> Q_ux[0][k]          (0, 5): delta_V[0] += (0.5 d)^T Q_uu d
+//   (k, 6)          pass 1: X[5][k]      pass 2: Y[5][k] -> Q_ux[1][k]          (1, 5): delta_V[1] += d^T Q_u
+//   (0, 7) (1, 7)   pass 1: X[4][4], X[5][4] -> Q_u[0], Q_u[1]
+//   (r, 7)          pass 2: Y[4 + r / 2][4 + r % 2] -> the four entries of Q_uu (+ lambda on its diagonal)
+// — the rows 4 and 5 of the big grid live in the columns 5 .. 7 that the small one has to spare.  Every element is the
+// expression backward_sweep_lanes evaluates, four (or two) products summed in index order, zeros included: same bits.  What
+// changes is how operands travel: every cross-lane move is a ds_bpermute with a per-lane source (32 per step; the 6 x 8 form
+// mixes 16 of them with 10 DPP moves and 8 v_readlane), every coefficient a per-lane LDS address that walks backwards with
+// the step — so the two halves may read from different places:
+//   half 0: trajectory A, its Jacobians and expansion in the wavefront's shared LDS arrays (as for a lone sweep);
+//   half 1: trajectory B, whose expansion phase wrote 256-byte ROWS to global memory (CILQR_GRP_ROW: the 16 slots of
+//           CILQR_GL_ROW, then the step's eight Jacobian entries) because LDS holds one set — streamed through a ring of four
+//           rows in LDS, 64 doubles (two rows) per refill, fetched two steps before the sweep gets there.
+// A sweep that meets a non-PD Q_uu (cs:415-420) is only MARKED and runs on (its gains are never used: the iteration ends as
+// BACKWARD_PASS_FAIL); returns bit 0 / bit 1 = trajectory A / B completed.  gr: buffer over the block's scratch, goff: byte
+// offsets of the two gain arrays in it.
+struct PairArgs {
+    double lambA, lambB, dtA, dtB;
+    const double* rowsB; // [(N + 1)][CILQR_GRP_ROW] in global memory
+    double* ringB;       // [CILQR_GL_RING] in LDS
+    unsigned goffA, goffB;
+};
+__device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairArgs& pa, double* scr_blk, unsigned scr_bytes, int lane,
+                                               double dVA[2], double dVB[2]) {
+    const int h = lane >> 5, q = lane & 31, r = q >> 3, cg = q & 7, hb = lane & 32;
+    // this lane's two elements
+    int R1, C1, R2, C2;
+    if (cg <= 4) { R1 = r; C1 = cg; R2 = r; C2 = (cg < 4) ? cg : 0; }
+    else if (cg == 5) { R1 = 4; C1 = r; R2 = 4; C2 = r; }
+    else if (cg == 6) { R1 = 5; C1 = r; R2 = 5; C2 = r; }
+    else { R1 = 4 + (r & 1); C1 = 4; R2 = 4 + (r >> 1); C2 = 4 + (r & 1); }
+    const bool diag = (R2 >= 4) && (C2 == R2);
+    const bool isvec = (cg == 4) || (cg == 7);
+    if (lane == 0) {
+        lA.xch[CILQR_XCH_CONST + 0] = 0.0;
+        lA.xch[CILQR_XCH_CONST + 1] = 1.0;
+        lA.xch[CILQR_XCH_CONST + 2] = pa.dtA;
+        lA.xch[CILQR_XCH_CONST + 3] = pa.dtB;
     }
     wave_sync();
-    const int wc = (cc <= 4) ? cc : 4;
-    const bool diag = (rp >= 4) && (cc == rp);
-    const int r4 = rp & 3;
-    const int src_c0 = 32 + wc, src_c1 = 40 + wc;
-    const int src_r0 = (rp >= 4) ? 36 : 32 + r4, src_r1 = (rp >= 4) ? 44 : 40 + r4;
-    const double krf = (rp == 4) ? 0.5 : 1.0;
-    double wn[NS], dvacc[NS];
-    unsigned am1[NS][4], am2[NS][4], alq[NS], alv[NS];
-    unsigned dm1[NS][4], dm2[NS][4], dlq[NS], dlv[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double* const base = l[s].x;
-        wn[s] = (cc < 4) ? base[mp[s].lq + mp[s].slq * N] : base[mp[s].lv + mp[s].slv * N];
-        dvacc[s] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            am1[s][k] = lds_addr(base + mp[s].m1[k] + mp[s].s1[k] * (N - 1));
-            am2[s][k] = lds_addr(base + mp[s].m2[k] + mp[s].s2[k] * (N - 1));
-            dm1[s][k] = 8u * (unsigned)mp[s].s1[k];
-            dm2[s][k] = 8u * (unsigned)mp[s].s2[k];
+    const double* const base = lA.x;
+    const int CCo = (int)(lA.xch - lA.x) + CILQR_XCH_CONST; // ZERO; + 1 ONE; + 2 dt of A; + 3 dt of B
+    const int A5 = (int)(lA.kd - lA.x);
+    // ten coefficient addresses (LDS bytes) at step N - 1, their per-step decrements, and what a ring address gets back
+    // every fourth step; a[0..3] = M[k][R1], a[4..7] = M[k][C2], a[8] = L[R2][C2], a[9] = l[R1]
+    unsigned a[10], d[10], w[10];
+    const unsigned ring0 = lds_addr(pa.ringB);
+    constexpr unsigned ROWB = CILQR_GRP_ROW * 8u;
+    auto place = [&](int j, int off, int stride, int slotB) {
+        // off / stride: doubles relative to lA.x (half 0); slotB: slot in trajectory B's row, -1 = a constant (off applies)
+        if (h == 0 || slotB < 0) {
+            int o = off;
+            if (h == 1 && off == CCo + 2) o = CCo + 3; // (B's own dt)
+            const int st = (h == 0) ? stride : 0;
+            a[j] = lds_addr(base + o + st * (N - 1));
+            d[j] = 8u * (unsigned)st;
+            w[j] = 0u;
+        } else {
+            a[j] = ring0 + 8u * (unsigned)slotB + (unsigned)((N - 1) & 3) * ROWB;
+            d[j] = ROWB;
+            w[j] = 4u * ROWB;
         }
-        alq[s] = lds_addr(base + mp[s].lq + mp[s].slq * (N - 1));
-        alv[s] = lds_addr(base + mp[s].lv + mp[s].slv * (N - 1));
-        dlq[s] = 8u * (unsigned)mp[s].slq;
-        dlv[s] = 8u * (unsigned)mp[s].slv;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int off, stride;
+        lane_map_M(lA, k, R1, off, stride);
+        place(k, off, stride, stride ? CILQR_GRP_ROW_JAC + (off - A5) : -1);
+        lane_map_M(lA, k, C2, off, stride);
+        place(4 + k, off, stride, stride ? CILQR_GRP_ROW_JAC + (off - A5) : -1);
     }
-    // One straight-line block per step: phase by phase over the sweeps, so that the scheduler can interleave their chains.  A
-    // sweep whose Q_uu turns out not to be positive definite is only MARKED: it keeps running on whatever numbers it has (its
-    // gains are never used: the iteration ends as BACKWARD_PASS_FAIL and expands afresh; no address leaves its arrays), which
-    // keeps the loop free of per-sweep control flow.  The exact pivot test (sqrt, quotient) is one rare branch for all sweeps.
+    int slotq = -1, slotv;
+    {
+        // L[R2][C2]: l_xx (7 packed entries 00 01 03 11 13 33 22), l_uu diagonal, zero elsewhere
+        int off = CCo, stride = 0;
+        if (R2 < 4 && C2 < 4) {
+            const int lo = (R2 < C2) ? R2 : C2, hi = (R2 < C2) ? C2 : R2;
+            int e = -1;
+            if (lo == 0 && hi == 0) e = 0;
+            if (lo == 0 && hi == 1) e = 1;
+            if (lo == 0 && hi == 3) e = 2;
+            if (lo == 1 && hi == 1) e = 3;
+            if (lo == 1 && hi == 3) e = 4;
+            if (lo == 3 && hi == 3) e = 5;
+            if (lo == 2 && hi == 2) e = 6;
+            if (e >= 0) { off = (int)(lA.lxx - lA.x) + e; stride = 7; slotq = (e < 6) ? CILQR_GL_LXX + e : CILQR_GL_LXX22; }
+        } else if (diag) {
+            off = (int)(lA.luu - lA.x) + (R2 - 4); stride = 2; slotq = CILQR_GL_LUU + (R2 - 4);
+        }
+        place(8, off, stride, slotq);
+        if (R1 < 4) { off = (int)(lA.lx - lA.x) + R1; stride = 4; slotv = CILQR_GL_LX + R1; }
+        else { off = (int)(lA.lu - lA.x) + (R1 - 4); stride = 2; slotv = CILQR_GL_LU + (R1 - 4); }
+        place(9, off, stride, slotv);
+    }
+    // cross-lane sources (ds_bpermute byte addresses)
+    int sw[4], sx[4], sq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sw[k] = (hb + 8 * k + C1) << 2;
+        sx[k] = ((R2 < 4) ? hb + 8 * R2 + k : hb + 8 * k + (R2 == 4 ? 5 : 6)) << 2;
+        sq[k] = (hb + 8 * k + 7) << 2;
+    }
+    int sc0, sc1, sr0, sr1;
+    if (cg <= 4) {
+        sc0 = (cg < 4) ? hb + 8 * cg + 5 : hb + 7;
+        sc1 = (cg < 4) ? hb + 8 * cg + 6 : hb + 15;
+        sr0 = hb + 8 * r + 5;
+        sr1 = hb + 8 * r + 6;
+    } else { // (only (0, 5) and (1, 5) matter: r = c = Q_u, the expected cost reduction)
+        sc0 = hb + 7; sc1 = hb + 15; sr0 = hb + 7; sr1 = hb + 15;
+    }
+    sc0 <<= 2; sc1 <<= 2; sr0 <<= 2; sr1 <<= 2;
+    const double krf = (q == 5) ? 0.5 : 1.0;
+    const double lamb = h ? pa.lambB : pa.lambA;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(scr_blk), 0, (int)scr_bytes, 0x00020000);
+    const unsigned goff = (h ? pa.goffB : pa.goffA) + 8u * (unsigned)q;
+    // trajectory B's rows: a ring of two chunks (two rows each)
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(const_cast<double*>(pa.rowsB)), 0,
+                                                                          (N + 1) * (int)ROWB, 0x00020000);
+    constexpr int CHB = 2 * (int)ROWB; // bytes per chunk
+    double chunk = 0.0;
+    {
+        const int c0 = (N - 1) / 2;
+        const double first = gl_load(grs, 8u * (unsigned)lane, c0 * CHB);
+        pa.ringB[(c0 & 1) * CILQR_WAVE + lane] = first;
+        if (c0 > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (c0 - 1) * CHB);
+    }
+    // W = [l_xx[N] | l_x[N]] on the lanes (r, c <= 4)
+    double wn = 0.0;
+    if (cg <= 4) {
+        if (h == 0) {
+            // (the addresses above are at step N - 1: one stride further is row N)
+            wn = (cg < 4) ? lds_load(a[8] + d[8]) : lds_load(a[9] + d[9]);
+        } else {
+            const int slot = (cg < 4) ? slotq : slotv;
+            wn = (slot >= 0) ? gl_load(grs, 8u * (unsigned)slot, N * (int)ROWB) : 0.0;
+        }
+    }
+    wave_sync(); // (the ring's first chunk is in place)
+    double dvacc = 0.0;
     unsigned failed = 0u;
     for (int i = N - 1; i >= 0; --i) {
-        double Q[NS], Zv[NS], S[NS], c0[NS], c1[NS], r0[NS], r1[NS], invdet[NS], Quu0[NS], Quu1[NS], Quu2[NS], Quu3[NS];
-        double m1[NS][4], m2[NS][4], Lq[NS], lv[NS], w0[NS], w1[NS], w2[NS], w3[NS], X[NS], Xq[NS];
-        unsigned need_exact = 0u;
-        int ccv = cc;
-        __asm__("" : "+v"(ccv));
-        // (sub-phase by sub-phase over the sweeps — written out in the order the chains should be issued: every LDS round
-        //  trip of one sweep in flight together with the other's)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                m1[s][k] = lds_load(am1[s][k]);
-                m2[s][k] = lds_load(am2[s][k]);
-                am1[s][k] -= dm1[s][k];
-                am2[s][k] -= dm2[s][k];
-            }
-            Lq[s] = lds_load(alq[s]);
-            lv[s] = lds_load(alv[s]);
-            alq[s] -= dlq[s];
-            alv[s] -= dlv[s];
-            w0[s] = lane_gather(wn[s], wc); w1[s] = lane_gather(wn[s], 8 + wc);
-            w2[s] = lane_gather(wn[s], 16 + wc); w3[s] = lane_gather(wn[s], 24 + wc);
+        if ((i & 1) == 1 && i != N - 1) {
+            // the sweep enters chunk c of B's rows: they arrived while chunk c + 1 was computed; fetch chunk c - 1
+            const int cch = i >> 1;
+            pa.ringB[(cch & 1) * CILQR_WAVE + lane] = chunk;
+            if (cch > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (cch - 1) * CHB);
         }
-        // (statement by statement over the sweeps: consecutive instructions belong to different chains)
-#define EACH_S for (int s = 0; s < NS; ++s)
-        double tX[NS], x0[NS], x1[NS], x2[NS], x3[NS], tY[NS], det[NS];
+        double m1[4], m2[4];
 #pragma unroll
-        EACH_S tX[s] = m1[s][0] * w0[s];
+        for (int k = 0; k < 4; ++k) {
+            m1[k] = lds_load(a[k]);
+            m2[k] = lds_load(a[4 + k]);
+        }
+        const double Lq = lds_load(a[8]), lv = lds_load(a[9]);
 #pragma unroll
-        EACH_S tX[s] = CQ_MADD(m1[s][1], w1[s], tX[s]);
+        for (int j = 0; j < 10; ++j) a[j] -= d[j];
+        if ((i & 3) == 0) {
 #pragma unroll
-        EACH_S tX[s] = CQ_MADD(m1[s][2], w2[s], tX[s]);
-#pragma unroll
-        EACH_S X[s] = CQ_MADD(m1[s][3], w3[s], tX[s]);
-#pragma unroll
-        EACH_S Zv[s] = lv[s] + X[s];
-#pragma unroll
-        EACH_S Xq[s] = dpp_move_banks<0x114, 0xA>(X[s]);
-#pragma unroll
-        EACH_S x0[s] = dpp_move<0x00>(Xq[s]);
-#pragma unroll
-        EACH_S x1[s] = dpp_move<0x55>(Xq[s]);
-#pragma unroll
-        EACH_S x2[s] = dpp_move<0xAA>(Xq[s]);
-#pragma unroll
-        EACH_S x3[s] = dpp_move<0xFF>(Xq[s]);
-#pragma unroll
-        EACH_S tY[s] = x0[s] * m2[s][0];
-#pragma unroll
-        EACH_S tY[s] = CQ_MADD(x1[s], m2[s][1], tY[s]);
-#pragma unroll
-        EACH_S tY[s] = CQ_MADD(x2[s], m2[s][2], tY[s]);
-#pragma unroll
-        EACH_S tY[s] = CQ_MADD(x3[s], m2[s][3], tY[s]);
-#pragma unroll
-        EACH_S Q[s] = Lq[s] + tY[s];
-#pragma unroll
-        EACH_S { if (diag) Q[s] = Q[s] + lamb[s]; }
-#pragma unroll
-        EACH_S S[s] = (ccv == 4) ? Zv[s] : Q[s];
-#pragma unroll
-        EACH_S { c0[s] = lane_gather(S[s], src_c0); c1[s] = lane_gather(S[s], src_c1); }
-#pragma unroll
-        EACH_S { r0[s] = lane_gather(S[s], src_r0); r1[s] = lane_gather(S[s], src_r1); }
-#pragma unroll
-        EACH_S { Quu0[s] = lane_bcast<36>(Q[s]); Quu1[s] = lane_bcast<37>(Q[s]); Quu2[s] = lane_bcast<44>(Q[s]); Quu3[s] = lane_bcast<45>(Q[s]); }
-#pragma unroll
-        EACH_S det[s] = Quu0[s] * Quu3[s] - Quu2[s] * Quu1[s];
-#pragma unroll
-        EACH_S invdet[s] = 1.0 / det[s];
-#pragma unroll
-        EACH_S {
-            const unsigned h0 = (unsigned)(dm_to_bits(Quu0[s]) >> 32), h3 = (unsigned)(dm_to_bits(Quu3[s]) >> 32);
+            for (int j = 0; j < 10; ++j) a[j] += w[j];
+        }
+        auto gather = [](double v, int src4) {
+            const unsigned long long u = dm_to_bits(v);
+            int lo = (int)(unsigned)(u & 0xffffffffULL), hi = (int)(unsigned)(u >> 32);
+            lo = __builtin_amdgcn_ds_bpermute(src4, lo);
+            hi = __builtin_amdgcn_ds_bpermute(src4, hi);
+            return dm_from_bits(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+        };
+        // pass 1
+        const double w0 = gather(wn, sw[0]), w1 = gather(wn, sw[1]), w2 = gather(wn, sw[2]), w3 = gather(wn, sw[3]);
+        const double X = CQ_MADD(m1[3], w3, CQ_MADD(m1[2], w2, CQ_MADD(m1[1], w1, m1[0] * w0)));
+        const double Zv = lv + X;
+        // pass 2
+        const double x0 = gather(X, sx[0]), x1 = gather(X, sx[1]), x2 = gather(X, sx[2]), x3 = gather(X, sx[3]);
+        const double Y = CQ_MADD(x3, m2[3], CQ_MADD(x2, m2[2], CQ_MADD(x1, m2[1], x0 * m2[0])));
+        double Q = Lq + Y;
+        if (diag) Q = Q + lamb;
+        const double Quu0 = gather(Q, sq[0]), Quu1 = gather(Q, sq[1]), Quu2 = gather(Q, sq[2]), Quu3 = gather(Q, sq[3]);
+        const double S = isvec ? Zv : Q;
+        const double c0 = gather(S, sc0), c1 = gather(S, sc1), r0 = gather(S, sr0), r1 = gather(S, sr1);
+        const double det = Quu0 * Quu3 - Quu2 * Quu1;
+        const double invdet = 1.0 / det;
+        {
+            // Eigen::LLT's verdict (see backward_sweep_lanes): decided without the square root on ordinary magnitudes
+            const unsigned h0 = (unsigned)(dm_to_bits(Quu0) >> 32), h3 = (unsigned)(dm_to_bits(Quu3) >> 32);
             const bool ordinary = ((h0 - 0x2B300000u) < 0x29800000u) && ((h3 - 0x2B300000u) < 0x29800000u);
-            const bool surely_pd = ordinary && (Quu0[s] * Quu3[s] > (Quu2[s] * Quu2[s]) * 1.0000000000009095);
-            if (!surely_pd) need_exact |= (1u << s);
-        }
-        if (need_exact != 0u) { // Eigen::LLT's verdict evaluated exactly (see backward_sweep_lanes)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (!(need_exact & (1u << s)) || (failed & (1u << s))) continue;
+            const bool surely_pd = ordinary && (Quu0 * Quu3 > (Quu2 * Quu2) * 1.0000000000009095);
+            unsigned long long need = __ballot(!surely_pd);
+            if (failed & 1u) need &= 0xffffffff00000000ULL;
+            if (failed & 2u) need &= 0x00000000ffffffffULL;
+            if (need != 0ULL) {
                 bool fail = false;
-                if (Quu0[s] <= 0.0) {
-                    fail = true;
-                } else {
-                    double l00 = dm_sqrt(Quu0[s]);
-                    double l10 = Quu2[s] / l00;
-                    double piv1 = Quu3[s] - l10 * l10;
-                    if (piv1 <= 0.0) fail = true;
+                if (!surely_pd) {
+                    if (Quu0 <= 0.0) {
+                        fail = true;
+                    } else {
+                        const double l00 = dm_sqrt(Quu0);
+                        const double l10 = Quu2 / l00;
+                        const double piv1 = Quu3 - l10 * l10;
+                        if (piv1 <= 0.0) fail = true;
+                    }
                 }
-                if (fail) failed |= (1u << s);
-            }
-            if (failed == (1u << NS) - 1u) break; // nobody left
-        }
-        double kc0[NS], kc1[NS], n00[NS], n01[NS], n10[NS], n11[NS], kr0[NS], kr1[NS], p0[NS], p1[NS], ta[NS], tb[NS], tc[NS];
-        int rpv = rp;
-        __asm__("" : "+v"(rpv));
-#pragma unroll
-        EACH_S { n00[s] = -(Quu3[s] * invdet[s]); n01[s] = -(-Quu1[s] * invdet[s]); n10[s] = -(-Quu2[s] * invdet[s]); n11[s] = -(Quu0[s] * invdet[s]); }
-#pragma unroll
-        EACH_S { kc0[s] = n00[s] * c0[s]; kc1[s] = n10[s] * c0[s]; kr0[s] = n00[s] * r0[s]; kr1[s] = n10[s] * r0[s]; }
-#pragma unroll
-        EACH_S { kc0[s] = CQ_MADD(n01[s], c1[s], kc0[s]); kc1[s] = CQ_MADD(n11[s], c1[s], kc1[s]);
-                 kr0[s] = CQ_MADD(n01[s], r1[s], kr0[s]); kr1[s] = CQ_MADD(n11[s], r1[s], kr1[s]); }
-#pragma unroll
-        EACH_S { kr0[s] = kr0[s] * krf; kr1[s] = kr1[s] * krf; }
-#pragma unroll
-        EACH_S { p0[s] = kr0[s] * Quu0[s]; p1[s] = kr0[s] * Quu1[s]; tb[s] = kr0[s] * c0[s]; tc[s] = r0[s] * kc0[s]; }
-#pragma unroll
-        EACH_S { p0[s] = CQ_MADD(kr1[s], Quu2[s], p0[s]); p1[s] = CQ_MADD(kr1[s], Quu3[s], p1[s]);
-                 tb[s] = CQ_MADD(kr1[s], c1[s], tb[s]); tc[s] = CQ_MADD(r1[s], kc1[s], tc[s]); }
-#pragma unroll
-        EACH_S ta[s] = p0[s] * kc0[s];
-#pragma unroll
-        EACH_S ta[s] = CQ_MADD(p1[s], kc1[s], ta[s]);
-#pragma unroll
-        EACH_S { const double own = (ccv < 4) ? Q[s] : Zv[s]; wn[s] = own + ta[s]; }
-#pragma unroll
-        EACH_S wn[s] = wn[s] + tb[s];
-#pragma unroll
-        EACH_S wn[s] = wn[s] + tc[s];
-#pragma unroll
-        EACH_S dvacc[s] = dvacc[s] + ((rpv == 4) ? ta[s] : tb[s]);
-#undef EACH_S
-        int lanev = lane;
-        __asm__("" : "+v"(lanev));
-        if (lanev < 5) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc0[s]), ggr[s], 8u * (unsigned)lane, i * (CILQR_KD * 8), 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc1[s]), ggr[s], 8u * (unsigned)lane + 8u * CILQR_KD_ROW,
-                                                      i * (CILQR_KD * 8), 0);
+                const unsigned long long fb = __ballot(fail);
+                if ((fb & 0x00000000ffffffffULL) != 0ULL) failed |= 1u;
+                if ((fb & 0xffffffff00000000ULL) != 0ULL) failed |= 2u;
+                if (failed == 3u) break;
             }
         }
+        const double n00 = -(Quu3 * invdet), n01 = -(-Quu1 * invdet), n10 = -(-Quu2 * invdet), n11 = -(Quu0 * invdet);
+        const double kc0 = CQ_MADD(n01, c1, n00 * c0), kc1 = CQ_MADD(n11, c1, n10 * c0); // (K | d)[:, c]
+        double kr0 = CQ_MADD(n01, r1, n00 * r0), kr1 = CQ_MADD(n11, r1, n10 * r0);       // K[:, r]
+        kr0 = kr0 * krf; // (exact: the factor is 1, or 0.5 on lane (0, 5) — hd = 0.5 d of cs:435)
+        kr1 = kr1 * krf;
+        const double p0 = CQ_MADD(kr1, Quu2, kr0 * Quu0);
+        const double p1 = CQ_MADD(kr1, Quu3, kr0 * Quu1);
+        const double ta = CQ_MADD(p1, kc1, p0 * kc0);
+        const double tb = CQ_MADD(kr1, c1, kr0 * c0);
+        const double tc = CQ_MADD(r1, kc1, r0 * kc0);
+        int cgv = cg;
+        __asm__("" : "+v"(cgv));
+        const double own = (cgv < 4) ? Q : Zv;
+        wn = ((own + ta) + tb) + tc;
+        int qv = q;
+        __asm__("" : "+v"(qv));
+        if (qv < 5) { // row 0 of a half holds (K | d) column c
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc0), gr, goff, i * (CILQR_KD * 8), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kc1), gr, goff + 8u * CILQR_KD_ROW, i * (CILQR_KD * 8), 0);
+        }
+        dvacc = dvacc + ((qv == 5) ? ta : tb);
     }
-    const unsigned alive = ((1u << NS) - 1u) & ~failed;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        dV[s][0] = lane_bcast<36>(dvacc[s]);
-        dV[s][1] = lane_bcast<44>(dvacc[s]);
-    }
+    dVA[0] = lane_bcast<5>(dvacc);
+    dVA[1] = lane_bcast<13>(dvacc);
+    dVB[0] = lane_bcast<37>(dvacc);
+    dVB[1] = lane_bcast<45>(dvacc);
     wave_sync();
-    return alive;
+    return 3u & ~failed;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Expansion + backward sweep of the trajectory in slot g (cs:463-690, cs:383-440), OUT OF LINE: everything it needs is in
-// LDS (x, u, lane indices, constants) or an argument, everything it produces goes to LDS (Jacobians, expansion — consumed
-// inside —, the expected cost reduction) or global memory (the gains), so the call carries nothing and the sweep's serial
-// loop gets a register allocation of its own.  Inlined into the kernel's state machine the loop picked up a scratch reload
-// per step whenever the code around it grew (152 -> 164 instructions a step, backward 69 k -> 85 k cycles per iteration).
-// prof: development library, cycle accounting (PH_DERIV = 1, PH_BACKWARD = 2, PH_TOTAL = 6 of the slot's accumulators).
-template <int NC, int G>
-__device__ __attribute__((noinline)) bool grp_expand_backward(double* lds, int g, int n_rt, int lane, double lamb, double* gains,
-                                                               long long* prof, int dual_probe = 0) {
-    const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
+// The head of an iteration in two steps (round 5), so that the sweeps of the wavefront's two trajectories can run as one:
+// grp_expand — cost expansion + model Jacobians of the trajectory in slot g (cs:463-690, ut:285-342), into the wavefront's
+// shared LDS arrays (STREAM = false: the first trajectory of a turn that gets here) or into its rows in global memory (STREAM =
+// true: the second one; LDS holds one set) — and grp_sweep, after every trajectory of the turn has had its segment: the
+// backward sweep (cs:383-440) of the one trajectory that is waiting, or of both in one instruction stream.  Both read
+// everything from LDS / their arguments and leave their results in GrpSt (dV, and for a completed sweep the request for
+// the search's first rollout pass) and global memory (gains): the calls carry nothing.
+template <int NC, int G, bool STREAM>
+__device__ __attribute__((noinline)) void grp_expand(double* lds, int g, int n_rt, int lane, double* rows_rt, long long* prof) {
+    const int N = NC ? NC : uniform_int(n_rt);
     Lds l;
     carve_group(l, lds, N, G, g);
     Cst c;
     load_cst_lds(c, grp_cst(lds, N, g));
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
-    long long t0 = (CILQR_GPROF && prof) ? (long long)__builtin_readcyclecounter() : 0;
+    const long long t0 = (CILQR_GPROF && prof) ? (long long)__builtin_readcyclecounter() : 0;
     l.W = 0; // the lane window gives way to the expansion (the rows' one lane lookup each: global memory)
-    // (always expanded afresh: the expansion area is shared by the wavefront's trajectories; after a failed pass the
-    //  reference keeps the old one, cs:469-475 — same trajectory, same bits)
-    cost_and_model_derivatives<false, false>(c, l, al, lane);
+    if (STREAM) {
+        double* const rows = (double*)uniform_ptr(rows_rt);
+        l.gl = rows;
+        l.kd = rows + CILQR_GRP_ROW_JAC; // (the Jacobians of step k at slot 16 of row k)
+        cost_and_model_derivatives<false, true, CILQR_GRP_ROW>(c, l, al, lane);
+    } else {
+        cost_and_model_derivatives<false, false>(c, l, al, lane);
+    }
     if (CILQR_GPROF && prof) {
         const long long t1 = (long long)__builtin_readcyclecounter();
         if (lane == 0) { prof[1] += t1 - t0; prof[6] += t1 - t0; }
-        t0 = t1;
     }
-    double dV[2];
-    bool ok;
-    if (CILQR_GPROF && dual_probe) {
-        // development probe (profiles/r04_experiments): the SAME sweep twice in one loop, two independent chains — what would
-        // two trajectories' sweeps cost side by side?  (identical inputs, identical outputs, the gains stored twice)
-        const Cst c2[2] = {c, c};
-        const Lds l2[2] = {l, l};
-        const double lamb2[2] = {lamb, lamb};
-        double dV2[2][2];
-        double* const gains2[2] = {gains, gains};
-        const unsigned done = backward_sweep_lanes_multi<2>(c2, l2, lamb2, lane, dV2, gains2);
-        ok = (done & 1u) != 0u;
-        dV[0] = dV2[0][0];
-        dV[1] = dV2[0][1];
+}
+
+// what a completed sweep leaves behind for the trajectory: the head of its line search (cs:349-354)
+__device__ inline void grp_after_sweep(GrpSt* st, bool ok, double dV0, double dV1, int tier) {
+    st->dV0 = dV0;
+    st->dV1 = dV1;
+    if (ok) {
+        const int all = (tier == 0) || (tier < 0 && st->deep_next != 0);
+        st->status = CILQR_RUNNING;
+        st->new_J = st->J_cur;
+        st->trials = 0;
+        st->flag = 0;
+        st->have_all = all;
+        st->t0 = 0;
+        st->req = all ? 2 : 1;
+        st->phase = GP_SEARCH;
     } else {
-        ok = backward_sweep_lanes<0, true, CILQR_GRP_QLDS>(c, l, lamb, lane, dV, nullptr, gains);
+        st->phase = GP_BPF;
     }
-    if (lane == 0) {
-        GrpSt* st = grp_state(lds, N, g);
-        st->dV0 = dV[0];
-        st->dV1 = dV[1];
+}
+
+// gA: the trajectory whose expansion is in LDS; gB: the one whose rows are in global memory, or -1.  Returns the number of
+// trajectories that now wait for a rollout pass.
+template <int NC, int G>
+__device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int gB_rt, int n_rt, int lane, double* scr_blk_rt, int tier_rt,
+                                                   long long* profA, long long* profB) {
+    const int N = NC ? NC : uniform_int(n_rt);
+    const int gA = uniform_int(gA_rt), gB = uniform_int(gB_rt), tier = uniform_int(tier_rt);
+    double* const scr_blk = (double*)uniform_ptr(scr_blk_rt);
+    Lds l;
+    carve_group(l, lds, N, G, gA);
+    GrpSt* const stA = grp_state(lds, N, gA);
+    const long long t0 = (CILQR_GPROF && profA) ? (long long)__builtin_readcyclecounter() : 0;
+    const size_t slot_d = grp_scratch_doubles(N);
+    const size_t gains_d = slab_doubles(N) + first_trial_doubles(N);
+    int asked = 0;
+    if (gB < 0) {
+        Cst c;
+        load_cst_lds(c, grp_cst(lds, N, gA));
+        double dV[2];
+        const bool ok = backward_sweep_lanes<0, true, CILQR_GRP_QLDS>(c, l, stA->lamb, lane, dV, nullptr, scr_blk + (size_t)gA * slot_d + gains_d);
+        if (lane == 0) grp_after_sweep(stA, ok, dV[0], dV[1], tier);
+        asked = ok ? 1 : 0;
+    } else {
+        GrpSt* const stB = grp_state(lds, N, gB);
+        PairArgs pa;
+        pa.lambA = stA->lamb; pa.lambB = stB->lamb;
+        pa.dtA = stA->dt; pa.dtB = stB->dt;
+        pa.rowsB = scr_blk + (size_t)gB * slot_d + grp_rows_offset(N);
+        pa.ringB = l.ring;
+        pa.goffA = (unsigned)(((size_t)gA * slot_d + gains_d) * sizeof(double));
+        pa.goffB = (unsigned)(((size_t)gB * slot_d + gains_d) * sizeof(double));
+        double dVA[2], dVB[2];
+        const unsigned ok = backward_sweep_pair(N, l, pa, scr_blk, (unsigned)(G * slot_d * sizeof(double)), lane, dVA, dVB);
+        if (lane == 0) {
+            grp_after_sweep(stA, (ok & 1u) != 0u, dVA[0], dVA[1], tier);
+            grp_after_sweep(stB, (ok & 2u) != 0u, dVB[0], dVB[1], tier);
+        }
+        asked = (int)(ok & 1u) + (int)((ok >> 1) & 1u);
     }
     wave_sync();
-    if (CILQR_GPROF && prof) {
+    if (CILQR_GPROF && profA) {
         const long long t1 = (long long)__builtin_readcyclecounter();
-        if (lane == 0) { prof[2] += t1 - t0; prof[6] += t1 - t0; }
+        const long long dt = (t1 - t0) / ((gB >= 0) ? 2 : 1); // (a sweep of both: shared out)
+        if (lane == 0) {
+            profA[2] += dt; profA[6] += dt;
+            if (gB >= 0 && profB) { profB[2] += dt; profB[6] += dt; }
+        }
     }
-    return ok;
+    return asked;
 }
+
+// (Round 4's grp_expand_backward — expansion + sweep of one trajectory in one call — and its development probe
+//  backward_sweep_lanes_multi, two sweeps interleaved in one loop on separate register sets: 1.95-2.11 x the time of one —
+//  are gone: grp_expand + grp_sweep do the same for one trajectory, and the sweep of two is backward_sweep_pair.)
 
 // get_total_cost (cs:199-287) of trial t of the trajectory in slot g — out of line for the same reason: the trial lives in
 // global memory (src / as: the slab or the first-trial buffer), x's lane window is staged (w0, W), the result is the return

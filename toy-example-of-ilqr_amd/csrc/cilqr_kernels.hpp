@@ -20,6 +20,9 @@ extern __shared__ double g_lds[];
 #ifndef CILQR_OOL_COST
 #define CILQR_OOL_COST 1
 #endif
+#ifndef CILQR_GRP_PAIR_SWEEP
+#define CILQR_GRP_PAIR_SWEEP 1 /* the grouped kernel sweeps both trajectories of a wavefront in one instruction stream (backward_sweep_pair) */
+#endif
 #ifndef CILQR_SOLVE_WAVES_PER_SIMD
 #define CILQR_SOLVE_WAVES_PER_SIMD 1
 #endif
@@ -71,7 +74,8 @@ struct BatchArgs {
     double* loop_states;        // optional [B][loop_ticks][4]: the ego state after every tick
     int32_t* loop_iters;        // optional [loop_ticks][B]: iterations of every tick's solve
     int pair_costs;             // grouped build: line-search trials after the first costed two per pass
-    int dual_probe;             // development probe: the backward sweep twice in one loop (CILQR_TUNE=grp_dual_probe=1)
+    int pair_sweep;             // grouped build: the backward sweeps of a wavefront's two trajectories in one instruction stream
+                                // (1; 0 = one after the other as in round 4 — development library, CILQR_TUNE=pair_sweep=0)
 };
 
 __device__ inline AlmSt load_alm(const BatchArgs& a, int b, int N) {
@@ -851,17 +855,41 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
     const bool steal = a.park != nullptr; // the tail of the launch: idle wavefronts take over trajectories of wavefronts that hold two
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    // Round 5: a turn of the wavefront = (pass 0) every trajectory's segment up to the point where it needs a rollout pass OR
+    // stands at the head of an iteration (GP_EXPAND); then the expansions of those — the first into the shared LDS arrays, the
+    // second into its rows in global memory — and ONE backward sweep for both (grp_sweep: two trajectories in one instruction
+    // stream); (pass 1, rare) the segments of trajectories whose sweep met a non-PD Q_uu, which carry on as in round 4 with
+    // expansion + sweep in one call; then the rollout pass.  All searches of a turn come before all expansions because a
+    // search's lane window and the first expansion share LDS.  CILQR_GRP_PAIR_SWEEP = 0: round 4's turn (A/B builds).
     for (;;) {
         int n_live = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            // ---- the heads of the iterations that are due: expansions, then the sweep(s) ----
+            int gA = -1, gB = -1;
+            for (int g = 0; g < G; ++g)
+                if (uniform_int(grp_state(g_lds, N, g)->phase) == GP_EXPAND) { if (gA < 0) gA = g; else gB = g; }
+            if (gA < 0) break;
+            const bool prof2 = CILQR_GPROF && a.prof != nullptr;
+            grp_expand<NC, G, false>(g_lds, gA, N, lane, nullptr, prof2 ? grp_prof(g_lds, N, gA) : nullptr);
+            if (gB >= 0)
+                grp_expand<NC, G, true>(g_lds, gB, N, lane, scr_blk + (size_t)gB * grp_scratch_doubles(N) + grp_rows_offset(N),
+                                        prof2 ? grp_prof(g_lds, N, gB) : nullptr);
+            const int asked = uniform_int(grp_sweep<NC, G>(g_lds, gA, gB, N, lane, scr_blk, a.tier, prof2 ? grp_prof(g_lds, N, gA) : nullptr,
+                                                           (prof2 && gB >= 0) ? grp_prof(g_lds, N, gB) : nullptr));
+            n_live += asked;
+            if (asked == ((gB >= 0) ? 2 : 1)) break; // (nobody failed: no second pass)
+        }
         for (int g = 0; g < G; ++g) {
             Lds l;
             carve_group(l, g_lds, N, G, g);
             GrpSt* const st = grp_state(g_lds, N, g);
             int phase = uniform_int(st->phase);
             if (phase == GP_DONE) continue;
+            if (pass == 1 && phase != GP_BPF) continue; // (second pass: only the trajectories whose sweep failed)
+            const bool split = CILQR_GRP_PAIR_SWEEP && a.pair_sweep != 0 && pass == 0;
             double* const scr = scr_blk + (size_t)g * grp_scratch_doubles(N);
             double* const first = scr + slab_doubles(N);
-            double* const gains = first + first_trial_doubles(N);
             long long* const pacc = grp_prof(g_lds, N, g);
             const bool prof = CILQR_GPROF && a.prof != nullptr;
             long long t_ph = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -879,7 +907,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             int keep_b = -1, t_done = 0; // closed loop: the slot's next trajectory is the same ego, its next tick
             double J_cur = 0.0, J_init = 0.0, lamb = 0.0, new_J = 0.0, dV[2] = {0.0, 0.0};
             long long tl_start = 0;
-            bool resume = (phase == GP_SEARCH);
+            int entry = (phase == GP_SEARCH) ? 1 : (phase == GP_BPF ? 2 : 0); // where the segment takes the solve up again
             // is a wavefront waiting for work?  (asked here, needed when this trajectory is back in solve: the answer's
             // latency is hidden; only a wavefront that holds two trajectories will act on it)
             unsigned waiting_probe = 0;
@@ -920,12 +948,18 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 tl_start = st->tl_start;
                 t_done = LOOP ? uniform_int(st->t_done) : 0;
                 load_cst_lds(c, grp_cst(g_lds, N, g));
-                stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
+                if (entry == 1) stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
                 GPROF_ADD(PH_TC_REF); // (grouped build: slot 10 = the segment's set-up — state, constants, lane window)
             }
             for (;;) {
                 int alpha_idx = -1;
-                if (!resume) {
+                if (entry == 2) {
+                    // the sweep of this trajectory met a non-PD Q_uu (cs:345-347): back in solve with what iter_step hands back
+                    entry = 0;
+                    status = CILQR_BACKWARD_PASS_FAIL;
+                    new_J = J_cur;
+                    trials = 0;
+                } else if (entry == 0) {
                     if (phase == GP_EMPTY) {
                         unsigned nb = (unsigned)a.B;
                         if (LOOP && keep_b >= 0) { nb = (unsigned)keep_b; keep_b = -1; } // the next tick of the ego this slot is driving
@@ -984,7 +1018,13 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         // ---- iter_step ----
                         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
                         if (prof) { GPROF_ADD(PH_TC_STAGE); }
-                        const bool ok = grp_expand_backward<NC, G>(g_lds, g, N, lane, lamb, gains, prof ? pacc : nullptr, a.dual_probe);
+                        if (split) { phase = GP_EXPAND; break; } // its expansion and sweep run after every trajectory's segment
+                        // (a trajectory on its own — second pass after a failed sweep, or round 4's turn: the same two functions, one
+                        //  trajectory; they read lambda and leave the request in its block)
+                        if (lane == 0) { st->lamb = lamb; st->deep_next = deep_next ? 1 : 0; st->J_cur = J_cur; }
+                        lds_sync();
+                        grp_expand<NC, G, false>(g_lds, g, N, lane, nullptr, prof ? pacc : nullptr);
+                        const bool ok = uniform_int(grp_sweep<NC, G>(g_lds, g, -1, N, lane, scr_blk, a.tier, prof ? pacc : nullptr, nullptr)) == 1;
                         if (prof) t_ph = (long long)__builtin_readcyclecounter(); // (booked inside)
                         status = CILQR_RUNNING;
                         dV[0] = st->dV0;
@@ -1002,7 +1042,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         status = CILQR_BACKWARD_PASS_FAIL;
                     }
                 } else {
-                    resume = false;
+                    entry = 0;
                     // ---- the line search of cs:354-372, from trial t0 on ----
                     bool done = false, again = false;
                     while (t0 < CILQR_MAX_ALPHA_TRIALS && !done) {
@@ -1085,8 +1125,10 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     if (steal && __builtin_amdgcn_readfirstlane((int)waiting_probe) != 0) {
                         // somebody is waiting for work and this wavefront holds another live trajectory: hand this one over
                         bool other = false;
-                        for (int h = 0; h < G; ++h)
-                            if (h != g && uniform_int(grp_state(g_lds, N, h)->phase) == GP_SEARCH) other = true;
+                        for (int h = 0; h < G; ++h) {
+                            const int ph = uniform_int(grp_state(g_lds, N, h)->phase);
+                            if (h != g && (ph == GP_SEARCH || ph == GP_EXPAND)) other = true; // (live: waits for a pass, or for its sweep)
+                        }
                         if (other && grp_take_ticket(a.ctl, lane)) {
                             if (lane == 0) {
                                 st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
@@ -1168,7 +1210,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             // what the trajectory carries to its next segment
             if (lane == 0) {
                 st->phase = phase;
-                if (phase == GP_SEARCH) {
+                if (phase == GP_SEARCH || phase == GP_EXPAND) {
                     st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
                     st->cost_evals = cost_evals; st->tl = tl; st->flag = flag; st->t0 = t0; st->trials = trials;
                     st->deep_next = deep_next ? 1 : 0; st->have_all = have_all ? 1 : 0;
@@ -1181,6 +1223,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             GPROF_ADD(PH_TC_SUM); // (slot 12 = parking the state)
 #undef GPROF_ADD
             if (phase == GP_SEARCH) n_live++;
+        }
         }
         if (n_live == 0) {
             if (!steal) break;
