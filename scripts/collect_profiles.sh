@@ -16,8 +16,12 @@ ONLY="--no-cpu-baseline --no-extras"
 # 1. the benchmark line as the driver runs it (headline = config 5, config 2 under extra, CPU baseline leg)
 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
 
-# 2. kernel trace + stats of the same command (headline workload only: every k_solve launch is the headline's)
+# 2. kernel trace + stats of the same command (headline workload only: every k_solve launch is the headline's).  Round 5: the
+# default command keeps three batches in flight inside the handle, so the trace's per-kernel durations are those of OVERLAPPING
+# launches (bench.py prints them as in_flight.kernel_ms_of_one_launch_while_overlapped); the second pass runs the same launches
+# one at a time (--in-flight 1: what roofline.in_flight.sequential.kernel_ms of the default line measures)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config5" -- $BENCH $ONLY > "$OUT/stats_config5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config5_seq" -- $BENCH --in-flight 1 $ONLY > "$OUT/stats_config5_seq.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_config2" -- $BENCH --config 2 $ONLY > "$OUT/stats_config2.log" 2>&1
 
 # 3. HBM traffic and SQ counters per workload, one small counter group per pass
@@ -28,25 +32,23 @@ for wl in c5 c3 c2 c2b16k c4 c5alm; do
                "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
         name=$(echo $grp | tr ' ' '+')
         rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_${wl}_$name" -- \
-            $BENCH $(wl_args $wl) --steps 3 --warmup 1 $ONLY > "$OUT/pmc_${wl}_$name.log" 2>&1
+            $BENCH $(wl_args $wl) --in-flight 1 --steps 3 --warmup 1 $ONLY > "$OUT/pmc_${wl}_$name.log" 2>&1
     done
 done
 unset CILQR_BENCH_ALM
 
 # 4. the other BASELINE configurations (one bench line each) and a batch sweep of config 2
 for c in 2 3 4; do
-    $BENCH --config $c --steps 5 --warmup 1 $ONLY > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.err"
+    $BENCH --config $c --in-flight 1 --steps 5 --warmup 1 $ONLY > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.err"
 done
 if [ -z "$QUICK" ]; then
 for b in 512 2048 4096 16384; do
-    $BENCH --config 2 --batch $b --steps 3 --warmup 1 $ONLY > "$OUT/bench_config2_B$b.json" 2>/dev/null
+    $BENCH --config 2 --batch $b --in-flight 1 --steps 3 --warmup 1 $ONLY > "$OUT/bench_config2_B$b.json" 2>/dev/null
 done
-# 4b. four batches in flight (extra.pipelined), config 2
-$BENCH --config 2 --streams 4 --steps 40 --warmup 3 $ONLY > "$OUT/bench_pipelined.json" 2>/dev/null
-# 4c. three batches in flight on the large launches: the next batch fills the tail of the one before
-for c in 5 3 4; do
-    $BENCH --config $c --streams 3 --steps 24 --warmup 2 $ONLY > "$OUT/bench_pipelined_c$c.json" 2>/dev/null
-done
+# 4b. batches in flight inside the handle: 1 .. 4 launch slots on the three large launches
+for c in 5 3 4; do for k in 1 2 3 4; do
+    $BENCH --config $c --in-flight $k --steps 24 --warmup 3 $ONLY > "$OUT/bench_inflight_c${c}_k$k.json" 2>/dev/null
+done; done
 fi
 
 # 5. in-kernel phase accounting.  Configs 3 and 5 run the grouped build (two trajectories per wavefront, two wavefronts per
@@ -85,3 +87,10 @@ for a in "5 c5" "3 c3" "4 c4"; do set -- $a; $ROOT/scripts/stall_counters.sh $TA
 # 10. the N > 1 code path of bench.py rehearsed with two processes on this one GPU (statistics over gloo): not a measurement
 CILQR_BENCH_ONE_DEVICE=1 CILQR_BENCH_BACKEND=gloo $PY -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
     --master-port 29577 $ROOT/bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/two_rank.json" 2> "$OUT/two_rank.err"
+
+# 11. the GPU test suite in both XNACK modes (this pool runs xnack-; HSA_XNACK=1 is the mode in which round 4's lost-store
+# anomaly does not occur) — logs kept under profiles/
+cd "$ROOT"
+timeout 1500 python -m pytest tests -m gpu -q --durations=10 > "$OUT/gpu_tests_xnack_off.log" 2>&1
+HSA_XNACK=1 timeout 1800 python -m pytest tests -m gpu -q --durations=10 > "$OUT/gpu_tests_xnack_on.log" 2>&1
+tail -2 "$OUT/gpu_tests_xnack_off.log" "$OUT/gpu_tests_xnack_on.log"

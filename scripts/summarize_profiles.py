@@ -52,7 +52,7 @@ def counters(pattern):
 bench = last_json(os.path.join(src, "bench.json"))
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
-for c in ("config5", "config2"):
+for c in ("config5", "config5_seq", "config2"):
     stats = glob.glob(os.path.join(src, f"stats_{c}", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_{c}_kernel_stats.csv"))
@@ -107,7 +107,26 @@ for wl in ("c5", "c3", "c2", "c2b16k", "c4", "c5alm"):
 if pmc_all:
     json.dump(pmc_all, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
     if "--current" in sys.argv:
-        json.dump(pmc_all, open(os.path.join(dst, "pmc_current.json"), "w"), indent=1)
+        # what the passes were collected on: bench.py compares the fingerprint of the kernel sources with its own and flags
+        # roofline.traffic_collected.stale when csrc/ has changed since (VERDICT r04 item 8 / task 10)
+        import subprocess
+        sys.path.insert(0, ROOT)
+        import bench as _bench
+        try:
+            rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "toy-example-of-ilqr_amd/csrc", "include"],
+                                        capture_output=True, text=True).stdout.strip())
+        except Exception:
+            rev, dirty = None, None
+        sha = _bench.csrc_fingerprint()
+        stamp = os.path.join(src, "_collected.json")  # written when the collection was LAUNCHED (scripts/r05_collect.sh): the tree may have moved on since
+        if os.path.exists(stamp):
+            st_ = json.load(open(stamp))
+            rev, dirty, sha = st_.get("git", rev), st_.get("csrc_dirty_at_collection", dirty), st_.get("csrc_sha16", sha)
+        cur = dict(pmc_all)
+        cur["_collected"] = {"git": rev, "csrc_dirty_at_collection": dirty, "csrc_sha16": sha, "in_flight": 1,
+                             "tag": tag, "how": "scripts/collect_profiles.sh: one counter group per rocprofv3 pass, launches one at a time"}
+        json.dump(cur, open(os.path.join(dst, "pmc_current.json"), "w"), indent=1)
 
 other = {"note": "python bench.py --config C [--batch B] --steps 3..5 --warmup 1 --no-cpu-baseline --no-extras on one "
                  "MI355X: the other BASELINE configurations and a batch sweep of config 2"}
@@ -121,6 +140,25 @@ for path in sorted(glob.glob(os.path.join(src, "bench_config[2-5]*.json"))):
         "iters_per_solve": round(e["iterations_per_solve_mean"], 2), "converged": e["converged"],
         "max_lamb": e["max_lamb"], "max_iter": e["max_iter"], "hbm_frac": round(b["roofline"]["frac"], 5)}
 json.dump(other, open(os.path.join(dst, f"{tag}_other_configs.json"), "w"), indent=1)
+
+fl = {}
+for c in (5, 3, 4):
+    for k in (1, 2, 3, 4):
+        b_ = last_json(os.path.join(src, f"bench_inflight_c{c}_k{k}.json"))
+        if b_:
+            fl.setdefault(b_["config"]["workload"], {})[f"in_flight_{k}"] = {
+                "value": b_["value"], "ms_per_step": b_["ms_per_step"],
+                "sequential_kernel_ms": (b_["roofline"]["in_flight"].get("sequential") or {}).get("kernel_ms"),
+                "buffer_sets_identical": b_["roofline"]["in_flight"].get("buffer_sets_identical")}
+if fl:
+    json.dump({"command": "python bench.py --config C --in-flight K --steps 24 --warmup 3 --no-cpu-baseline --no-extras",
+               "what": "cilqr_set_batches_in_flight(K): K launch slots inside ONE handle", "workloads": fl},
+              open(os.path.join(dst, f"{tag}_in_flight.json"), "w"), indent=1)
+for mode in ("off", "on"):
+    p_ = os.path.join(src, f"gpu_tests_xnack_{mode}.log")
+    if os.path.exists(p_):
+        tail = open(p_, errors="replace").read().splitlines()[-25:]
+        open(os.path.join(dst, f"{tag}_gpu_tests_xnack_{mode}.txt"), "w").write("\n".join(tail) + "\n")
 
 b = last_json(os.path.join(src, "bench_pipelined.json"))
 if b:

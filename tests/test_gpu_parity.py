@@ -1888,7 +1888,7 @@ def test_lost_rows_shape_is_still_what_loses_rows():
                 env["HSA_XNACK"] = xnack
             if which == "repro":
                 env["CILQR_AMD_LIB"] = lib
-            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "lost_rows_repro.py"), "4"], capture_output=True,
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "lost_rows_repro.py"), "2"], capture_output=True,
                                text=True, timeout=600, env=env)
             if which == "repro" and r.returncode != 0 and "undefined symbol" in r.stderr:
                 pytest.skip("ab/libLR.so is older than the C-ABI (rebuild it with -DCILQR_LOSTROWS_REPRO)")
