@@ -93,4 +93,4 @@ CILQR_BENCH_ONE_DEVICE=1 CILQR_BENCH_BACKEND=gloo $PY -m torch.distributed.run -
 cd "$ROOT"
 timeout 1500 python -m pytest tests -m gpu -q --durations=10 > "$OUT/gpu_tests_xnack_off.log" 2>&1
 HSA_XNACK=1 timeout 1800 python -m pytest tests -m gpu -q --durations=10 > "$OUT/gpu_tests_xnack_on.log" 2>&1
-tail -2 "$OUT/gpu_tests_xnack_off.log" "$OUT/gpu_tests_xnack_on.log"
+tail -n 2 "$OUT/gpu_tests_xnack_off.log"; tail -n 2 "$OUT/gpu_tests_xnack_on.log"
