@@ -738,6 +738,7 @@ def test_work_sharing_between_blocks_is_transparent(pkg, orc_det):
     from oracle import Scene
     wl = pkg.workloads.config4(B=640, N=100)
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    eng.set_group_mode(0)  # (k_solve's two-rows-per-lane builds: by default such a batch now runs two trajectories per wavefront)
     out = {}
     for mode in (1, 0):
         eng.set_work_sharing(mode)
@@ -777,6 +778,7 @@ def test_long_horizon_builds_across_horizons(pkg, orc_det, N, B):
         pytest.skip("obstacle routes shorter than the horizon")
     params = [pkg.copy_params(q, N=N, max_iter=30) for q in wl.params]
     eng = pkg.BatchedCILQR(params, wl.scenes)
+    eng.set_group_mode(0)  # (the lone-wavefront builds; pairs at these horizons: test_two_trajectories_per_wavefront_at_long_horizons)
     rng = np.random.default_rng(N)
     last_u = rng.normal(0.0, 0.05, size=(B, N, 2))
     out = {}
@@ -1398,6 +1400,7 @@ def test_resumable_solves_are_transparent(pkg, orc_det):
     between blocks, every output — decision traces included — is the one of the unsliced solve and of the oracle."""
     wl = pkg.workloads.config4(B=4096)
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    eng.set_group_mode(0)  # (k_solve's builds; the grouped build's sliced solves: test_sliced_solves_of_the_grouped_build)
     ids = (wl.scenario_id, wl.param_id, wl.tick)
     eng.set_resume_iters(0)
     whole = eng.solve_batch(wl.x0, *ids, trace_cap=128)
@@ -1425,6 +1428,7 @@ def test_resumable_solves_are_transparent(pkg, orc_det):
     compare_solves(sub, refs, "resumable (config 4, first rows)")
     # a batch that fits the chip at once has nothing to reorder: its solves run whole
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    eng.set_group_mode(0)
     eng.set_resume_iters(8)
     small = eng.solve_batch(wl.x0[:1800], wl.scenario_id[:1800], wl.param_id[:1800], wl.tick[:1800])
     assert eng.resume_stats() == 0
@@ -1985,3 +1989,99 @@ def test_sweeps_of_two_trajectories_in_one_instruction_stream(pkg, orc_det, scen
             bpf += int((a["trace"]["status"][bb][:a["res"]["trace_len"][bb]] == 2).sum())
     monkeypatch.delenv("CILQR_TUNE", raising=False)
     assert bpf > 0, "no backward pass failed: the second pass of a turn was not exercised"
+
+
+@pytest.mark.parametrize("N,B", [(64, 203), (76, 150), (100, 301), (127, 97)])
+def test_two_trajectories_per_wavefront_at_long_horizons(pkg, orc_det, N, B, monkeypatch):
+    """Round 5: the grouped kernel's LONG layout — horizons of 64 ... 127, two rows per lane: both trajectories' expansions
+    and Jacobians stream from rows in global memory through one ring per half of the wavefront (backward_sweep_pair<BOTH>),
+    the gains reach the rollout pass through a ring of two eight-step chunks (rollout_group_long), shadow lanes store out
+    of range.  Against k_solve's lone-wavefront builds (CILQR_TUNE=group_long=0) on every trajectory — outputs, results and
+    the whole decision trace — and against the oracle on a sample; cold and warm starts; mixed scenarios (config 4's four,
+    one of them with the rear-axle model), two parameter sets per scenario with different dt, a negative control weight on
+    some rows (non-PD Q_uu: one half of a sweep fails while the other goes on), odd batches (a trajectory that sweeps alone)."""
+    from oracle import Scene
+    wl = pkg.workloads.config4(B=B, N=N)
+    for s in wl.scenes:
+        if s.obs.shape[1] < N + 1:
+            pytest.skip("obstacle routes shorter than the horizon")
+    params = []
+    for q in wl.params:
+        params.append(pkg.copy_params(q, max_iter=25))
+        params.append(pkg.copy_params(q, max_iter=25, dt=0.08))
+    params.append(pkg.copy_params(wl.params[0], max_iter=25, w_acc=-40.0))
+    sid = wl.scenario_id
+    pid = (2 * sid + (np.arange(B) // 4) % 2).astype(np.int32)
+    pid[np.arange(B) % 13 == 5] = len(params) - 1
+    rng = np.random.default_rng(N)
+    last_u = rng.normal(0.0, 0.05, size=(B, N, 2))
+    outs = {}
+    for tune in ("group=2", "group=2,group_long=0"):
+        monkeypatch.setenv("CILQR_TUNE", tune)
+        eng = pkg.BatchedCILQR(params, wl.scenes, dev=True)
+        outs[tune] = (eng.solve_batch(wl.x0, sid, pid, wl.tick, trace_cap=64),
+                      eng.solve_batch(wl.x0, sid, pid, wl.tick, last_u=last_u, trace_cap=64))
+        info = eng.last_launch_info()
+        assert info["trajectories_per_wavefront"] == (2 if tune == "group=2" else 1), info
+        eng.close()
+    monkeypatch.delenv("CILQR_TUNE", raising=False)
+    bpf = 0
+    for k, what in ((0, "cold"), (1, "warm")):
+        a, b = outs["group=2"][k], outs["group=2,group_long=0"][k]
+        eq_bits(a["u"], b["u"], f"N={N} {what} u")
+        eq_bits(a["x"], b["x"], f"N={N} {what} x")
+        assert (a["res"] == b["res"]).all(), (N, what)
+        for f in ("status", "trials", "accepted", "alpha_idx", "lamb", "new_J"):
+            eq_bits(a["trace"][f], b["trace"][f], f"N={N} {what} trace.{f}")
+        for bb in range(B):
+            bpf += int((a["trace"]["status"][bb][:a["res"]["trace_len"][bb]] == 2).sum())
+    assert bpf > 0, "no backward pass failed"
+    a = outs["group=2"][0]
+    for bb in range(0, B, 9):
+        s0 = wl.scenes[sid[bb]]
+        scene = Scene(s0.lane_x, s0.lane_y, s0.lane_yaw, s0.obs, s0.road_borders, s0.ref_velo)
+        r = orc_det.solver(params[pid[bb]]).solve(wl.x0[bb], scene)
+        eq_bits(a["u"][bb], r["u"], f"N={N} u[{bb}] vs oracle")
+        eq_bits(a["x"][bb], r["x"], f"N={N} x[{bb}] vs oracle")
+        assert a["res"]["iters"][bb] == r["res"]["iters"]
+        assert a["res"]["J_final"][bb] == r["res"]["J_final"] or (np.isnan(a["res"]["J_final"][bb]) and np.isnan(r["res"]["J_final"]))
+
+
+@pytest.mark.parametrize("cfg", ["3", "4"])
+def test_sliced_solves_of_the_grouped_build(pkg, orc_det, cfg):
+    """Round 5: the launches that run two trajectories per wavefront slice their solves (cilqr_set_resume_iters; automatic:
+    16 / 12 iterations) once the last round of fresh trajectories is being handed out: at the end of a slice a trajectory is
+    parked and queued, the slot takes the next one; places in the queue are CLAIMED (fetch-and-add), a slot whose place has no
+    entry yet looks again every turn.  Whatever the slice length — 1 iteration (every trajectory changes slots after every
+    iteration once the final round has begun), 5, the automatic one, none — every output and the whole decision trace are the
+    ones of the unsliced launch, of lone wavefronts (group mode 0) and, on a sample, of the oracle; no wait expired."""
+    wl = pkg.workloads.config3(B=5000) if cfg == "3" else pkg.workloads.config4(B=4600)
+    ids = (wl.scenario_id, wl.param_id, wl.tick)
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes)
+    eng.set_resume_iters(0)
+    whole = eng.solve_batch(wl.x0, *ids, trace_cap=128)
+    assert eng.last_launch_info()["trajectories_per_wavefront"] == 2
+    for iters in (1, 5, -1):
+        eng.set_resume_iters(iters)
+        out = eng.solve_batch(wl.x0, *ids, trace_cap=128)
+        parked = eng.resume_stats()
+        st = eng.work_sharing_stats()
+        assert st["error"] == 0, (iters, st)
+        for k in ("u", "x"):
+            eq_bits(whole[k], out[k], f"config {cfg}: {k} with {iters} iterations per slice")
+        assert (whole["res"] == out["res"]).all() and (whole["trace"] == out["trace"]).all(), (cfg, iters)
+        assert parked > (2000 if iters == 1 else 100), (cfg, iters, parked)
+    eng.set_group_mode(0)
+    eng.set_resume_iters(-1)
+    lone = eng.solve_batch(wl.x0, *ids, trace_cap=128)
+    eng.close()
+    for k in ("u", "x"):
+        eq_bits(whole[k], lone[k], f"config {cfg}: {k} against lone wavefronts")
+    assert (whole["res"] == lone["res"]).all() and (whole["trace"] == lone["trace"]).all()
+    scenes = [oracle_scene_tab(t) for t in wl.scenes]
+    rows = np.r_[0:16, 1402, 4081]
+    sid = wl.scenario_id if wl.scenario_id is not None else np.zeros(wl.B, np.int32)
+    pid = wl.param_id if wl.param_id is not None else np.zeros(wl.B, np.int32)
+    refs = [orc_det.solver(wl.params[pid[b]]).solve(wl.x0[b], scenes[sid[b]], trace_cap=128) for b in rows]
+    sub = {k: whole[k][rows] for k in ("u", "x", "res", "trace")}
+    compare_solves(sub, refs, f"sliced solves (config {cfg}, sample)")

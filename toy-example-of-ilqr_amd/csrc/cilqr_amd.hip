@@ -27,6 +27,8 @@ extern template __global__ void k_solve_grp<0, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<50, 2, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<30, 2, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -375,7 +377,7 @@ struct cilqr_handle {
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
     // resumable solves (k_solve's RES: the two-row builds in persistent launches): iterations per slice, 0 = off.  A
     // launch whose batch fits the chip at once (no second round of trajectories) has nothing to reorder and runs whole.
-    int resume_iters = 32;
+    int resume_iters = -1;     // -1 = automatic: 32 (k_solve), group_slice / group_slice_long (the grouped build's sliced solves)
     unsigned last_parked = 0;
     bool fused_call = false;   // the call in progress is a fused solve (not a piecewise entry point)
     bool looping = false;      // the call in progress is a closed loop in one launch: the plain builds (see the dispatch)
@@ -394,6 +396,11 @@ struct cilqr_handle {
     int poison_scratch = 0;    // development library: fill the kernels' scratch before every launch (CILQR_TUNE=poison=1: NaN
                                // patterns, 2: zeros) — results must not depend on what the scratch held
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
+    int group_long = 1;        // ... horizons of 64 ... 127 run the grouped build too (its long layout; CILQR_TUNE=group_long=0: k_solve's
+                               // two-rows-per-lane builds)
+    int group_slice = 16;      // ... solves run this many iterations at a time while other trajectories wait (0: to their end in one go)
+    int group_slice_long = 12; // ... the same for the long layout
+    int group_slice_window_pct = 100; // ... hand-overs at the end of a slice begin when fewer fresh trajectories are left than this share of the resident slots
     int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
     int prof_B = 0;
     DevBuf st[16];
@@ -467,6 +474,13 @@ static void update_window(cilqr_handle* h) {
         int wg = (int)(room / 16) / 8 * 8;
         wg = std::max(wg, grp_expansion_doubles(N) / 2 / 8 * 8);
         h->win_grp = std::max(8, std::min(want, wg));
+        if (N + 1 > CILQR_WAVE) {
+            // the long layout (two rows per lane): the window sits behind the stage-cost scratch; the largest that keeps 8
+            // wavefronts on a CU, as long as it is comfortable — else 7, 6, ...
+            fixed = grpl_lds_bytes(N, 0, grp_n(h)) - sizeof(double) * (size_t)grpl_shared_doubles(N, 0, grp_n(h)) +
+                    sizeof(double) * (size_t)grpl_cs_doubles(N);
+            h->win_grp = std::max(8, pick(occ_floor));
+        }
     }
 }
 
@@ -578,6 +592,10 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "group_steal") h->group_steal = v;
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
                 else if (k == "pair_sweep") h->group_pair_sweep = v;
+                else if (k == "group_long") h->group_long = v;
+                else if (k == "group_slice") h->group_slice = v;
+                else if (k == "group_slice_long") h->group_slice_long = v;
+                else if (k == "group_slice_window") h->group_slice_window_pct = v;
                 else if (k == "group_loop") h->group_loop = v;
                 else if (k == "poison") h->poison_scratch = v;
                 else known = false;
@@ -730,7 +748,7 @@ extern "C" int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode) {
 
 extern "C" int cilqr_set_resume_iters(cilqr_handle* h, int32_t iters) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
-    if (iters < 0 || iters > 100000) return fail(CILQR_ERR_BAD_ARG, "iterations per slice must be in [0, 100000]");
+    if (iters < -1 || iters > 100000) return fail(CILQR_ERR_BAD_ARG, "iterations per slice must be in [0, 100000] (or -1: automatic)");
     h->resume_iters = iters;
     return CILQR_OK;
 }
@@ -1094,13 +1112,15 @@ static bool single_slot(const cilqr_handle* h, int B) {
 
 // does this batch run a build that keeps the cost expansion in global memory (k_solve's LG)?
 static bool global_expansion(const cilqr_handle* h, int B) {
-    if (!single_slot(h, B) || h->global_expansion == 0 || h->looping) return false;
+    if (!single_slot(h, B) || h->looping) return false;
+    if (h->global_expansion == 0 && h->params[0].solve_type == 1) return false; // (the switch still means something under ALM only)
     const int N = h->params[0].N;
     const int alm = h->params[0].solve_type == 1 ? 1 : 0;
     if (N + 1 <= CILQR_WAVE) return false; // (builds exist for two rows per lane only; shorter horizons fit anyway)
     // worth it where the LDS block with the expansion inside keeps a CU from holding the 8 wavefronts its registers
     // allow (barrier mode: N >= 76; augmented Lagrangian, whose dense l_xx makes the block larger: every horizon
     // above 63): measured +30-40 % at N = 100, +6 % at N = 80, -5 % at N = 64 (barrier) where nothing is gained
+    if (!alm) return true; // (round 5: the one lone two-row barrier build the library carries)
     return h->global_expansion == 1 || lds_bytes(N, 64, alm, 1, 0) * 8 > 163840;
 }
 
@@ -1108,7 +1128,8 @@ static bool global_expansion(const cilqr_handle* h, int B) {
 // Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
 static bool grouped(const cilqr_handle* h, int B) {
     if (h->group_mode == 0 || h->group_mode == 1) return false;
-    if (h->params[0].solve_type == 1 || two_rows(h) || h->debug_flags != 0) return false;
+    if (h->params[0].solve_type == 1 || h->debug_flags != 0) return false;
+    if (two_rows(h) && (!h->group_long || h->looping)) return false; // (the long layout has no closed-loop build)
     if (h->looping && (!h->group_loop || h->profiling)) return false; // (closed loop in one launch: the LOOP builds of k_solve_grp)
     if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
     if (!h->persistent_blocks) return false;
@@ -1157,6 +1178,7 @@ static BatchArgs make_args(cilqr_handle* h, int B, const Staged& ids) {
     a.ctl = static_cast<unsigned*>(SL(h).sh_ctl.p);
     a.rq_cap = 0;
     a.res_iters = 0;
+    a.res_window = 0;
     a.loop_ticks = 0;
     a.loop_x0 = nullptr;
     a.loop_tick = nullptr;
@@ -1241,26 +1263,30 @@ static int ensure_scratch(cilqr_handle* h, int B, bool fused = false) {
     }
     // resumable solves: only the launches that can park — two rows per lane, barrier mode, persistent blocks (lone
     // wavefronts two per SIMD, no closed loop), more trajectories than resident blocks
-    const bool can_park = fused && two_rows(h) && h->resume_iters > 0 && h->params[0].solve_type == 0 && !h->looping &&
+    const bool can_park = fused && two_rows(h) && h->resume_iters != 0 && h->params[0].solve_type == 0 && !h->looping &&
                           h->persistent_blocks && lone_two_per_simd(h, B) && h->debug_flags == 0 && !h->profiling &&
                           (size_t)B > (size_t)h->num_cus; // (more than one round of resident blocks is possible)
-    if (can_park && (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p)) {
+    // (one buffer serves both kinds of parked state — k_solve's resumable solves and the grouped build's hand-overs — sized for
+    //  the larger record: a handle may switch between the two kernels from call to call)
+    const size_t park_need = sizeof(double) * std::max(park_doubles(N), grp_park_doubles(N)) * (size_t)B;
+    if (can_park && (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p || SL(h).park.cap < park_need)) {
         int rcw = wait_slot(h, h->cur); // (this handle's previous launch may be using the old arrays)
         if (rcw) return rcw;
         SL(h).park.release(); SL(h).rq.release();
-        if (SL(h).park.ensure(sizeof(double) * park_doubles(N) * (size_t)B) || SL(h).rq.ensure(sizeof(unsigned long long) * (size_t)B))
+        if (SL(h).park.ensure(park_need) || SL(h).rq.ensure(sizeof(unsigned long long) * (size_t)B))
             return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
         SL(h).park_B = B;
         SL(h).park_N = N;
     }
     // the grouped build hands trajectories from wavefronts that hold two to wavefronts that have run dry (cilqr_group.hpp)
     if (fused && grouped(h, B) && h->group_steal) {
-        const size_t need = sizeof(double) * grp_park_doubles(N) * (size_t)B;
-        if (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p || SL(h).park.cap < need || SL(h).rq.cap < sizeof(unsigned long long) * (size_t)B) {
+        const size_t need = park_need;
+        const size_t rq_need = sizeof(unsigned long long) * (size_t)B * CILQR_GRP_Q_PER_TRAJECTORY; // (not reused within a launch)
+        if (B > SL(h).park_B || N != SL(h).park_N || !SL(h).park.p || SL(h).park.cap < need || SL(h).rq.cap < rq_need) {
             int rcw = wait_slot(h, h->cur);
             if (rcw) return rcw;
             SL(h).park.release(); SL(h).rq.release();
-            if (SL(h).park.ensure(need) || SL(h).rq.ensure(sizeof(unsigned long long) * (size_t)B))
+            if (SL(h).park.ensure(need) || SL(h).rq.ensure(rq_need))
                 return fail(CILQR_ERR_DEVICE, "hipMalloc parked-solve state");
             SL(h).park_B = B;
             SL(h).park_N = N;
@@ -1403,7 +1429,9 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         // compile-time horizons: BASELINE's 50 and the 30 of the reference's own YAMLs (config/scenario_*.yaml:5)
         auto kg = (a.N == 50) ? k_solve_grp<50, 2> : (a.N == 30 ? k_solve_grp<30, 2> : k_solve_grp<0, 2>);
         if (loop.ticks >= 1) kg = (a.N == 50) ? k_solve_grp<50, 2, true> : (a.N == 30 ? k_solve_grp<30, 2, true> : k_solve_grp<0, 2, true>);
-        const size_t shm = grp_lds_bytes(a.N, a.W, G);
+        const bool longl = a.N + 1 > CILQR_WAVE; // two rows per lane: the long layout
+        if (longl) kg = (a.N == 100) ? k_solve_grp<100, 2, false, 2> : k_solve_grp<0, 2, false, 2>;
+        const size_t shm = longl ? grpl_lds_bytes(a.N, a.W, G) : grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
         if (rc) return rc;
@@ -1413,11 +1441,14 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         a.next = static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_NEXT;
         HIP_TRY(hipMemsetAsync(SL(h).sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
         h->last_launch_reset_ctl = true;
-        if (h->group_steal && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N) {
+        if (h->group_steal && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N &&
+            SL(h).rq.cap >= sizeof(unsigned long long) * (size_t)B * CILQR_GRP_Q_PER_TRAJECTORY) {
             a.park = static_cast<double*>(SL(h).park.p);
             a.rq = static_cast<unsigned long long*>(SL(h).rq.p);
-            HIP_TRY(hipMemsetAsync(SL(h).rq.p, 0, sizeof(unsigned long long) * (size_t)SL(h).park_B, s));
-            a.rq_cap = SL(h).park_B;
+            a.rq_cap = (int)std::min<size_t>(0x7fffffff, (size_t)B * CILQR_GRP_Q_PER_TRAJECTORY);
+            HIP_TRY(hipMemsetAsync(SL(h).rq.p, 0, sizeof(unsigned long long) * (size_t)a.rq_cap, s));
+            a.res_iters = (loop.ticks >= 1) ? 0 : (h->resume_iters >= 0 ? h->resume_iters : (longl ? h->group_slice_long : h->group_slice));
+            a.res_window = (int)std::min<long long>(0x7fffffffLL, (long long)grid * G * h->group_slice_window_pct / 100);
             h->last_launch_shared = true; // (the host-buffer entry point then checks the launch's error word: a bounded wait that expired)
         }
         if (SL(h).scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
@@ -1485,10 +1516,10 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             // (two rows per lane: built with work sharing between blocks, which a.sh_ctl switches on.  Shorter horizons
             //  are not: a trial costs 5 us there, the hand-over of a search about 10, and the build costs the solve loop
             //  3 % in spilled registers — measured: config 5 -5 %, config 3 -33 % with it, config 4 +25 %)
-            kern = two ? k_solve<false, 2, false, false, false, 2, 1, 0, false, true, true> : k_solve<false, 1, false, false, false, 2, 1>;
-            if (global_expansion(h, B)) {
+            kern = k_solve<false, 1, false, false, false, 2, 1>;
+            if (two) {
+                if (!global_expansion(h, B)) return fail(CILQR_ERR_DEVICE, "internal: no build for this launch shape");
                 kern = k_solve<false, 2, false, false, false, 2, 1, 0, true, true, true>;
-                if (a.N == 100) kern = k_solve<false, 2, false, false, false, 2, 1, 100, true, true, true>;
                 lg = true;
             }
             one = true;
@@ -1518,12 +1549,12 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
             h->last_launch_reset_ctl = true;
             // resumable solves: the builds that carry them (two rows per lane, persistent), batches that take more than
             // one round of the resident blocks
-            if (two && !a.alm && loop.ticks < 1 && h->resume_iters > 0 && B > grid && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N) {
+            if (two && !a.alm && loop.ticks < 1 && h->resume_iters != 0 && B > grid && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N) {
                 a.park = static_cast<double*>(SL(h).park.p);
                 a.rq = static_cast<unsigned long long*>(SL(h).rq.p);
                 HIP_TRY(hipMemsetAsync(SL(h).rq.p, 0, sizeof(unsigned long long) * (size_t)SL(h).park_B, s));
                 a.rq_cap = SL(h).park_B;
-                a.res_iters = h->resume_iters;
+                a.res_iters = h->resume_iters < 0 ? 32 : h->resume_iters;
             }
         } else {
             a.sh_ctl = nullptr; // (the work sharing rides on the persistent blocks)

@@ -1501,6 +1501,29 @@ __device__ inline int rq_pop(unsigned* ctl, const unsigned long long* q, unsigne
     }
     return __builtin_amdgcn_readfirstlane(b);
 }
+// The same queue taken from by CLAIM instead of compare-and-swap (the grouped build's sliced solves, cilqr_group.hpp): a taker
+// reserves the next position with one fetch-and-add on SH_Q_HEAD and then owns it — it reads the entry when the push that
+// was (or will be) given that number has stored it.  No retry loops: when thousands of slots reach the end of a slice within the
+// same microseconds, compare-and-swap lets one of them through per round trip to memory (measured: 3 us per hand-over,
+// config 3 three times as long), fetch-and-adds pipeline.  A claim beyond the pushes so far is a place in line for the next push.
+__device__ inline bool rq_avail(const unsigned* ctl, int lane) { // pushes not yet claimed?
+    int d = 0;
+    if (lane == 0) d = ((int)(sh_ld(ctl + SH_Q_RESV) - sh_ld(ctl + SH_Q_HEAD)) > 0) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(d) != 0;
+}
+__device__ inline unsigned rq_claim(unsigned* ctl, int lane) {
+    unsigned h = 0;
+    if (lane == 0) h = __hip_atomic_fetch_add(ctl + SH_Q_HEAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+}
+__device__ inline int rq_poll(const unsigned long long* q, unsigned cap, unsigned h, int lane) { // the trajectory at position h, or -1: not there yet
+    int b = -1;
+    if (lane == 0) {
+        const unsigned long long e = sh_ld64(q + (h % cap));
+        if ((unsigned)(e >> 32) == h + 1u) b = (int)(unsigned)(e & 0xffffffffULL);
+    }
+    return __builtin_amdgcn_readfirstlane(b);
+}
 __device__ inline bool rq_nonempty(const unsigned* ctl, const unsigned long long* q, unsigned cap, int lane) {
     int d = 0;
     if (lane == 0) {

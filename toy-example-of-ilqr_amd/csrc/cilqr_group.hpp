@@ -38,6 +38,7 @@ namespace cilqr {
 #endif
 
 enum { GP_EMPTY = 0, GP_ITER = 1, GP_SEARCH = 2, GP_DONE = 3, GP_STOLEN = 4 /* b names a parked trajectory to take over */,
+       GP_CLAIMED = 7 /* pad2 = the slot's place in the queue of parked trajectories (rq_claim): its entry is awaited */,
        GP_EXPAND = 5 /* at the head of an iteration: its expansion and sweep run after every trajectory's segment (grp_expand, grp_sweep) */,
        GP_BPF = 6 /* that sweep met a non-PD Q_uu: back in solve with BACKWARD_PASS_FAIL */ };
 
@@ -84,6 +85,31 @@ __host__ __device__ inline size_t grp_rows_offset(int N) {
 }
 __host__ __device__ inline size_t grp_scratch_doubles(int N) {
     return grp_rows_offset(N) + (size_t)CILQR_GRP_ROW * (size_t)(N + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: two trajectories per wavefront for horizons of 64 ... 127 as well (two rows per lane) — the LONG layout.
+// At N = 100 what persists per trajectory is 6.6 KB; a second copy of k_solve's 8 KB Jacobian / gain array and a 12 KB expansion
+// would leave a CU three or four wavefronts.  So nothing of a horizon's length lives in the shared area any more:
+//   * BOTH expansions (and Jacobians) go to their 256-byte rows in global memory (grp_expand<STREAM>) and the sweep streams
+//     both halves through a ring each (backward_sweep_pair<BOTH>); a trajectory that sweeps alone runs the same code on both halves;
+//   * the gains stay in global memory and reach the rollout pass through a ring of two chunks of CILQR_GRPL_CHUNK steps
+//     (rollout_group_long), refilled by all 64 lanes one chunk ahead;
+//   * trial costs run one at a time (one stage-cost slot, two rows per lane).
+// Shared area = max(stage-cost scratch + lane window | the sweep's constants + two rings | the gains ring): 20 KB a wavefront
+// at N = 100 with a window of 304 samples — eight wavefronts = sixteen trajectories per CU (k_solve's build: eight).
+#define CILQR_GRPL_CHUNK 8
+#define CILQR_GRPL_CHUNK_BYTES (CILQR_GRPL_CHUNK * CILQR_KD * 8)
+__host__ __device__ inline int grpl_cs_doubles(int N) { return (3 * (N + 1) + 1) & ~1; }
+__host__ __device__ inline int grpl_gring_doubles(int G) { return 2 * G * CILQR_GRPL_CHUNK * CILQR_KD; }
+__host__ __device__ inline int grpl_shared_doubles(int N, int W, int G) {
+    int s = grpl_cs_doubles(N) + 2 * W;
+    const int sweep = CILQR_XCH + 2 * CILQR_GL_RING, roll = grpl_gring_doubles(G);
+    s = s > sweep ? s : sweep;
+    return s > roll ? s : roll;
+}
+__host__ __device__ inline size_t grpl_lds_bytes(int N, int W, int G) {
+    return sizeof(double) * ((size_t)G * grp_pg_doubles(N) + (size_t)grpl_shared_doubles(N, W, G));
 }
 
 typedef double __attribute__((ext_vector_type(2))) f64x2;
@@ -146,25 +172,78 @@ __device__ __attribute__((noinline)) void grp_park_copy(double* pk, double* lx, 
     wave_sync();
 }
 
-// An idle wavefront: leave a ticket, wait for a parked trajectory.  Returns its number, or -1 when the launch is over (every
-// trajectory finished), too many are waiting already, or the bound on the wait is reached.
-__device__ __attribute__((noinline)) int grp_wait_for_work(unsigned* ctl, const unsigned long long* q, unsigned cap, unsigned B, int lane) {
+// An idle wavefront: leave a ticket, take a place in the queue (rq_claim: the next push that has no taker is this wavefront's)
+// and wait for it.  claim >= 0: a place one of its slots holds already — no new ticket.  Returns the trajectory, or -1 when the
+// launch is over (every trajectory finished), too many are waiting already, or the bound on the wait is reached (flagged:
+// the push that comes for an abandoned place would be lost).
+__device__ __attribute__((noinline)) int grp_wait_for_work(unsigned* ctl, const unsigned long long* q, unsigned cap, unsigned B, int lane,
+                                                           long long claim = -1) {
     if (sh_ld_u(ctl + SH_FINISHED, lane) >= B) return -1;
-    if (sh_ld_u(ctl + SH_HELPING, lane) >= (unsigned)CILQR_GRP_MAX_WAITING) return -1; // (a look first)
-    if (sh_add_u(ctl + SH_HELPING, 1u, lane) >= (unsigned)CILQR_GRP_MAX_WAITING) {
-        (void)sh_add_u(ctl + SH_HELPING, 0u - 1u, lane);
-        return -1;
+    unsigned h;
+    if (claim < 0) {
+        if (sh_ld_u(ctl + SH_HELPING, lane) >= (unsigned)CILQR_GRP_MAX_WAITING) return -1; // (a look first)
+        if (sh_add_u(ctl + SH_HELPING, 1u, lane) >= (unsigned)CILQR_GRP_MAX_WAITING) {
+            (void)sh_add_u(ctl + SH_HELPING, 0u - 1u, lane);
+            return -1;
+        }
+        (void)sh_add_u(ctl + SH_HELPERS, 1u, lane);
+        h = rq_claim(ctl, lane);
+    } else {
+        // (a wavefront that holds a place never leaves before the launch is over: the push that comes for it would be lost)
+        h = (unsigned)claim;
+        (void)sh_add_u(ctl + SH_HELPING, 1u, lane);
+        (void)sh_add_u(ctl + SH_HELPERS, 1u, lane);
     }
-    (void)sh_add_u(ctl + SH_HELPERS, 1u, lane);
     for (int spin = 0; spin < (1 << 20); ++spin) { // (a launch lasts milliseconds; this bound is seconds)
-        const int pb = rq_pop(ctl, q, cap, lane);
-        if (pb >= 0) return pb; // (the ticket was taken by whoever parked it)
+        const int pb = rq_poll(q, cap, h, lane);
+        if (pb >= 0) return pb;
         if (sh_ld_u(ctl + SH_FINISHED, lane) >= B) return -1;
         __builtin_amdgcn_s_sleep(127);
     }
     if (lane == 0) sh_st(ctl + SH_ERROR, 1u);
     return -1;
 }
+// Sliced solves (round 5; k_solve's resumable solves are the model, cilqr_device.hpp): a solve runs `res_iters` iterations at a
+// time.  At the end of a slice the trajectory is parked and queued — and the slot takes the next one — when somebody else is
+// in need of the slot: parked trajectories wait, or the LAST fresh trajectories are about to be handed out (fewer than
+// `window` left: the launch's final round — before that a fresh trajectory finds a slot soon enough anyway and the hand-over,
+// 2.9 KB out and in again plus the set-up of a segment, would be paid by every long solve of a large batch for nothing).
+// Once the counter is dry every slot that falls empty takes a parked trajectory, so the long solves of the final round
+// advance side by side, a slice at a time, instead of finishing one by one on an emptying chip.
+// The queue of the grouped build is NOT reused within a launch (CILQR_GRP_Q_PER_TRAJECTORY entries per trajectory, position =
+// push number): a place that was claimed is read whenever its owner next looks, and a ring that wrapped could have been
+// overwritten by then (found with slices of ONE iteration: 100 pushes per trajectory, the push cap positions later landed
+// before a slot's once-a-turn look; the trajectory was lost and the launch flagged).  Hand-overs of either kind simply stop
+// when the room is used up (grp_queue_room; two batches' worth of margin for pushes that have looked already): solves then
+// run on where they are.
+#define CILQR_GRP_Q_PER_TRAJECTORY 16
+__device__ inline bool grp_queue_room(const unsigned* ctl, unsigned B, unsigned cap, int lane) {
+    return sh_ld_u(ctl + SH_Q_RESV, lane) + 2u * B < cap;
+}
+__device__ __attribute__((noinline)) bool grp_slot_wanted(const unsigned* next, unsigned B, unsigned window, int fresh_left,
+                                                          const unsigned* ctl, const unsigned long long* q, unsigned cap, int lane) {
+    if (!grp_queue_room(ctl, B, cap, lane)) return false;
+    if (fresh_left) {
+        const unsigned nx = sh_ld_u(next, lane);
+        if (nx < B && B - nx <= window) return true;
+    }
+    return rq_avail(ctl, lane);
+}
+// A slot in need of work: a parked trajectory (>= 0); -1: none is queued; -2: the place taken (*claim) has no entry yet — it was
+// claimed by a faster slot in between, or its push is still on the way: the slot keeps the place (GP_CLAIMED) and looks again
+// every turn.
+__device__ __attribute__((noinline)) int grp_take_parked(unsigned* ctl, const unsigned long long* q, unsigned cap, int lane, int* claim) {
+    if (!rq_avail(ctl, lane)) return -1;
+    const unsigned h = rq_claim(ctl, lane);
+    for (int t = 0; t < 4; ++t) {
+        const int pb = rq_poll(q, cap, h, lane);
+        if (pb >= 0) return pb;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *claim = (int)h;
+    return -2;
+}
+
 // a wavefront with two trajectories: is somebody waiting?  Takes the ticket if so.
 __device__ inline bool grp_take_ticket(unsigned* ctl, int lane) {
     for (int tries = 0; tries < 4; ++tries) {
@@ -203,6 +282,35 @@ __device__ inline void carve_group(Lds& l, double* base, int N, int G, int g) {
     l.W = 0;
 }
 
+__device__ inline void carve_group_long(Lds& l, double* base, int N, int G, int g) {
+    double* p = base + (size_t)g * grp_pg_doubles(N);
+    l.x = p; p += 4 * (N + 1);
+    l.u = p; p += 2 * N;
+    l.ridx = reinterpret_cast<int*>(p);
+    l.tidx = l.ridx + (N + 2);
+    p += grp_idx_doubles(N);
+    l.ck = reinterpret_cast<CstK*>(p);
+    double* s = base + (size_t)G * grp_pg_doubles(N);
+    l.kd = s; // (only as the stage-cost scratch: Jacobians and gains live in global memory)
+    l.cs = s;
+    l.lxs = 7;
+    l.lx = l.lu = l.lxx = l.luu = nullptr;
+    l.xch = s;                // during a sweep
+    l.ring = s + CILQR_XCH;   // ... two rings, one per half of the wavefront
+    l.win = s + grpl_cs_doubles(N);
+    l.gl = nullptr;
+    l.ctld = nullptr;
+    l.ctli = nullptr;
+    l.prof = nullptr;
+    l.w0 = 0;
+    l.W = 0;
+}
+template <bool LONG>
+__device__ inline void carve_group_t(Lds& l, double* base, int N, int G, int g) {
+    if (LONG) carve_group_long(l, base, N, G, g);
+    else carve_group(l, base, N, G, g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Round 5: the backward sweeps (cs:383-440) of BOTH trajectories of a wavefront in ONE instruction stream.
 //
@@ -233,7 +341,12 @@ struct PairArgs {
     const double* rowsB; // [(N + 1)][CILQR_GRP_ROW] in global memory
     double* ringB;       // [CILQR_GL_RING] in LDS
     unsigned goffA, goffB;
+    // BOTH (the long layout): trajectory A streams too — byte offsets of the two trajectories' rows in the block's scratch
+    // area (read through the one descriptor over it) and A's ring
+    unsigned roffA, roffB;
+    double* ringA;
 };
+template <bool BOTH = false>
 __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairArgs& pa, double* scr_blk, unsigned scr_bytes, int lane,
                                                double dVA[2], double dVB[2]) {
     const int h = lane >> 5, q = lane & 31, r = q >> 3, cg = q & 7, hb = lane & 32;
@@ -258,11 +371,11 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
     // ten coefficient addresses (LDS bytes) at step N - 1, their per-step decrements, and what a ring address gets back
     // every fourth step; a[0..3] = M[k][R1], a[4..7] = M[k][C2], a[8] = L[R2][C2], a[9] = l[R1]
     unsigned a[10], d[10], w[10];
-    const unsigned ring0 = lds_addr(pa.ringB);
+    const unsigned ring0 = lds_addr((BOTH && h == 0) ? pa.ringA : pa.ringB);
     constexpr unsigned ROWB = CILQR_GRP_ROW * 8u;
     auto place = [&](int j, int off, int stride, int slotB) {
         // off / stride: doubles relative to lA.x (half 0); slotB: slot in trajectory B's row, -1 = a constant (off applies)
-        if (h == 0 || slotB < 0) {
+        if ((!BOTH && h == 0) || slotB < 0) {
             int o = off;
             if (h == 1 && off == CCo + 2) o = CCo + 3; // (B's own dt)
             const int st = (h == 0) ? stride : 0;
@@ -297,13 +410,13 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
             if (lo == 1 && hi == 3) e = 4;
             if (lo == 3 && hi == 3) e = 5;
             if (lo == 2 && hi == 2) e = 6;
-            if (e >= 0) { off = (int)(lA.lxx - lA.x) + e; stride = 7; slotq = (e < 6) ? CILQR_GL_LXX + e : CILQR_GL_LXX22; }
+            if (e >= 0) { off = BOTH ? 0 : (int)(lA.lxx - lA.x) + e; stride = 7; slotq = (e < 6) ? CILQR_GL_LXX + e : CILQR_GL_LXX22; }
         } else if (diag) {
-            off = (int)(lA.luu - lA.x) + (R2 - 4); stride = 2; slotq = CILQR_GL_LUU + (R2 - 4);
+            off = BOTH ? 0 : (int)(lA.luu - lA.x) + (R2 - 4); stride = 2; slotq = CILQR_GL_LUU + (R2 - 4);
         }
         place(8, off, stride, slotq);
-        if (R1 < 4) { off = (int)(lA.lx - lA.x) + R1; stride = 4; slotv = CILQR_GL_LX + R1; }
-        else { off = (int)(lA.lu - lA.x) + (R1 - 4); stride = 2; slotv = CILQR_GL_LU + (R1 - 4); }
+        if (R1 < 4) { off = BOTH ? 0 : (int)(lA.lx - lA.x) + R1; stride = 4; slotv = CILQR_GL_LX + R1; }
+        else { off = BOTH ? 0 : (int)(lA.lu - lA.x) + (R1 - 4); stride = 2; slotv = CILQR_GL_LU + (R1 - 4); }
         place(9, off, stride, slotv);
     }
     // cross-lane sources (ds_bpermute byte addresses)
@@ -332,17 +445,28 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(const_cast<double*>(pa.rowsB)), 0,
                                                                           (N + 1) * (int)ROWB, 0x00020000);
     constexpr int CHB = 2 * (int)ROWB; // bytes per chunk
-    double chunk = 0.0;
+    double chunk = 0.0, chunkA = 0.0;
+    const unsigned laneA = pa.roffA + 8u * (unsigned)lane, laneB = pa.roffB + 8u * (unsigned)lane; // (BOTH: through gr)
     {
         const int c0 = (N - 1) / 2;
-        const double first = gl_load(grs, 8u * (unsigned)lane, c0 * CHB);
-        pa.ringB[(c0 & 1) * CILQR_WAVE + lane] = first;
-        if (c0 > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (c0 - 1) * CHB);
+        if (BOTH) {
+            const double fa = gl_load(gr, laneA, c0 * CHB), fb = gl_load(gr, laneB, c0 * CHB);
+            pa.ringA[(c0 & 1) * CILQR_WAVE + lane] = fa;
+            pa.ringB[(c0 & 1) * CILQR_WAVE + lane] = fb;
+            if (c0 > 0) { chunkA = gl_load(gr, laneA, (c0 - 1) * CHB); chunk = gl_load(gr, laneB, (c0 - 1) * CHB); }
+        } else {
+            const double first = gl_load(grs, 8u * (unsigned)lane, c0 * CHB);
+            pa.ringB[(c0 & 1) * CILQR_WAVE + lane] = first;
+            if (c0 > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (c0 - 1) * CHB);
+        }
     }
     // W = [l_xx[N] | l_x[N]] on the lanes (r, c <= 4)
     double wn = 0.0;
     if (cg <= 4) {
-        if (h == 0) {
+        if (BOTH) {
+            const int slot = (cg < 4) ? slotq : slotv;
+            wn = (slot >= 0) ? gl_load(gr, (h ? pa.roffB : pa.roffA) + 8u * (unsigned)slot, N * (int)ROWB) : 0.0;
+        } else if (h == 0) {
             // (the addresses above are at step N - 1: one stride further is row N)
             wn = (cg < 4) ? lds_load(a[8] + d[8]) : lds_load(a[9] + d[9]);
         } else {
@@ -358,7 +482,10 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
             // the sweep enters chunk c of B's rows: they arrived while chunk c + 1 was computed; fetch chunk c - 1
             const int cch = i >> 1;
             pa.ringB[(cch & 1) * CILQR_WAVE + lane] = chunk;
-            if (cch > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (cch - 1) * CHB);
+            if (BOTH) {
+                pa.ringA[(cch & 1) * CILQR_WAVE + lane] = chunkA;
+                if (cch > 0) { chunkA = gl_load(gr, laneA, (cch - 1) * CHB); chunk = gl_load(gr, laneB, (cch - 1) * CHB); }
+            } else if (cch > 0) chunk = gl_load(grs, 8u * (unsigned)lane, (cch - 1) * CHB);
         }
         double m1[4], m2[4];
 #pragma unroll
@@ -458,11 +585,12 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
 // backward sweep (cs:383-440) of the one trajectory that is waiting, or of both in one instruction stream.  Both read
 // everything from LDS / their arguments and leave their results in GrpSt (dV, and for a completed sweep the request for
 // the search's first rollout pass) and global memory (gains): the calls carry nothing.
-template <int NC, int G, bool STREAM>
+template <int NC, int G, bool STREAM, bool LONG = false>
 __device__ __attribute__((noinline)) void grp_expand(double* lds, int g, int n_rt, int lane, double* rows_rt, long long* prof) {
+    static_assert(STREAM || !LONG, "long layout: every expansion goes to its rows in global memory");
     const int N = NC ? NC : uniform_int(n_rt);
     Lds l;
-    carve_group(l, lds, N, G, g);
+    carve_group_t<LONG>(l, lds, N, G, g);
     Cst c;
     load_cst_lds(c, grp_cst(lds, N, g));
     AlmSt al;
@@ -504,20 +632,42 @@ __device__ inline void grp_after_sweep(GrpSt* st, bool ok, double dV0, double dV
 
 // gA: the trajectory whose expansion is in LDS; gB: the one whose rows are in global memory, or -1.  Returns the number of
 // trajectories that now wait for a rollout pass.
-template <int NC, int G>
+template <int NC, int G, bool LONG = false>
 __device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int gB_rt, int n_rt, int lane, double* scr_blk_rt, int tier_rt,
                                                    long long* profA, long long* profB) {
     const int N = NC ? NC : uniform_int(n_rt);
     const int gA = uniform_int(gA_rt), gB = uniform_int(gB_rt), tier = uniform_int(tier_rt);
     double* const scr_blk = (double*)uniform_ptr(scr_blk_rt);
     Lds l;
-    carve_group(l, lds, N, G, gA);
+    carve_group_t<LONG>(l, lds, N, G, gA);
     GrpSt* const stA = grp_state(lds, N, gA);
     const long long t0 = (CILQR_GPROF && profA) ? (long long)__builtin_readcyclecounter() : 0;
     const size_t slot_d = grp_scratch_doubles(N);
     const size_t gains_d = slab_doubles(N) + first_trial_doubles(N);
     int asked = 0;
-    if (gB < 0) {
+    if (LONG) {
+        // both halves stream from the rows in global memory; a trajectory on its own occupies both halves (the same numbers
+        // twice: its gains are stored by two lanes each, identically)
+        const int gb = (gB < 0) ? gA : gB;
+        GrpSt* const stB = grp_state(lds, N, gb);
+        PairArgs pa;
+        pa.lambA = stA->lamb; pa.lambB = stB->lamb;
+        pa.dtA = stA->dt; pa.dtB = stB->dt;
+        pa.rowsB = scr_blk + (size_t)gb * slot_d + grp_rows_offset(N);
+        pa.ringA = l.ring;
+        pa.ringB = l.ring + CILQR_GL_RING;
+        pa.goffA = (unsigned)(((size_t)gA * slot_d + gains_d) * sizeof(double));
+        pa.goffB = (unsigned)(((size_t)gb * slot_d + gains_d) * sizeof(double));
+        pa.roffA = (unsigned)(((size_t)gA * slot_d + grp_rows_offset(N)) * sizeof(double));
+        pa.roffB = (unsigned)(((size_t)gb * slot_d + grp_rows_offset(N)) * sizeof(double));
+        double dVA[2], dVB[2];
+        const unsigned ok = backward_sweep_pair<true>(N, l, pa, scr_blk, (unsigned)(G * slot_d * sizeof(double)), lane, dVA, dVB);
+        if (lane == 0) {
+            grp_after_sweep(stA, (ok & 1u) != 0u, dVA[0], dVA[1], tier);
+            if (gB >= 0) grp_after_sweep(stB, (ok & 2u) != 0u, dVB[0], dVB[1], tier);
+        }
+        asked = (int)(ok & 1u) + ((gB >= 0) ? (int)((ok >> 1) & 1u) : 0);
+    } else if (gB < 0) {
         Cst c;
         load_cst_lds(c, grp_cst(lds, N, gA));
         double dV[2];
@@ -560,12 +710,12 @@ __device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int g
 // get_total_cost (cs:199-287) of trial t of the trajectory in slot g — out of line for the same reason: the trial lives in
 // global memory (src / as: the slab or the first-trial buffer), x's lane window is staged (w0, W), the result is the return
 // value; serial reference-point chains that had to be run are counted in GrpSt::nfb.
-template <int NC, int G>
+template <int NC, int G, int NCH = 1>
 __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, int n_rt, int lane, const double* src, int t, int as,
                                                             int w0, int W) {
     const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
-    carve_group(l, lds, N, G, g);
+    carve_group_t<(NCH > 1)>(l, lds, N, G, g);
     l.w0 = w0;
     l.W = W;
     Cst c;
@@ -574,7 +724,7 @@ __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, i
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
     int nfb = 0;
     double J1[1];
-    total_cost_trials<false, 1, false, 1>(c, l, al, src, t, 1, lane, w0, 0, &nfb, J1, nullptr, 0, as);
+    total_cost_trials<false, NCH, false, 1>(c, l, al, src, t, 1, lane, w0, 0, &nfb, J1, nullptr, 0, as);
     if (nfb != 0 && lane == 0) grp_state(lds, N, g)->nfb += nfb;
     return J1[0];
 }
@@ -611,12 +761,12 @@ __device__ __attribute__((noinline)) double grp_cost_trials2(double* lds, int g,
 // The initial trajectory of the trajectory in slot g and its cost (cs:155-197, cs:104): fills x, u, the lane indices and
 // the trial-index seeds; the row-0 lane index comes back in *idx0_out (LDS: GrpSt::idx0).  Once per solve: out of line so
 // that its serial rollout's register needs stay out of the kernel's.
-template <int NC, int G>
+template <int NC, int G, bool LONG = false>
 __device__ __attribute__((noinline)) double grp_init(double* lds, int g, int n_rt, int lane, double xs0, double xs1, double xs2,
                                                       double xs3, const double* last_u, int Wcap) {
     const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
-    carve_group(l, lds, N, G, g);
+    carve_group_t<LONG>(l, lds, N, G, g);
     Cst c;
     load_cst_lds(c, grp_cst(lds, N, g));
     AlmSt al;
@@ -875,6 +1025,197 @@ __device__ __attribute__((noinline)) bool rollout_group(double* lds_base, double
         if (CILQR_GPROF && al == 0) grp_state(lds_base, N, gl)->small_steps = i_small;
     }
     wave_sync();
+    if (lane < G) grp_state(lds_base, N, lane)->req = 0;
+    wave_sync();
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The rollout pass of the LONG layout (horizons of 64 ... 127): as rollout_group, but the gains of a whole horizon do not fit
+// the shared LDS area (2 x 10 N doubles = 16 KB at N = 100), so they come in through a ring of two chunks of CILQR_GRPL_CHUNK
+// steps per trajectory: chunk c + 1 is fetched from global memory — by all 64 lanes, 16 bytes each (+ 16 on the first lanes) —
+// while the steps of chunk c run, and dropped into the ring half (c + 1) & 1 when the loop first asks for one of its steps.
+// Every lane of the wavefront runs the loop (the refill needs them all): a lane that has no trial of its own — or a trial of
+// the other vehicle model — shadows a lane that has, with its stores sent outside the buffer's range (dropped by the
+// hardware's range check), so the wave-uniform decisions (small-angle form or general form) see only real trials.
+struct LongStage {
+    unsigned src1, src2; // byte offsets (block scratch) of this lane's 16 bytes of chunk 0: element lane, element lane + 64
+    unsigned ring0;      // LDS byte address of ring half 0 (wave-uniform: element e of a chunk lands at + 16 e)
+    bool two;            // lane + 64 is an element of the chunk
+};
+typedef unsigned __attribute__((address_space(3))) lds_u32;
+
+template <int G>
+__device__ inline void roll_fetch_l(RollIn& g, const GrpRoll& q, int i) {
+    const unsigned xa = q.xaddr, ua = q.uaddr;
+    const unsigned ka = q.kaddr + (unsigned)(((i / CILQR_GRPL_CHUNK) & 1) * (G * CILQR_GRPL_CHUNK_BYTES) + (i % CILQR_GRPL_CHUNK) * (CILQR_KD * 8));
+    const f64x2 a = *(lds_cf64x2*)(size_t)(xa + 32u * (unsigned)i);
+    const f64x2 b = *(lds_cf64x2*)(size_t)(xa + 32u * (unsigned)i + 16u);
+    const f64x2 u = *(lds_cf64x2*)(size_t)(ua + 16u * (unsigned)i);
+    g.x[0] = a.x; g.x[1] = a.y; g.x[2] = b.x; g.x[3] = b.y;
+    g.u[0] = u.x; g.u[1] = u.y;
+#pragma unroll
+    for (int j = 0; j < CILQR_KD / 2; ++j) {
+        const f64x2 v = *(lds_cf64x2*)(size_t)(ka + 16u * (unsigned)j);
+        g.k[2 * j] = v.x;
+        g.k[2 * j + 1] = v.y;
+    }
+}
+
+template <int RP, int PIN, int G>
+__device__ inline int rollout_long_rp(int N, __amdgpu_buffer_rsrc_t rs, const GrpRoll& q, const LongStage& sg) {
+    const int nch = (N + CILQR_GRPL_CHUNK - 1) / CILQR_GRPL_CHUNK;
+    // The gains ring is filled by LDS-DMA (buffer_load ... lds: global memory -> LDS without passing through registers; the
+    // element lane e of a chunk lands at ring half + 16 e, which is the chunk's layout): no registers held for a chunk in
+    // flight, and — the point — no compiler-placed wait.  Through registers the compiler, which cannot count the slab stores
+    // between a load in one trip of the loop and its use eight steps later, put s_waitcnt vmcnt(0) in front of the LDS
+    // write: every eighth step waited for all its predecessors' slab stores to reach L2 (the pass 50 % longer per step than
+    // the short horizons').  The vector-memory counter retires in order, so waiting until at most 20 operations are
+    // outstanding when a chunk is first needed covers its DMA: 23 (first chunk) or 24 slab stores were issued behind it.
+    int have = 0; // chunks 0 .. have have been asked for and waited for (ring half = chunk & 1)
+    auto issue = [&](int c) {
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (LDS reads of the half about to be overwritten have returned)
+        lds_u32* const d1 = (lds_u32*)(size_t)(sg.ring0 + (unsigned)((c & 1) * (G * CILQR_GRPL_CHUNK_BYTES)));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d1, 16, sg.src1, c * CILQR_GRPL_CHUNK_BYTES, 0, 0);
+        if (sg.two) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d1 + 256, 16, sg.src2, c * CILQR_GRPL_CHUNK_BYTES, 0, 0);
+    };
+    auto need = [&](int j) { // before the first read of step j's gains
+        const int c = j / CILQR_GRPL_CHUNK;
+        if (c > have) {
+            __asm__ volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            have = c;
+            if (c + 1 < nch) issue(c + 1);
+        }
+    };
+    issue(0);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (nch > 1) issue(1);
+    const f64x2 a0 = *(lds_cf64x2*)(size_t)(q.xaddr);
+    const f64x2 b0 = *(lds_cf64x2*)(size_t)(q.xaddr + 16u);
+    double xc[4] = {a0.x, a0.y, b0.x, b0.y};
+    slab_st2(rs, q.vrow0, xc[0], xc[1]);
+    slab_st2(rs, q.vrow0 + q.pairb, xc[2], xc[3]);
+    GrpOut o;
+    o.bx0 = q.vrow0;
+    o.bx1 = q.vrow0 + q.pairb;
+    o.bu = q.vrow0 + 2u * q.pairb;
+    DmPinned pk;
+    if (PIN) dm_pin_load(pk);
+    // straight-line small-angle loop handing over to the general one, two register sets, inputs of step i + 1 fetched while
+    // step i computes (rollout_group_rp) — but the hand-over keeps both sets instead of fetching step i again: its chunk's
+    // ring half may already be the target of the next DMA
+    int i = 0;
+    RollIn ga, gb;
+    bool second = false; // gb (not ga) holds the step the small-angle loop stopped at
+    roll_fetch_l<G>(ga, q, 0);
+    for (;;) {
+        if (i >= N) break;
+        if (i + 1 < N) { need(i + 1); roll_fetch_l<G>(gb, q, i + 1); }
+        if (!roll_step_g<RP, true, PIN>(q, rs, pk, ga, xc, o, i)) break;
+        ++i;
+        if (i >= N) break;
+        if (i + 1 < N) { need(i + 1); roll_fetch_l<G>(ga, q, i + 1); }
+        if (!roll_step_g<RP, true, PIN>(q, rs, pk, gb, xc, o, i)) { second = true; break; }
+        ++i;
+    }
+    const int i_small = i;
+    if (i < N) {
+        if (second) { const RollIn t = ga; ga = gb; gb = t; } // ga: step i, gb: step i + 1
+        for (;;) {
+            roll_step_g<RP, false, PIN>(q, rs, pk, ga, xc, o, i);
+            ++i;
+            if (i >= N) break;
+            if (i + 1 < N) { need(i + 1); roll_fetch_l<G>(ga, q, i + 1); }
+            roll_step_g<RP, false, PIN>(q, rs, pk, gb, xc, o, i);
+            ++i;
+            if (i >= N) break;
+            if (i + 1 < N) { need(i + 1); roll_fetch_l<G>(gb, q, i + 1); }
+        }
+    }
+    return i_small;
+}
+
+template <int G, int PIN>
+__device__ __attribute__((noinline)) bool rollout_group_long(double* lds_base, double* scr_blk, int N_arg, int lane) {
+    const int N = uniform_int(N_arg); // (see rollout_group: the horizon back into a scalar register)
+    const int R = N + 1;
+    static_assert(G <= 3, "lanes: three searches of 20 step sizes fit a wavefront; a chunk of three trajectories is 120 elements");
+    int start = 0, gl = -1, al = 0, rq = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        GrpSt* st = grp_state(lds_base, N, g);
+        const int req = uniform_int(st->req);
+        const int n = (req == 2) ? CILQR_MAX_ALPHA_TRIALS : (req == 1 ? 1 : 0);
+        if (lane >= start && lane < start + n) { gl = g; al = lane - start; rq = req; }
+        start += n;
+    }
+    if (start == 0) return false;
+    wave_sync(); // (the sweeps' gain stores have completed: they were issued a segment ago)
+    double* const ring = lds_base + (size_t)G * grp_pg_doubles(N);
+    const unsigned slot_b = (unsigned)(grp_scratch_doubles(N) * sizeof(double));
+    const unsigned gains_b = (unsigned)((slab_doubles(N) + first_trial_doubles(N)) * sizeof(double));
+    constexpr int EPG = CILQR_GRPL_CHUNK * CILQR_KD / 2; // 16-byte elements of a chunk per trajectory
+    LongStage sg;
+    {
+        const int e1 = lane, e2 = lane + CILQR_WAVE;
+        const int g1 = e1 / EPG, r1 = e1 % EPG;
+        const int g2 = (e2 < EPG * G) ? e2 / EPG : 0, r2 = e2 % EPG;
+        sg.two = e2 < EPG * G;
+        sg.src1 = (unsigned)g1 * slot_b + gains_b + 16u * (unsigned)r1;
+        sg.src2 = (unsigned)g2 * slot_b + gains_b + 16u * (unsigned)r2;
+        static_assert(EPG * G > CILQR_WAVE && EPG * G <= 2 * CILQR_WAVE, "a chunk = one full DMA of 64 elements + a partial one");
+        sg.ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_cdouble*)ring);
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)uniform_ptr(scr_blk), 0, (int)(G * grp_scratch_doubles(N) * sizeof(double)), 0x00020000);
+    GrpRoll q;
+    q.alpha = 1.0; q.dt = 0.0; q.wb = 1.0;
+    q.xaddr = q.uaddr = q.kaddr = lds_addr(lds_base);
+    q.goff = 0u; q.vrow0 = 0u; q.pairb = 0u; q.tileb = 0u;
+    int rp = -1;
+    if (gl >= 0) {
+        double* pg = lds_base + (size_t)gl * grp_pg_doubles(N);
+        const GrpSt* st = grp_state(lds_base, N, gl);
+        q.alpha = dm_pow2i(-al);
+        q.dt = st->dt;
+        q.wb = st->wb;
+        rp = st->rp;
+        q.xaddr = lds_addr(pg);
+        q.uaddr = lds_addr(pg + 4 * R);
+        const unsigned as = (rq == 2) ? (unsigned)CILQR_MAX_ALPHA_TRIALS : 1u;
+        const unsigned gbase = (unsigned)gl * slot_b;
+        q.kaddr = lds_addr(ring) + (unsigned)gl * CILQR_GRPL_CHUNK_BYTES;
+        q.goff = gbase + gains_b;
+        q.tileb = as * (unsigned)(2 * CILQR_SLAB_TILE * sizeof(double));
+        q.pairb = (unsigned)CILQR_SLAB_RT(R) * q.tileb;
+        q.vrow0 = gbase + ((rq == 2) ? 0u : (unsigned)(slab_doubles(N) * sizeof(double))) +
+                  (unsigned)(2 * CILQR_SLAB_TILE * sizeof(double)) * (unsigned)al;
+    }
+    for (int model = 0; model < 2; ++model) {
+        const bool mine = (gl >= 0) && (rp == model);
+        const unsigned long long m = __ballot(mine);
+        if (m == 0ULL) continue;
+        const int proto = __ffsll((long long)m) - 1;
+        GrpRoll qq;
+        qq.alpha = __shfl(q.alpha, proto, CILQR_WAVE);
+        qq.dt = __shfl(q.dt, proto, CILQR_WAVE);
+        qq.wb = __shfl(q.wb, proto, CILQR_WAVE);
+        qq.xaddr = __shfl(q.xaddr, proto, CILQR_WAVE);
+        qq.uaddr = __shfl(q.uaddr, proto, CILQR_WAVE);
+        qq.kaddr = __shfl(q.kaddr, proto, CILQR_WAVE);
+        qq.goff = __shfl(q.goff, proto, CILQR_WAVE);
+        qq.pairb = __shfl(q.pairb, proto, CILQR_WAVE);
+        qq.tileb = __shfl(q.tileb, proto, CILQR_WAVE);
+        qq.vrow0 = 0x40000000u; // (a shadow lane: its stores fall outside the buffer)
+        if (mine) qq = q;
+        int i_small;
+        if (model == 0) i_small = rollout_long_rp<0, PIN, G>(N, rs, qq, sg);
+        else i_small = rollout_long_rp<1, PIN, G>(N, rs, qq, sg);
+        if (CILQR_GPROF && mine && al == 0) grp_state(lds_base, N, gl)->small_steps = i_small;
+        wave_sync();
+    }
     if (lane < G) grp_state(lds_base, N, lane)->req = 0;
     wave_sync();
     return true;

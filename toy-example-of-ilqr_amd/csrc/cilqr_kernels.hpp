@@ -66,6 +66,7 @@ struct BatchArgs {
     unsigned* ctl;              // the launch's control words
     int rq_cap;
     int res_iters;              // iterations per slice
+    int res_window;             // (grouped build) slices end in a hand-over only once fewer fresh trajectories than this are left
     // closed planning loop on the device (cilqr_closed_loop_batch_device): every ego runs `loop_ticks` ticks back to back —
     // solve, ego <- x.row(1), obstacle window one tick on, warm start from the plan just made (mp:180-197, cs:163-180)
     int loop_ticks;             // 0 / 1 = one solve per trajectory
@@ -837,10 +838,14 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
 // LOOP: the closed planning loop in one launch (cilqr_closed_loop_batch_device; mp:180-197, cs:163-180): a trajectory slot keeps
 // its ego for all its ticks — solve, ego <- x.row(1), tick + 1, next solve warm from the plan just stored where the ego's
 // configuration says so — as k_solve's LOOP builds do, but two egos per wavefront share their rollout passes.
-template <int NC, int G, bool LOOP = false>
+template <int NC, int G, bool LOOP = false, int NCH = 1>
 __global__ void __launch_bounds__(CILQR_WAVE, 2)
 k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, double* u_out, double* __restrict__ x_out,
             cilqr_result* __restrict__ res_out, cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
+    // NCH = 2: horizons of 64 ... 127, two rows per lane — the LONG layout of cilqr_group.hpp (both expansions and the gains in
+    // global memory, streamed; trial costs one at a time)
+    constexpr bool LONG = NCH > 1;
+    static_assert(!(LONG && LOOP), "the closed loop in one launch has no long-horizon grouped build");
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int N = NC ? NC : a.N;
     double* const scr_blk = a.scratch + (size_t)blockIdx.x * G * grp_scratch_doubles(N);
@@ -853,6 +858,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
     bool fresh_left = true;
     const int T = LOOP ? a.loop_ticks : 1;
     const bool steal = a.park != nullptr; // the tail of the launch: idle wavefronts take over trajectories of wavefronts that hold two
+    const bool slice = steal && a.res_iters > 0; // ... and solves run a.res_iters iterations at a time (see the end of an iteration)
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
     // Round 5: a turn of the wavefront = (pass 0) every trajectory's segment up to the point where it needs a rollout pass OR
@@ -871,21 +877,46 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 if (uniform_int(grp_state(g_lds, N, g)->phase) == GP_EXPAND) { if (gA < 0) gA = g; else gB = g; }
             if (gA < 0) break;
             const bool prof2 = CILQR_GPROF && a.prof != nullptr;
-            grp_expand<NC, G, false>(g_lds, gA, N, lane, nullptr, prof2 ? grp_prof(g_lds, N, gA) : nullptr);
+            if (LONG)
+                grp_expand<NC, G, true, LONG>(g_lds, gA, N, lane, scr_blk + (size_t)gA * grp_scratch_doubles(N) + grp_rows_offset(N),
+                                              prof2 ? grp_prof(g_lds, N, gA) : nullptr);
+            else
+                grp_expand<NC, G, false>(g_lds, gA, N, lane, nullptr, prof2 ? grp_prof(g_lds, N, gA) : nullptr);
             if (gB >= 0)
-                grp_expand<NC, G, true>(g_lds, gB, N, lane, scr_blk + (size_t)gB * grp_scratch_doubles(N) + grp_rows_offset(N),
-                                        prof2 ? grp_prof(g_lds, N, gB) : nullptr);
-            const int asked = uniform_int(grp_sweep<NC, G>(g_lds, gA, gB, N, lane, scr_blk, a.tier, prof2 ? grp_prof(g_lds, N, gA) : nullptr,
-                                                           (prof2 && gB >= 0) ? grp_prof(g_lds, N, gB) : nullptr));
+                grp_expand<NC, G, true, LONG>(g_lds, gB, N, lane, scr_blk + (size_t)gB * grp_scratch_doubles(N) + grp_rows_offset(N),
+                                              prof2 ? grp_prof(g_lds, N, gB) : nullptr);
+            const int asked = uniform_int(grp_sweep<NC, G, LONG>(g_lds, gA, gB, N, lane, scr_blk, a.tier, prof2 ? grp_prof(g_lds, N, gA) : nullptr,
+                                                                 (prof2 && gB >= 0) ? grp_prof(g_lds, N, gB) : nullptr));
             n_live += asked;
             if (asked == ((gB >= 0) ? 2 : 1)) break; // (nobody failed: no second pass)
         }
         for (int g = 0; g < G; ++g) {
             Lds l;
-            carve_group(l, g_lds, N, G, g);
+            carve_group_t<LONG>(l, g_lds, N, G, g);
             GrpSt* const st = grp_state(g_lds, N, g);
             int phase = uniform_int(st->phase);
-            if (phase == GP_DONE) continue;
+            if (phase == GP_CLAIMED) { // the slot holds a place in the queue: has its entry arrived?
+                if (pass != 0) continue;
+                const int pb = rq_poll(a.rq, (unsigned)a.rq_cap, (unsigned)uniform_int(st->pad2), lane);
+                if (pb < 0) continue;
+                if (lane == 0) { st->b = pb; st->req = 0; }
+                lds_sync();
+                phase = GP_STOLEN;
+            }
+            if (phase == GP_DONE) {
+                // (sliced solves: a slot that ran dry takes a parked trajectory as soon as one is queued)
+                if (LOOP || !slice || pass != 0) continue;
+                int claim = -1;
+                const int pb = uniform_int(grp_take_parked(a.ctl, a.rq, (unsigned)a.rq_cap, lane, &claim));
+                if (pb == -2) { if (lane == 0) { st->phase = GP_CLAIMED; st->pad2 = uniform_int(claim); } lds_sync(); }
+                if (pb < 0) continue;
+#ifdef CILQR_DEV_BUILD
+                (void)sh_add_u(a.ctl + SH_HELPED, 1u, lane); // (slots revived)
+#endif
+                if (lane == 0) { st->b = pb; st->req = 0; }
+                lds_sync();
+                phase = GP_STOLEN;
+            }
             if (pass == 1 && phase != GP_BPF) continue; // (second pass: only the trajectories whose sweep failed)
             const bool split = CILQR_GRP_PAIR_SWEEP && a.pair_sweep != 0 && pass == 0;
             double* const scr = scr_blk + (size_t)g * grp_scratch_doubles(N);
@@ -905,6 +936,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             int b = 0, idx0 = 0, status = CILQR_RUNNING, iters = 0, ls_trials = 0, cost_evals = 0, tl = 0, flag = 0, t0 = 0, trials = 0;
             bool deep_next = false, have_all = false;
             int keep_b = -1, t_done = 0; // closed loop: the slot's next trajectory is the same ego, its next tick
+            int it0 = 0;                 // sliced solves: the iteration count at which this slice began
             double J_cur = 0.0, J_init = 0.0, lamb = 0.0, new_J = 0.0, dV[2] = {0.0, 0.0};
             long long tl_start = 0;
             int entry = (phase == GP_SEARCH) ? 1 : (phase == GP_BPF ? 2 : 0); // where the segment takes the solve up again
@@ -912,6 +944,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             // latency is hidden; only a wavefront that holds two trajectories will act on it)
             unsigned waiting_probe = 0;
             if (steal && lane == 0) waiting_probe = sh_ld(a.ctl + SH_HELPING);
+            for (;;) { // (a slot that takes a parked trajectory off the queue in mid-segment comes round once more)
             if (phase == GP_STOLEN) {
                 // a trajectory another wavefront parked between two iterations: its x, u, lane indices and scalars
                 b = uniform_int(st->b);
@@ -931,6 +964,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb;
                 tl_start = st->tl_start;
                 t_done = LOOP ? uniform_int(st->t_done) : 0;
+                it0 = iters;
                 load_cst<LOOP>(c, a, b, l, lane); // (fills this slot's copy of the cost model's constants)
                 if (NC) c.N = NC;
                 if (lane == 0) { *grp_cst(g_lds, N, g) = c; st->b = b; st->req = 0; }
@@ -947,6 +981,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 J_cur = st->J_cur; J_init = st->J_init; lamb = st->lamb; new_J = st->new_J; dV[0] = st->dV0; dV[1] = st->dV1;
                 tl_start = st->tl_start;
                 t_done = LOOP ? uniform_int(st->t_done) : 0;
+                it0 = uniform_int(st->pad1);
                 load_cst_lds(c, grp_cst(g_lds, N, g));
                 if (entry == 1) stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
                 GPROF_ADD(PH_TC_REF); // (grouped build: slot 10 = the segment's set-up — state, constants, lane window)
@@ -967,7 +1002,23 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                             t_done = 0;
                             if (fresh_left) nb = sh_add_u(a.next, 1u, lane);
                         }
-                        if (nb >= (unsigned)a.B) { fresh_left = false; phase = GP_DONE; break; }
+                        if (nb >= (unsigned)a.B) {
+                            fresh_left = false;
+                            phase = GP_DONE;
+                            if (!LOOP && slice) { // sliced solves: no fresh trajectory left — a parked one, if any
+                                int claim = -1;
+                                const int pb = uniform_int(grp_take_parked(a.ctl, a.rq, (unsigned)a.rq_cap, lane, &claim));
+                                if (pb >= 0) {
+                                    if (lane == 0) { st->b = pb; st->req = 0; }
+                                    lds_sync();
+                                    phase = GP_STOLEN;
+                                } else if (pb == -2) {
+                                    if (lane == 0) st->pad2 = uniform_int(claim);
+                                    phase = GP_CLAIMED;
+                                }
+                            }
+                            break;
+                        }
                         b = (int)nb;
                         if (prof) {
                             for (int e = lane; e < CILQR_PROF_SLOTS; e += CILQR_WAVE) pacc[e] = 0;
@@ -1004,12 +1055,13 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         } else {
                             xs0 = x0[4 * b]; xs1 = x0[4 * b + 1]; xs2 = x0[4 * b + 2]; xs3 = x0[4 * b + 3];
                         }
-                        J_cur = grp_init<NC, G>(g_lds, g, N, lane, xs0, xs1, xs2, xs3, lu ? lu + (size_t)b * N * 2 : nullptr, a.W);
+                        J_cur = grp_init<NC, G, LONG>(g_lds, g, N, lane, xs0, xs1, xs2, xs3, lu ? lu + (size_t)b * N * 2 : nullptr, a.W);
                         idx0 = uniform_int(st->idx0);
                         J_init = J_cur;
                         lamb = c.k->init_lamb;
                         status = CILQR_RUNNING;
                         iters = 0; ls_trials = 0; cost_evals = 1; tl = 0; flag = 0;
+                        it0 = 0;
                         deep_next = false;
                         phase = GP_ITER;
                         GPROF_ADD(PH_INIT);
@@ -1023,8 +1075,9 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         //  trajectory; they read lambda and leave the request in its block)
                         if (lane == 0) { st->lamb = lamb; st->deep_next = deep_next ? 1 : 0; st->J_cur = J_cur; }
                         lds_sync();
-                        grp_expand<NC, G, false>(g_lds, g, N, lane, nullptr, prof ? pacc : nullptr);
-                        const bool ok = uniform_int(grp_sweep<NC, G>(g_lds, g, -1, N, lane, scr_blk, a.tier, prof ? pacc : nullptr, nullptr)) == 1;
+                        if (LONG) grp_expand<NC, G, true, LONG>(g_lds, g, N, lane, scr + grp_rows_offset(N), prof ? pacc : nullptr);
+                        else grp_expand<NC, G, false>(g_lds, g, N, lane, nullptr, prof ? pacc : nullptr);
+                        const bool ok = uniform_int(grp_sweep<NC, G, LONG>(g_lds, g, -1, N, lane, scr_blk, a.tier, prof ? pacc : nullptr, nullptr)) == 1;
                         if (prof) t_ph = (long long)__builtin_readcyclecounter(); // (booked inside)
                         status = CILQR_RUNNING;
                         dV[0] = st->dV0;
@@ -1054,13 +1107,13 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         const double* src = have_all ? scr : first;
                         const int as = have_all ? CILQR_MAX_ALPHA_TRIALS : 1;
                         // past the first trial the costs come two per pass (the searches that get here mostly go on)
-                        const int nt = (G > 1 && a.pair_costs && have_all && t0 >= 1 && t0 + 1 < CILQR_MAX_ALPHA_TRIALS) ? 2 : 1; // (G = 1: three wavefronts per SIMD, 168 VGPRs — the paired form needs 208)
+                        const int nt = (G > 1 && !LONG && a.pair_costs && have_all && t0 >= 1 && t0 + 1 < CILQR_MAX_ALPHA_TRIALS) ? 2 : 1; // (G = 1: three wavefronts per SIMD, 168 VGPRs — the paired form needs 208)
                         double Jp[2];
-                        if (G > 1 && nt == 2) {
+                        if (G > 1 && !LONG && nt == 2) {
                             Jp[0] = grp_cost_trials2<NC, (G > 1 ? G : 2)>(g_lds, g, N, lane, src, t0, l.w0, l.W);
                             Jp[1] = st->J_pair;
                         } else {
-                            Jp[0] = grp_cost_trial<NC, G>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
+                            Jp[0] = grp_cost_trial<NC, G, NCH>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
                             Jp[1] = 0.0;
                         }
                         GPROF_ADD(PH_TRIAL_COST);
@@ -1129,7 +1182,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                             const int ph = uniform_int(grp_state(g_lds, N, h)->phase);
                             if (h != g && (ph == GP_SEARCH || ph == GP_EXPAND)) other = true; // (live: waits for a pass, or for its sweep)
                         }
-                        if (other && grp_take_ticket(a.ctl, lane)) {
+                        if (other && grp_queue_room(a.ctl, (unsigned)a.B, (unsigned)a.rq_cap, lane) && grp_take_ticket(a.ctl, lane)) {
                             if (lane == 0) {
                                 st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
                                 st->cost_evals = cost_evals; st->tl = tl; st->flag = flag;
@@ -1149,6 +1202,27 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                             break;
                         }
                         waiting_probe = 0; // (asked once per segment)
+                    }
+                    if (!LOOP && slice && iters - it0 >= a.res_iters) {
+                        // Sliced solves (as k_solve's resumable ones): the slice is over.  While fresh trajectories are left, or
+                        // parked ones wait, this one goes to the back of the queue and the slot takes the next — every long solve
+                        // is well under way when the short ones are done, instead of finishing alone at the end of the launch.
+                        if (grp_slot_wanted(a.next, (unsigned)a.B, (unsigned)a.res_window, fresh_left ? 1 : 0, a.ctl, a.rq, (unsigned)a.rq_cap, lane)) {
+                            if (lane == 0) {
+                                st->b = b; st->idx0 = idx0; st->status = status; st->iters = iters; st->ls_trials = ls_trials;
+                                st->cost_evals = cost_evals; st->tl = tl; st->flag = flag;
+                                st->deep_next = deep_next ? 1 : 0;
+                                st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->tl_start = tl_start;
+                                st->t_done = t_done;
+                            }
+                            lds_sync();
+                            grp_park_copy(a.park + (size_t)b * grp_park_doubles(N), l.x, l.u, l.ridx, st, N, lane, 1);
+                            rq_push(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)b, lane);
+                            (void)grp_take_ticket(a.ctl, lane); // (if a wavefront waits, this push is the one its ticket asked for)
+                            phase = GP_EMPTY;
+                        } else {
+                            it0 = iters; // (nothing else wants the slot: another slice)
+                        }
                     }
                     continue;
                 }
@@ -1207,6 +1281,8 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 if (LOOP && t_done < T) { keep_b = b; continue; }
                 if (steal) (void)sh_add_u(a.ctl + SH_FINISHED, 1u, lane);
             }
+            if (phase != GP_STOLEN) break;
+            } // (the slot's restart loop)
             // what the trajectory carries to its next segment
             if (lane == 0) {
                 st->phase = phase;
@@ -1217,6 +1293,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     st->J_cur = J_cur; st->J_init = J_init; st->lamb = lamb; st->new_J = new_J; st->dV0 = dV[0]; st->dV1 = dV[1];
                     st->tl_start = tl_start;
                     st->t_done = t_done;
+                    st->pad1 = it0;
                 }
             }
             lds_sync(); // (not wave_sync: the sweep's gain stores may still be in flight; rollout_group waits for them)
@@ -1227,9 +1304,23 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
         }
         if (n_live == 0) {
             if (!steal) break;
-            const int pb = grp_wait_for_work(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)a.B, lane);
+            // a place in the queue one of the slots holds already, else (sliced solves) a parked trajectory if one is queued,
+            // else a ticket and a place (grp_wait_for_work)
+            int pb = -1, gw = 0;
+            long long claim = -1;
+            for (int g = G - 1; g >= 0; --g)
+                if (uniform_int(grp_state(g_lds, N, g)->phase) == GP_CLAIMED) { gw = g; claim = (long long)(unsigned)uniform_int(grp_state(g_lds, N, g)->pad2); }
+            if (claim < 0 && !LOOP && slice) {
+                int c2 = -1;
+                pb = uniform_int(grp_take_parked(a.ctl, a.rq, (unsigned)a.rq_cap, lane, &c2));
+                if (pb == -2) claim = (long long)(unsigned)uniform_int(c2);
+            }
+            if (pb < 0) pb = grp_wait_for_work(a.ctl, a.rq, (unsigned)a.rq_cap, (unsigned)a.B, lane, claim);
+#ifdef CILQR_DEV_BUILD
+            if (pb < 0 && sh_ld_u(a.ctl + SH_FINISHED, lane) < (unsigned)a.B) (void)sh_add_u(a.ctl + SH_ANNOUNCED, 1u, lane); // (left before the end)
+#endif
             if (pb < 0) break;
-            if (lane == 0) { GrpSt* st0 = grp_state(g_lds, N, 0); st0->b = pb; st0->phase = GP_STOLEN; st0->req = 0; }
+            if (lane == 0) { GrpSt* st0 = grp_state(g_lds, N, gw); st0->b = pb; st0->phase = GP_STOLEN; st0->req = 0; }
             lds_sync();
             continue;
         }
@@ -1240,7 +1331,8 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             int reqs[G], n_req = 0;
             for (int g = 0; g < G; ++g) { reqs[g] = uniform_int(grp_state(g_lds, N, g)->req); n_req += reqs[g] != 0; }
             const long long t0_ = (long long)__builtin_readcyclecounter();
-            rollout_group<G, 0, (G <= 2)>(g_lds, scr_blk, N, lane);
+            if (LONG) rollout_group_long<G, 0>(g_lds, scr_blk, N, lane);
+            else rollout_group<G, 0, (G <= 2)>(g_lds, scr_blk, N, lane);
             const long long dt_ = ((long long)__builtin_readcyclecounter() - t0_) / (n_req > 0 ? n_req : 1);
             if (lane == 0)
                 for (int g = 0; g < G; ++g)
@@ -1251,6 +1343,8 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         pa[reqs[g] == 1 ? PH_ROLL_FIRST : (uniform_int(grp_state(g_lds, N, g)->t0) == 1 ? PH_ROLL_SECOND : PH_ROLL_ALL)] += 1;
                     }
             wave_sync();
+        } else if (LONG) {
+            rollout_group_long<G, 0>(g_lds, scr_blk, N, lane);
         } else {
             rollout_group<G, 0, (G <= 2)>(g_lds, scr_blk, N, lane);
         }
@@ -1283,13 +1377,12 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
     X(1, false, 2, false, true, false, 1, CILQR_NT, 0, false, false, false, false)            \
     X(2, false, 1, false, true, false, 1, CILQR_NT, 50, false, false, false, false)           \
     X(3, false, 1, false, true, false, 1, CILQR_NT, 30, false, false, false, false)           \
-    /* large batches, lone wavefronts two per SIMD: N <= 63 when the grouped kernel is switched off (cilqr_set_group_mode(0), \
-       a compiler other than the validated one); N 64 ... 75 with work sharing + resumable solves; N >= 76 with the expansion \
-       in global memory, any horizon and BASELINE's 100 */ \
+    /* large batches, lone wavefronts two per SIMD — what runs when the grouped kernel is switched off (cilqr_set_group_mode(0), \
+       a compiler other than the validated one): N <= 63; N >= 64 with the expansion in global memory, work sharing and \
+       resumable solves (round 5: the grouped kernel's long layout took the large batches of these horizons over, the builds \
+       with the expansion in LDS for N 64 ... 75 and the compile-time N = 100 one are gone) */ \
     X(4, false, 1, false, false, false, 2, 1, 0, false, false, false, false)                  \
-    X(5, false, 2, false, false, false, 2, 1, 0, false, true, true, false)                   \
     X(6, false, 2, false, false, false, 2, 1, 0, true, true, true, false)                    \
-    X(7, false, 2, false, false, false, 2, 1, 100, true, true, true, false)                  \
     /* augmented Lagrangian: helper wavefronts, lone two per SIMD, long horizons with the expansion in global memory */ \
     X(0, CILQR_ALM_DBG, 1, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \
     X(1, CILQR_ALM_DBG, 2, true, true, false, 1, CILQR_NT, 0, false, false, false, false)     \

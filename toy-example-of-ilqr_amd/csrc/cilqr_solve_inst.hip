@@ -60,4 +60,9 @@ template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 5
 template __global__ void k_solve_grp<30, 2> CILQR_GRP_SIGNATURE;
 template __global__ void k_solve_grp<30, 2, true> CILQR_GRP_SIGNATURE;
+// horizons of 64 ... 127 (two rows per lane, the long layout of cilqr_group.hpp): BASELINE's 100, any
+#elif CILQR_INST_GROUP == 3
+template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATURE;
+#elif CILQR_INST_GROUP == 4
+template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 #endif
