@@ -54,11 +54,13 @@ fi
 # 5. in-kernel phase accounting.  Configs 3 and 5 run the grouped build (two trajectories per wavefront, two wavefronts per
 # SIMD: --group 2); next to it the one-trajectory build they ran before, accounted at two wavefronts per SIMD as well
 # (CILQR_TUNE=prof2=1) and at one (the r01-r03 figures)
-for c in 2 4; do
-    $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
-done
+# (round 5, second half: configs[3]'s shard runs the grouped build's long layout too; the accounting of a sliced solve restarts
+#  when it is resumed, so the grouped passes run with the slices switched off)
+$PY $ROOT/scripts/phase_profile.py --config 2 > "$OUT/phase_config2.json" 2> "$OUT/phase_config2.err"
+$PY $ROOT/scripts/phase_profile.py --config 4 > "$OUT/phase_config4_single_1wps.json" 2> "$OUT/phase_config4.err"
+CILQR_TUNE=group_slice=0,group_slice_long=0 $PY $ROOT/scripts/phase_profile.py --config 4 --group 2 > "$OUT/phase_config4.json" 2>> "$OUT/phase_config4.err"
 for c in 3 5; do
-    $PY $ROOT/scripts/phase_profile.py --config $c --group 2 > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
+    CILQR_TUNE=group_slice=0,group_slice_long=0 $PY $ROOT/scripts/phase_profile.py --config $c --group 2 > "$OUT/phase_config$c.json" 2> "$OUT/phase_config$c.err"
     CILQR_TUNE=prof2=1 $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config${c}_single_2wps.json" 2>> "$OUT/phase_config$c.err"
     $PY $ROOT/scripts/phase_profile.py --config $c > "$OUT/phase_config${c}_single_1wps.json" 2>> "$OUT/phase_config$c.err"
 done
@@ -77,9 +79,13 @@ for c in 3 4 5; do
 done
 
 # 8b. the same launches with one trajectory per wavefront (the r03 shape), for the timelines' before / after
-for c in 3 5; do
+for c in 3 4 5; do
     GROUP_MODE=0 $PY $ROOT/scripts/block_timeline.py $c > "$OUT/timeline_config${c}_single.json" 2>> "$OUT/timeline_config$c.err"
 done
+# 8c. sliced solves: kernel time, hand-overs and unfinished trajectories over time, by slice length (development library)
+$PY $ROOT/scripts/slice_probe.py 3 "group_slice=0" "group_slice=8" "group_slice=16" "group_slice=32" > "$OUT/slices_config3.jsonl" 2> "$OUT/slices.err"
+$PY $ROOT/scripts/slice_probe.py 4 "group_slice_long=0" "group_slice_long=8" "group_slice_long=12" "group_slice_long=24" > "$OUT/slices_config4.jsonl" 2>> "$OUT/slices.err"
+$PY $ROOT/scripts/slice_probe.py 5 "group_slice=0" "group_slice=16" > "$OUT/slices_config5.jsonl" 2>> "$OUT/slices.err"
 
 # 9. where the wave-cycles go (SQ wait / active counters), headline and the two 8192-trajectory launches
 for a in "5 c5" "3 c3" "4 c4"; do set -- $a; $ROOT/scripts/stall_counters.sh $TAG "--config $1" $2 > /dev/null 2>&1; done

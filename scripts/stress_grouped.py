@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs ON THE GPU BOX: hammer the grouped build (k_solve_grp: two or three trajectories per wavefront, one rollout pass for
-all, trajectories handed over between wavefronts at the launch's tail).  Random horizons up to 63, batch sizes from a handful
+all, trajectories handed over between wavefronts at the launch's tail, sliced solves).  Random horizons up to 63 — and, round 5,
+64 ... 127 (the long layout: both expansions and the gains streamed, config 4's scenario mix) —, batch sizes from a handful
 to several rounds of the resident wavefronts, scenario / parameter mixes, iteration budgets, rollout policies, warm starts;
 every launch is solved with one trajectory per wavefront first (k_solve) and then with 2 and 3 per wavefront, with and
 without the tail hand-over (development library: CILQR_TUNE is read per handle), and compared bit for bit — u, x, every
@@ -46,11 +47,17 @@ def main():
     launches = handed_over = waiting = 0
     shapes = []
     while time.time() < t_end:
-        N = int(rng.choice([5, 12, 30, 41, 50, 50, 50, 63]))
+        N = int(rng.choice([5, 12, 30, 41, 50, 50, 50, 63, 64, 77, 100, 100, 127]))
         B = int(rng.choice([1, 2, 3, 7, 64, 333, 1024, 2049, 4100, 6200, 9000, 17000]))
         kind = int(rng.integers(0, 3))
         first = int(rng.integers(0, 50000))
-        if kind == 0:
+        if N > 63:
+            kind = 3
+            B = min(B, 9000)
+            wl = pkg.workloads.config4(B=B, N=N, first=first)
+            if any(sc.obs.shape[1] < N + 1 for sc in wl.scenes):
+                continue
+        elif kind == 0:
             wl = pkg.workloads.config3(B=B, N=N, first=first)
         elif kind == 1:
             wl = pkg.workloads.config5(B_base=max(1, B // 16), N=N, first=first)
@@ -69,7 +76,10 @@ def main():
             warm = np.cumsum(rng.normal(0, 0.05, (wl.B, wl.N, 2)), axis=1) * np.array([1.0, 0.05])
         rollout = int(rng.choice([-1, -1, 0, 1]))
         ref = None
-        for tune in ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0", "group=2,pair_sweep=0"):
+        slice_a, slice_b = int(rng.choice([1, 2, 3, 5, 8])), int(rng.choice([0, 13, 40]))
+        for tune in ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0", "group=2,pair_sweep=0",
+                     f"group=2,group_slice={slice_a},group_slice_long={slice_a},group_slice_window=300",
+                     f"group=2,group_slice={slice_b},group_slice_long={slice_b}"):
             eng = engine(wl, tune)
             eng.set_helper_mode(0)
             eng.set_rollout_mode(rollout)
