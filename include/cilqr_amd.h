@@ -240,10 +240,15 @@ int cilqr_get_alm_state(cilqr_handle* h, int32_t B, double* mu, double* mu_next,
  * 0 = never; 1 = always.  Results are identical in every mode. */
 int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
 
-/* Trajectories per wavefront (horizons up to 63, barrier mode): -1 (default) = automatic — batches beyond the helper
- * range run two trajectories per wavefront, whose line-search rollouts (src/cilqr_solver.cpp:442-461, a serial chain over
- * the horizon) share one pass of the instruction stream; 0 or 1 = one trajectory per wavefront everywhere; 2 = two
- * wherever that build can run (any batch size).  Results are identical in every mode. */
+/* Trajectories per wavefront (barrier mode, every horizon the library takes — up to 63 with one row per lane, 64 ... 127
+ * with two and both trajectories' expansions streamed from global memory): -1 (default) = automatic — batches beyond the
+ * helper range run two trajectories per wavefront, whose line-search rollouts (src/cilqr_solver.cpp:442-461, a serial chain
+ * over the horizon) share one pass of the instruction stream and whose backward sweeps (cs:383-440) run as one, a
+ * trajectory per half-wavefront; 0 or 1 = one trajectory per wavefront everywhere; 2 = two wherever that build can run (any
+ * batch size).  Results are identical in every mode.  A launch in pairs hands trajectories from wavefront to wavefront
+ * (sliced solves, idle wavefronts at its tail); should a bounded wait inside it ever expire, cilqr_solve_batch returns
+ * CILQR_ERR_DEVICE and the device-pointer entry points report it through cilqr_work_sharing_stats out[3] (a trajectory
+ * that was being handed over may then be missing from the outputs — never observed: 26 k stress launches). */
 int cilqr_set_group_mode(cilqr_handle* h, int32_t mode);
 
 /* Work sharing between blocks (horizons above 63, batches beyond the helper range): 1 (default) = blocks that find no

@@ -194,6 +194,18 @@ if b:
                "what": "bench.py's multi-GPU branch on one rank: init_process_group('nccl') = RCCL, dist.barrier(), the SUM "
                        "and MAX all-reduces of the statistics, destroy_process_group",
                "bench_line": b, "stderr_tail": err}, open(os.path.join(dst, f"{tag}_force_dist.json"), "w"), indent=1)
+# sliced solves of the grouped build by slice length (scripts/slice_probe.py): one JSON line per setting
+sl = {}
+for c in (3, 4, 5):
+    p = os.path.join(src, f"slices_config{c}.jsonl")
+    if os.path.exists(p) and os.path.getsize(p):
+        sl[f"config{c}"] = [json.loads(l) for l in open(p) if l.startswith("{")]
+if sl:
+    json.dump({"what": "development library, CILQR_TUNE=group_slice / group_slice_long = iterations per slice (0: solves run whole); "
+                       "one launch each with the block timeline on; parked = hand-overs (end of a slice + idle wavefronts at the tail); "
+                       "unfinished_started_in_20_slices = trajectories started and not finished, in 20 equal slices of the launch",
+               "by_workload": sl}, open(os.path.join(dst, f"{tag}_sliced_solves.json"), "w"), indent=1)
+
 for c in (3, 4, 5):
     for suffix in ("", "_single"):
         p = os.path.join(src, f"timeline_config{c}{suffix}.json")
