@@ -207,7 +207,8 @@ class BatchedCILQR:
                 "lane_window_samples": int(out[3])}
 
     def set_group_mode(self, mode):
-        """-1 automatic, 0 / 1 one trajectory per wavefront, 2 two per wavefront wherever that build can run"""
+        """-1 automatic (two per wavefront beyond the helper range, barrier mode, every horizon), 0 / 1 one trajectory per
+        wavefront, 2 two per wavefront wherever that build can run"""
         self._check(self._lib.cilqr_set_group_mode(self._h, int(mode)), "cilqr_set_group_mode")
 
     def set_rollout_mode(self, mode):
@@ -237,8 +238,9 @@ class BatchedCILQR:
         return {"announced": int(out[0]), "helped": int(out[1]), "helpers": int(out[2]), "error": int(out[3])}
 
     def set_resume_iters(self, iters):
-        """iterations per slice of the resumable solves (long horizons in batches larger than the chip holds at once);
-        0 = off.  Same results either way."""
+        """iterations per slice of the resumable / sliced solves (batches larger than the chip holds at once: a solve runs
+        this many iterations at a time and is parked in between, so that long solves do not finish alone at the end of a
+        launch); -1 = automatic (32 for lone wavefronts, 16 / 12 for trajectories in pairs), 0 = off.  Same results either way."""
         self._check(self._lib.cilqr_set_resume_iters(self._h, int(iters)), "cilqr_set_resume_iters")
 
     def resume_stats(self):
