@@ -400,7 +400,7 @@ struct cilqr_handle {
                                // two-rows-per-lane builds)
     int group_slice = 16;      // ... solves run this many iterations at a time while other trajectories wait (0: to their end in one go)
     int group_slice_long = 12; // ... the same for the long layout
-    int group_slice_window_pct = 100; // ... hand-overs at the end of a slice begin when fewer fresh trajectories are left than this share of the resident slots
+    int group_slice_window_pct = 200; // ... hand-overs at the end of a slice begin when fewer fresh trajectories are left than this share of the resident slots
     int group_steal = 1;       // ... idle wavefronts take over trajectories of wavefronts that still hold two (the launch's tail)
     int prof_B = 0;
     DevBuf st[16];

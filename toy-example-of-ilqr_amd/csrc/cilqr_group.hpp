@@ -197,7 +197,9 @@ __device__ __attribute__((noinline)) int grp_wait_for_work(unsigned* ctl, const 
     for (int spin = 0; spin < (1 << 20); ++spin) { // (a launch lasts milliseconds; this bound is seconds)
         const int pb = rq_poll(q, cap, h, lane);
         if (pb >= 0) return pb;
-        if (sh_ld_u(ctl + SH_FINISHED, lane) >= B) return -1;
+        // (every wavefront polls its OWN place; the one word they all share is looked at every eighth time: the wavefronts
+        //  that hold a place are not capped at CILQR_GRP_MAX_WAITING, and a line serves ~90 atomics per microsecond)
+        if ((spin & 7) == 7 && sh_ld_u(ctl + SH_FINISHED, lane) >= B) return -1;
         __builtin_amdgcn_s_sleep(127);
     }
     if (lane == 0) sh_st(ctl + SH_ERROR, 1u);
