@@ -266,7 +266,7 @@ int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]);
  * fresh trajectories before parked ones — so the solves that will take 100 iterations are well under way when the short
  * ones are done, instead of starting late and finishing alone.  Same results bit for bit (whoever resumes a solve
  * computes the same numbers).  The launches that run two trajectories per wavefront (large batches, barrier mode) slice
- * their solves the same way once the last two rounds of fresh trajectories are being handed out.  -1 (default) = automatic: 32
+ * their solves the same way once the last round of fresh trajectories is being handed out.  -1 (default) = automatic: 32
  * iterations per slice for lone wavefronts, 16 (horizons up to 63) / 12 (longer) for pairs; 0 = every solve runs to its end
  * in one go; n > 0 = n iterations per slice everywhere.  cilqr_resume_stats: how many times a solve was parked (end of a
  * slice, or handed to an idle wavefront at the tail of the launch) in the handle's last such launch. */

@@ -388,7 +388,7 @@ struct cilqr_handle {
                                //  one trial per pass: the one-per-SIMD lone builds could only be reached through tuning switches
                                //  and are gone from the library)
     int prof_two_per_simd = 0; // development library: cycle accounting in the two-per-SIMD headline build (CILQR_TUNE=prof2=1)
-    int group_mode = -1;       // trajectories per wavefront in the large-batch launches, barrier mode, every horizon (64 ... 127: the long layout)
+    int group_mode = -1;       // trajectories per wavefront in the large-batch launches of horizons up to 63, barrier mode
                                // (k_solve_grp): -1 = 2 where that build applies, 0 / 1 = never (k_solve), 2 = wherever it can run
     int win_grp = 0;           // lane window of those launches
     int group_loop = 1;        // the closed loop in one launch runs the grouped build too (0: k_solve's LOOP builds)

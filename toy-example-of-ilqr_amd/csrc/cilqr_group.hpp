@@ -1,6 +1,5 @@
-// cilqr_group.hpp — the solve kernel for large batches (barrier mode): G trajectories per wavefront, ONE rollout pass for all of
-// them, one backward sweep for both (round 5), sliced solves (round 5); horizons up to 63 as described here, 64 ... 127 in the
-// "long layout" further down.
+// cilqr_group.hpp — the solve kernel for large batches of short horizons: G trajectories per wavefront, ONE rollout pass
+// for all of them.
 //
 // Why.  The line search's forward pass (cs:442-461) is a serial chain over the horizon; k_solve runs it with lane =
 // trial step size, and 72 % of the iterations of the headline workload roll out alpha = 1 alone: one live lane of 64
@@ -209,9 +208,8 @@ __device__ __attribute__((noinline)) int grp_wait_for_work(unsigned* ctl, const 
 // Sliced solves (round 5; k_solve's resumable solves are the model, cilqr_device.hpp): a solve runs `res_iters` iterations at a
 // time.  At the end of a slice the trajectory is parked and queued — and the slot takes the next one — when somebody else is
 // in need of the slot: parked trajectories wait, or the LAST fresh trajectories are about to be handed out (fewer than
-// `window` left — the host passes two rounds of the resident slots: measured best of 0.5 / 1 / 2, sliced_solves.txt; before
-// that a fresh trajectory finds a slot soon enough anyway and the hand-over, 2.9 KB out and in again plus the set-up of a
-// segment, would be paid by every long solve of a large batch for nothing).
+// `window` left: the launch's final round — before that a fresh trajectory finds a slot soon enough anyway and the hand-over,
+// 2.9 KB out and in again plus the set-up of a segment, would be paid by every long solve of a large batch for nothing).
 // Once the counter is dry every slot that falls empty takes a parked trajectory, so the long solves of the final round
 // advance side by side, a slice at a time, instead of finishing one by one on an emptying chip.
 // The queue of the grouped build is NOT reused within a launch (CILQR_GRP_Q_PER_TRAJECTORY entries per trajectory, position =

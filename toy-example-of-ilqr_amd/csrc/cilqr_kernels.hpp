@@ -826,7 +826,7 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
 
 
 // ------------------------------------------------------------------------------------------------
-// k_solve_grp: the solve for large batches, barrier mode (NCH = 1: horizons up to 63; NCH = 2: 64 ... 127) — G trajectories per wavefront, one rollout
+// k_solve_grp: the solve for large batches of horizons up to 63, barrier mode — G trajectories per wavefront, one rollout
 // pass for all of them (cilqr_group.hpp).  Persistent blocks pulling trajectories from a.next, like k_solve's.
 // Every trajectory runs CILQRSolver::solve (cs:85-153) + iter_step (cs:337-381) through the same device functions as in
 // solve_one, cut into segments at the two points where its line search needs a rollout pass:
