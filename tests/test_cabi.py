@@ -362,3 +362,49 @@ int main() {
     subprocess.run(["g++", "-std=c++17", "-pthread", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.strip() == "OK 24576 8192", out  # BASELINE configs[3]: rank 3 of 8 gets trajectories 24576 ... 32767
+
+
+def test_gains_ring_of_the_long_rollout_is_waited_for_with_a_counted_wait(tmp_path):
+    """Round 5 (profiles/r05_experiments/sweep_ring_by_lds_dma.txt): rollout_group_long refills its gains ring by LDS-DMA
+    (buffer_load ... lds) and waits for a chunk with `s_waitcnt vmcnt(20)` — 24 slab stores are issued behind a chunk's DMA.
+    Staged through registers the compiler had put `s_waitcnt vmcnt(0)` in front of the LDS write: every eighth step drained
+    all earlier slab stores and the pass took 24 % longer.  A guard on the shipped code: the DMA refills are there, each
+    loop's refill sits behind a counted wait, and vmcnt(0) appears only where the function drains on purpose (entry, the two
+    models' first chunk, exit)."""
+    import importlib.util
+    import re
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("kernel_metadata", ROOT / "scripts" / "kernel_metadata.py")
+    km = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, str(ROOT / "scripts"))
+    spec.loader.exec_module(km)
+    seen = 0
+    for co in km.extract_code_objects(str(ROOT / "toy-example-of-ilqr_amd" / "libcilqr_amd.so"), str(tmp_path)):
+        txt = subprocess.run([str(pathlib.Path(km.LLVM) / "llvm-objdump"), "-d", "--no-show-raw-insn", co],
+                             capture_output=True, text=True).stdout
+        cur, body = None, {}
+        for ln in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", ln)
+            if m:
+                cur = m.group(1)
+                body[cur] = []
+            elif cur and ln.strip():
+                body[cur].append(ln.strip())
+        for name, lines in body.items():
+            if "rollout_group_long" not in name:
+                continue
+            seen += 1
+            ops = [l.split("//")[0].strip() for l in lines]
+            dma = [i for i, o in enumerate(ops) if o.startswith("buffer_load_dwordx4") and o.endswith("lds")]
+            counted = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(20)" in o]
+            drains = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt(0)" in o]
+            assert len(dma) >= 16 and len(counted) >= 8, (name, len(dma), len(counted))
+            assert len(drains) <= 6, (name, drains)
+            # every counted wait is followed within a few instructions by the next chunk's refill (wait, then overwrite the other half)
+            for i in counted:
+                assert any(i < j <= i + 24 for j in dma), (name, i)
+            # no other wait on the vector-memory counter inside the function: the compiler has nothing to wait for (LDS reads only)
+            others = [o for o in ops if o.startswith("s_waitcnt") and "vmcnt(" in o and "vmcnt(20)" not in o and "vmcnt(0)" not in o]
+            assert not others, (name, others[:4])
+    assert seen >= 2  # the long-layout kernels of horizon 100 and of any horizon
