@@ -1,0 +1,254 @@
+"""A small-step MODEL of the grouped kernel's hand-over protocol (csrc/cilqr_kernels.hpp k_solve_grp, csrc/cilqr_group.hpp
+grp_take_parked / grp_wait_for_work / grp_slot_wanted / grp_take_ticket, csrc/cilqr_device.hpp rq_push / rq_claim / rq_poll),
+run under random interleavings: every wavefront is a little state machine whose shared-memory operations (counter reads, fetch-and-
+adds, the two halves of a push, polls) are separate steps a scheduler interleaves at random.  What must hold whatever the
+interleaving (the properties the GPU tests can only sample): every trajectory is finished exactly once, no trajectory sits in
+the queue when the last wavefront has left, no wavefront that holds a place in the queue leaves before the launch is over, a
+place is never claimed twice, pushes never exceed the queue's room.  Round 5 found two protocol errors of exactly this kind on
+the GPU the slow way (an abandoned ring position under one-iteration slices; tickets left behind by wavefronts served from a
+slice) — the model reproduces the first when the room check is taken out (test below).  CPU only; the model is a restatement,
+kept deliberately close to the kernel's control flow, not the kernel."""
+import random
+
+import pytest
+
+EMPTY, LIVE, DONE, CLAIMED = "EMPTY", "LIVE", "DONE", "CLAIMED"
+MAX_WAITING = 4          # CILQR_GRP_MAX_WAITING scaled to the model's handful of wavefronts
+Q_PER_TRAJECTORY = 16    # CILQR_GRP_Q_PER_TRAJECTORY
+
+
+class Launch:
+    def __init__(self, iters, n_waves, res_iters, window, rng, room_check=True, per_trajectory=Q_PER_TRAJECTORY):
+        self.left = list(iters)               # iterations each trajectory still needs
+        self.B = len(iters)
+        self.next = 0                         # SH_NEXT
+        self.finished = 0                     # SH_FINISHED
+        self.helping = 0                      # SH_HELPING (tickets)
+        self.resv = 0                         # SH_Q_RESV
+        self.head = 0                         # SH_Q_HEAD
+        self.cap = self.B * per_trajectory
+        self.q = {}                           # position -> trajectory (an entry that has been STORED)
+        self.claimed = set()
+        self.done_count = [0] * self.B
+        self.res_iters, self.window, self.room_check = res_iters, window, room_check
+        self.rng = rng
+        self.waves = [self.wave(w) for w in range(n_waves)]
+        self.alive = [True] * n_waves
+        self.pushes = 0
+        self.overwritten = False
+
+    # ---- the queue's primitives: every yield is a point where other wavefronts may run ----
+    def push(self, b):
+        s = self.resv
+        self.resv += 1                        # fetch-and-add
+        yield
+        if s >= self.cap:                     # (the kernel indexes s % cap: a wrapped position overwrites an older entry)
+            self.overwritten = True
+            s_mod = s % self.cap
+            self.q.pop(s_mod, None)
+        self.q[s] = b                         # the entry's store, a step later
+        self.pushes += 1
+
+    def room(self):
+        return (self.resv + 2 * self.B < self.cap) if self.room_check else True
+
+    def avail(self):
+        return self.resv - self.head > 0
+
+    def claim(self):
+        h = self.head
+        self.head += 1
+        assert h not in self.claimed
+        self.claimed.add(h)
+        return h
+
+    def take_ticket(self):
+        if self.helping > 0:                  # (compare-and-swap: atomic)
+            self.helping -= 1
+            return True
+        return False
+
+    def take_parked(self):
+        """-> ('b', b) | ('none',) | ('claim', h)"""
+        if not self.avail():
+            return ("none",)
+        yield
+        h = self.claim()
+        for _ in range(4):
+            yield
+            if h in self.q:
+                return ("b", self.q.pop(h))
+        return ("claim", h)
+
+    def wait_for_work(self, claim):
+        """-> b or None (leave)"""
+        if self.finished >= self.B:
+            return None
+        if claim is None:
+            if self.helping >= MAX_WAITING:
+                return None
+            self.helping += 1
+            yield
+            h = self.claim()
+        else:
+            h = claim
+            self.helping += 1
+        spins = 0
+        while True:
+            yield
+            if h in self.q:
+                return self.q.pop(h)
+            spins += 1
+            if spins % 8 == 7 and self.finished >= self.B:
+                return None
+            assert spins < 200000, "a wavefront waits for ever"
+
+    # ---- one wavefront: two slots, turns ----
+    def wave(self, w):
+        slots = [dict(phase=EMPTY, b=None, it0=0, done=0, claim=None) for _ in range(2)]
+        fresh_left = True
+        slice_on = self.res_iters > 0
+
+        def start(sl, b):
+            sl.update(phase=LIVE, b=b, it0=self.total_done[b], claim=None)
+
+        self.total_done = getattr(self, "total_done", [0] * self.B)
+        while True:
+            n_live = 0
+            for g, sl in enumerate(slots):
+                if sl["phase"] == CLAIMED:
+                    yield
+                    if sl["claim"] in self.q:
+                        start(sl, self.q.pop(sl["claim"]))
+                    else:
+                        continue
+                if sl["phase"] == DONE:
+                    if not slice_on:
+                        continue
+                    r = yield from self.take_parked()
+                    if r[0] == "claim":
+                        sl.update(phase=CLAIMED, claim=r[1])
+                    if r[0] != "b":
+                        continue
+                    start(sl, r[1])
+                probe = self.helping          # (read at the start of the segment)
+                yield
+                while True:                   # the segment: pull if empty, run ONE iteration, then decide
+                    if sl["phase"] == EMPTY:
+                        nb = self.B
+                        if fresh_left:
+                            nb = self.next
+                            self.next += 1
+                        yield
+                        if nb >= self.B:
+                            fresh_left = False
+                            sl["phase"] = DONE
+                            if slice_on:
+                                r = yield from self.take_parked()
+                                if r[0] == "b":
+                                    start(sl, r[1])
+                                    continue
+                                if r[0] == "claim":
+                                    sl.update(phase=CLAIMED, claim=r[1])
+                            break
+                        sl.update(phase=LIVE, b=nb, it0=0, claim=None)
+                    b = sl["b"]
+                    # one iteration of the solve
+                    assert self.left[b] > 0, "a finished trajectory is being run again"
+                    self.left[b] -= 1
+                    self.total_done[b] += 1
+                    yield
+                    if self.left[b] == 0:
+                        self.done_count[b] += 1
+                        self.finished += 1
+                        sl.update(phase=EMPTY, b=None)
+                        yield
+                        continue              # the slot takes the next trajectory inside the same segment
+                    # hand-over to a waiting wavefront (ticket), only by a wavefront that holds another live trajectory
+                    other = any(o is not sl and o["phase"] == LIVE for o in slots)
+                    if probe and other and self.room() and self.take_ticket():
+                        yield from self.push(b)
+                        sl.update(phase=DONE, b=None)
+                        break
+                    probe = 0
+                    if slice_on and self.total_done[b] - sl["it0"] >= self.res_iters:
+                        wanted = self.room() and ((fresh_left and self.next < self.B and self.B - self.next <= self.window) or self.avail())
+                        yield
+                        if wanted:
+                            yield from self.push(b)
+                            self.take_ticket()
+                            sl.update(phase=EMPTY, b=None)
+                            continue
+                        sl["it0"] = self.total_done[b]
+                    n_live += 1
+                    break                     # (the trajectory waits for the rollout pass: end of its segment)
+            if n_live == 0:
+                claim, gw = None, 0
+                for g in (1, 0):
+                    if slots[g]["phase"] == CLAIMED:
+                        claim, gw = slots[g]["claim"], g
+                got = None
+                if claim is None and slice_on:
+                    r = yield from self.take_parked()
+                    if r[0] == "b":
+                        got = r[1]
+                    elif r[0] == "claim":
+                        claim = r[1]
+                if got is None:
+                    got = yield from self.wait_for_work(claim)
+                if got is None:
+                    assert all(s["phase"] != CLAIMED for s in slots) or self.finished >= self.B, "left while holding a place"
+                    self.alive[w] = False
+                    return
+                start(slots[gw], got)
+            yield                             # (the rollout pass)
+
+    def run(self):
+        live = list(range(len(self.waves)))
+        steps = 0
+        while live:
+            i = self.rng.choice(live)
+            try:
+                next(self.waves[i])
+            except StopIteration:
+                live.remove(i)
+            steps += 1
+            assert steps < 5_000_000, "the launch does not end"
+        return steps
+
+
+def check(L):
+    assert L.finished == L.B and all(c == 1 for c in L.done_count), (L.finished, L.done_count)
+    assert all(v == 0 for v in L.left)
+    assert not L.q, f"trajectories left in the queue: {L.q}"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_every_trajectory_is_finished_exactly_once_under_random_interleavings(seed):
+    rng = random.Random(1000 + seed)
+    n_waves = rng.choice([1, 2, 3, 5, 8])
+    B = rng.choice([1, 2, 5, 2 * n_waves, 2 * n_waves + 1, 5 * n_waves, 40])
+    iters = [rng.choice([1, 1, 2, 3, 5, 8, 13, 30]) for _ in range(B)]
+    res = rng.choice([0, 1, 2, 3, 5, 12])
+    window = rng.choice([0, n_waves, 2 * n_waves, 4 * n_waves, 10 ** 6])
+    L = Launch(iters, n_waves, res, window, rng)
+    L.run()
+    check(L)
+    assert L.resv <= L.cap and not L.overwritten
+
+
+def test_one_iteration_slices_stop_handing_over_when_the_queue_has_no_room_left():
+    """the case that lost a trajectory on the GPU (ring reuse): with the room check the pushes stop short of the capacity"""
+    rng = random.Random(7)
+    L = Launch([40] * 24, 4, 1, 10 ** 6, rng, per_trajectory=4)
+    L.run()
+    check(L)
+    assert L.resv <= L.cap and not L.overwritten and L.pushes > 24
+    # ... and without it positions wrap: the model's stand-in for the entry that was overwritten before its owner looked
+    L2 = Launch([40] * 24, 4, 1, 10 ** 6, random.Random(7), room_check=False, per_trajectory=4)
+    try:
+        L2.run()
+        lost = L2.overwritten
+    except AssertionError:
+        lost = True
+    assert lost
