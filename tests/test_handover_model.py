@@ -252,3 +252,68 @@ def test_one_iteration_slices_stop_handing_over_when_the_queue_has_no_room_left(
     except AssertionError:
         lost = True
     assert lost
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# rollout_group_long's counted wait (csrc/cilqr_group.hpp, rollout_long_rp): `s_waitcnt vmcnt(20)` before the first read of a
+# chunk of the gains ring is only a wait for that chunk's LDS-DMA if at least 20 vector-memory operations were issued BEHIND
+# the DMA (the counter retires in order) — here the slab stores, three per completed step + two for row 0.  Replay of the
+# function's control flow (the order of need() / fetch / step in the small-angle loop, the hand-over to the general loop at
+# any step, horizons 64 ... 127): at every wait the DMA being waited for has >= 20 younger operations, the chunk a fetch
+# reads is the one last waited for, and a DMA never lands in the ring half that still holds a chunk whose steps have not all
+# been fetched.
+def _replay_rollout(N, hand_over_at):
+    CH = 8
+    nch = (N + CH - 1) // CH
+    ops = []                      # the wavefront's vector-memory operations in issue order: ("dma", chunk) | ("st",)
+    have = 0
+    waited = {0}                  # chunks whose DMA has been waited for
+    half = {}                     # ring half -> chunk it holds (or is being filled with)
+    fetched = set()
+
+    def issue(c):
+        ops.append(("dma", c))
+        # the half it lands in must not hold steps that are still to be fetched
+        old = half.get(c & 1)
+        if old is not None:
+            assert all(s in fetched for s in range(old * CH, min(N, (old + 1) * CH))), (N, hand_over_at, c, old)
+        half[c & 1] = c
+
+    def need(j):
+        nonlocal have
+        c = j // CH
+        if c > have:
+            # s_waitcnt vmcnt(20): everything but the 20 youngest operations has completed
+            pos = max(i for i, o in enumerate(ops) if o == ("dma", c))
+            assert len(ops) - 1 - pos >= 20, (N, hand_over_at, c, len(ops) - 1 - pos)
+            waited.add(c)
+            have = c
+            if c + 1 < nch:
+                issue(c + 1)
+
+    def fetch(j):
+        assert j // CH in waited and half[(j // CH) & 1] == j // CH, (N, hand_over_at, j)
+        fetched.add(j)
+
+    issue(0)                      # (followed by vmcnt(0))
+    if nch > 1:
+        issue(1)
+    ops.append(("st",)); ops.append(("st",))        # row 0 of the trial
+    i = 0
+    fetch(0)
+    small = True
+    while i < N:
+        if i + 1 < N:
+            need(i + 1)
+            fetch(i + 1)
+        if small and i == hand_over_at:
+            small = False         # the small-angle step fails: nothing stored, the general loop takes step i over (no re-fetch)
+        ops.extend([("st",)] * 3)
+        i += 1
+    assert fetched == set(range(N))
+
+
+@pytest.mark.parametrize("N", [64, 65, 71, 72, 73, 96, 100, 120, 127])
+def test_counted_wait_of_the_long_rollout_covers_its_dma(N):
+    for h in list(range(0, N, 5)) + [N - 2, N - 1, N + 1]:   # N + 1: the small-angle loop runs to the end
+        _replay_rollout(N, h)
