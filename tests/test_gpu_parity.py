@@ -1870,18 +1870,18 @@ def test_lost_rows_shape_is_still_what_loses_rows():
     """Round 5 (VERDICT r04 task 5): the real instruction stream of round 4's lost-store anomaly.  ab/libLR.so — the library
     built with -DCILQR_LOSTROWS_REPRO: the grouped rollout pass with its 16-byte slab stores inside waterfall loops — against
     the shipped library, pairs per wavefront against lone wavefronts (scripts/lost_rows_repro.py), with XNACK off (how this
-    pool runs) and with HSA_XNACK=1.  ASSERTED: the shipped library is clean in both modes.  RECORDED (printed, and in
+    pool runs) and with HSA_XNACK=1.  (Round 6: the experiment library is libcilqr_amd_lostrows.so, built by build().)  ASSERTED: the shipped library is clean in both modes.  RECORDED (printed, and in
     profiles/r05_experiments/lost_rows_time_box.txt: 12 of 12 launches, ~290 of 4 100 trajectories with XNACK off, none with
     XNACK on): what the excluded shape does on this box — a hardware / firmware revision that stops losing rows shows up here.
-    Skipped where the experiment library has not been built (it is not part of build())."""
+    Never skipped: the experiment library is built on the spot when it is not there."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "ab", "libLR.so")
-    if not os.path.exists(lib):
-        pytest.skip("ab/libLR.so (build.build_library(out=..., extra_defs=('-DCILQR_LOSTROWS_REPRO',))) is not here")
+    import importlib
+    b = importlib.import_module("toy-example-of-ilqr_amd.build")
+    lib = str(b.build_lostrows())  # part of build(); rebuilt here (hipcc, ~1 min) when absent or older than the sources: never skipped
     seen = {}
     for which in ("shipped", "repro"):
         for xnack in (None, "1"):
@@ -1894,8 +1894,6 @@ def test_lost_rows_shape_is_still_what_loses_rows():
                 env["CILQR_AMD_LIB"] = lib
             r = subprocess.run([sys.executable, os.path.join(root, "scripts", "lost_rows_repro.py"), "2"], capture_output=True,
                                text=True, timeout=600, env=env)
-            if which == "repro" and r.returncode != 0 and "undefined symbol" in r.stderr:
-                pytest.skip("ab/libLR.so is older than the C-ABI (rebuild it with -DCILQR_LOSTROWS_REPRO)")
             assert r.returncode == 0, r.stderr[-2000:]
             seen[(which, xnack)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print({f"{k[0]} xnack={k[1]}": v["mismatching_trajectories_per_launch"] for k, v in seen.items()})

@@ -15,6 +15,9 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcilqr_amd.so"
 LIB_DEV = PKG / "libcilqr_amd_dev.so"
+# NOT a product: the library with round 4's lost-store instruction shape compiled back in (-DCILQR_LOSTROWS_REPRO), kept next to
+# the shipped ones so that tests/test_gpu_parity.py::test_lost_rows_shape_is_still_what_loses_rows runs wherever the suite runs
+LIB_LOSTROWS = PKG / "libcilqr_amd_lostrows.so"
 OBJ = PKG / "build"
 GROUPS = 8
 
@@ -95,6 +98,11 @@ def build_library(force=False, verbose=False, dev=False, out=None, jobs=None, ex
     return lib
 
 
+def build_lostrows(force=False, verbose=False):
+    """the anomaly-regression library (see LIB_LOSTROWS); nothing in the package loads it"""
+    return build_library(force, verbose, out=LIB_LOSTROWS, extra_defs=("-DCILQR_LOSTROWS_REPRO",))
+
+
 def build_examples(force=False, verbose=False):
     """host C++ driver on top of the C-ABI (plain g++, links libcilqr_amd.so)"""
     src = ROOT / "examples" / "headless_planner.cpp"
@@ -114,5 +122,6 @@ def build_examples(force=False, verbose=False):
 def build_all(force=False, verbose=False):
     lib = build_library(force, verbose)
     build_library(force, verbose, dev=True)
+    build_lostrows(force, verbose)
     build_examples(force, verbose)
     return lib
