@@ -266,7 +266,7 @@ class GpuRun:
             per_launch = [self.eng.slot_kernel_ms(k) for k in range(K)]
             ident = all(bool(torch.equal(o[0], outs[0][0])) and bool(torch.equal(o[1], outs[0][1])) and bool(torch.equal(o[2], outs[0][2]))
                         for o in outs[1:])
-            extra = {"in_flight": K, "kernel_region_ms": region_ms,
+            extra = {"in_flight": K, "steps": steps, "kernel_region_ms": region_ms,
                      "kernel_ms_of_one_launch_while_overlapped (last launch of each slot)": per_launch,
                      "mean_launches_overlapping": float(np.mean(per_launch)) * steps / region_ms if region_ms > 0 else None,
                      "buffer_sets_identical": ident}
@@ -347,9 +347,56 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+_DEVICE_CODE_CACHE = {}
+
+
+def device_code_unchanged(manifest_rel):
+    """Are the INSTRUCTIONS of the library this process runs the ones the counter passes were collected on?  The source stamp
+    (csrc_fingerprint) moves with any host-side edit of csrc/; this compares the machine code of every kernel and out-of-line
+    device function inside libcilqr_amd.so with the manifest recorded at collection (scripts/device_code_identity.py).
+    None when it cannot be answered (no manifest recorded, LLVM tools missing)."""
+    if not manifest_rel:
+        return None
+    if manifest_rel in _DEVICE_CODE_CACHE:
+        return _DEVICE_CODE_CACHE[manifest_rel]
+    ans = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import device_code_identity as dci
+        ref = json.load(open(os.path.join(ROOT, manifest_rel)))["functions"]
+        ref = {k: sorted([list(x) for x in v]) for k, v in ref.items()}
+        r = dci.compare(ref, dci.manifest(os.path.join(ROOT, "toy-example-of-ilqr_amd", "libcilqr_amd.so")))
+        solve = [n for n in r["changed"] + r["missing"] if "k_solve" in n]
+        ans = {"manifest": manifest_rel, "functions_same": r["same"], "functions_changed": len(r["changed"]),
+               "functions_missing": len(r["missing"]), "functions_added": len(r["added"]),
+               "all_solve_kernels_unchanged": not solve, "everything_unchanged": not r["changed"] and not r["missing"]}
+    except Exception as e:  # noqa: BLE001
+        ans = {"error": f"{type(e).__name__}: {e}"[:200]}
+    _DEVICE_CODE_CACHE[manifest_rel] = ans
+    return ans
+
+
 def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None, flight=None):
+    """kernel_ms: the average duration of ONE launch with nothing else in flight (HIP events around every launch) — what
+    rocprofv3's per-kernel average of `--in-flight 1` shows and what the counter passes of pmc_current.json ran as.  When the
+    timed region kept several batches in flight, the region's effective per-launch time is reported under
+    in_flight.effective (throughput, not a kernel duration)."""
     N, M_of = wl.N, wl.M_of
     alg_bytes_launch = float((res["iters"] * pkg.workloads.bytes_per_iteration(N, M_of)).sum())
+    eff_ms = None
+    if flight and flight.get("in_flight", 1) > 1:
+        eff_ms = flight.get("kernel_region_ms", 0.0) / max(1, flight.get("steps", 1)) or None
+        seq = (flight.get("sequential") or {}).get("kernel_ms")
+        if seq:
+            kernel_ms = seq
+        flight = dict(flight)
+        if eff_ms:
+            flight["effective"] = {"kernel_ms": eff_ms, "achieved_GBs": alg_bytes_launch / (eff_ms * 1e-3) / 1e9,
+                                   "frac": alg_bytes_launch / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "what": "kernel time of the whole timed region (two HIP events: first launch enqueued ... every "
+                                           "launch slot joined) / launches; the launches overlap, so this is a throughput figure — "
+                                           "rocprofv3's per-kernel average of the default command is the OVERLAPPED duration of one "
+                                           "launch (kernel_ms_of_one_launch_while_overlapped), longer than either"}
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
     pmc = counters_for(wl.name) if world == 1 else None
     traffic = traffic_src = valu = None
@@ -364,7 +411,8 @@ def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None, flight=None
         now = csrc_fingerprint()
         traffic_meta = {"collected_at_git": meta.get("git"), "collected_on_csrc_sha16": meta.get("csrc_sha16"),
                         "this_run_csrc_sha16": now, "collected_with_in_flight": meta.get("in_flight", 1),
-                        "stale": (meta.get("csrc_sha16") != now)}
+                        "stale": (meta.get("csrc_sha16") != now),
+                        "device_code": device_code_unchanged(meta.get("device_code_manifest"))}
         if pmc.get("SQ_INSTS_VALU"):
             # the bound that actually applies: vector-instruction issue.  Wave instructions per launch from the
             # SQ counter pass, 4 cycles of a SIMD each at best, against all SIMD-cycles of the live kernel time
@@ -401,12 +449,10 @@ def roofline_block(pkg, wl, res, kernel_ms, world, launch_info=None, flight=None
                           "command — a static file, not this run",
             "kernel": ("k_solve_grp" if (launch_info or {}).get("trajectories_per_wavefront", 1) > 1 else "k_solve"),
             "launch": launch_info, "kernel_ms": kernel_ms,
-            "kernel_ms_is": ("average duration of a launch, one launch at a time (HIP events around every launch)" if not flight else
-                             "EFFECTIVE duration of a launch: kernel time of the whole timed region (two HIP events: first launch enqueued "
-                             "... every launch slot joined) / launches — the launches of the region overlap (batches in flight inside the "
-                             "handle), so achieved = the region's algorithmic bytes / the region's kernel time; rocprofv3's average "
-                             "duration of the kernel in the same command is the OVERLAPPED duration of one launch (next field), "
-                             "`sequential` has the one-at-a-time figure of rounds 1-4"),
+            "kernel_ms_is": "average duration of a launch, one launch at a time (HIP events around every launch); with batches in "
+                            "flight in the timed region: of the sequential leg timed right after it (in_flight.sequential), and "
+                            "in_flight.effective has the region's own figure.  achieved / frac / valu_issue / fp64_useful all use "
+                            "this duration — the mode the counter passes ran in",
             "in_flight": flight or {"in_flight": 1},
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "algorithmic_bytes_per_iteration": "16(6N+4) + 24M(N+1) (SURVEY.md 8(d))",
@@ -660,7 +706,10 @@ def main():
     stats, tmax = st_mod.reduce_stats(st_mod.local_stats(res, N, wl.M_of), elapsed, dist, red_dev)
     value = stats[0] * args.steps / tmax
     # every rank's own clock and kernel time: a straggler rank (or a GPU that throttles) is visible in the line
+    seq_main = (flight_main or {}).get("sequential") or {}
     per_rank = gather_objects(dist, {"rank": rank, "elapsed_s": elapsed, "kernel_ms": kernel_ms,
+                                     "kernel_ms_one_batch_at_a_time": seq_main.get("kernel_ms", kernel_ms),
+                                     "ms_per_step_one_batch_at_a_time": seq_main.get("ms_per_step", elapsed / args.steps * 1e3),
                                      "iterations_per_step": float(res["iters"].sum())}, world)
     gpu_u = gpu_x = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -709,7 +758,9 @@ def main():
                                    "the bit-identity with the oracle's detmath build in this object")
         return {"cpu_check": cpu_chk, "workload": wl_s.name, "baseline_config": cfg, "batch_per_gpu": B_s, "global_batch": int(st_s[8]),
                 "horizon": wl_s.N, "steps": steps_side, "value": st_s[0] * steps_side / tmax_s, "unit": "iLQR iterations/s",
-                "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": kms_s, "in_flight": rl["in_flight"],
+                "ms_per_step": tmax_s / steps_side * 1e3, "kernel_ms": rl["kernel_ms"],
+                "kernel_ms_is": "one launch at a time (in_flight.effective.kernel_ms: the timed region's launches / its kernel time)",
+                "in_flight": rl["in_flight"],
                 "kernel_ms_min_max_over_ranks": [float(min(pr_s)), float(max(pr_s))],
                 "iterations_per_launch_rank0": float(res_s["iters"].sum()),
                 "slowest_trajectory_iterations": int(res_s["iters"].max()),
@@ -774,6 +825,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # the two ways of running the same K steps, by name: `value` is the first — the timed region of this
+            # command; the second is the sequential leg timed right after it (rounds 1-4 reported that one)
+            "value_is": (f"value_batches_in_flight_{args.in_flight}" if args.in_flight > 1 else "value_one_batch_at_a_time"),
+            f"value_batches_in_flight_{max(1, args.in_flight)}": value,
+            "value_one_batch_at_a_time": float(sum(r["iterations_per_step"] for r in per_rank)
+                                               / (max(r["ms_per_step_one_batch_at_a_time"] for r in per_rank) * 1e-3)),
+            "kernel_ms_one_batch_at_a_time": float(max(r["kernel_ms_one_batch_at_a_time"] for r in per_rank)),
             "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B, "batches_in_flight": args.in_flight,
                        "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
                        "parallelism": f"trajectory-sharded x{world}, "

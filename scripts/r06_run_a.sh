@@ -14,7 +14,7 @@ python - "$OUT/bench.json" <<'PY'
 import json,sys
 b=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
 r=b['roofline']; e=b['extra']
-print('headline', '%.4g it/s'%b['value'], 'ms/step %.3f'%b['ms_per_step'], 'eff kernel_ms %.3f'%r['kernel_ms'], r['in_flight'])
+print('headline', '%.4g it/s'%b['value'], 'ms/step %.3f'%b['ms_per_step'], 'kernel_ms one at a time %.3f'%r['kernel_ms'], 'value one at a time %.4g'%b['value_one_batch_at_a_time'], r['in_flight'])
 for k in ('config2_latency','config3','config4_sharded','config5_alm'):
     x=e.get(k)
     print(k, x and {kk:x.get(kk) for kk in ('value','ms_per_step','kernel_ms','in_flight','error')})

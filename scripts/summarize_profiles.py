@@ -124,8 +124,19 @@ if pmc_all:
             st_ = json.load(open(stamp))
             rev, dirty, sha = st_.get("git", rev), st_.get("csrc_dirty_at_collection", dirty), st_.get("csrc_sha16", sha)
         cur = dict(pmc_all)
+        # the machine code the passes ran (scripts/device_code_identity.py): bench.py compares the library it runs with this
+        manifest_rel = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import device_code_identity as dci
+            manifest_rel = f"profiles/{tag}_device_code.json"
+            json.dump({"lib": "libcilqr_amd.so", "functions": dci.manifest(os.path.join(ROOT, "toy-example-of-ilqr_amd", "libcilqr_amd.so"))},
+                      open(os.path.join(ROOT, manifest_rel), "w"), indent=0, sort_keys=True)
+        except Exception as e:  # noqa: BLE001
+            print("no device-code manifest:", e, file=sys.stderr)
+            manifest_rel = None
         cur["_collected"] = {"git": rev, "csrc_dirty_at_collection": dirty, "csrc_sha16": sha, "in_flight": 1,
-                             "tag": tag, "how": "scripts/collect_profiles.sh: one counter group per rocprofv3 pass, launches one at a time"}
+                             "device_code_manifest": manifest_rel, "tag": tag, "how": "scripts/collect_profiles.sh: one counter group per rocprofv3 pass, launches one at a time"}
         json.dump(cur, open(os.path.join(dst, "pmc_current.json"), "w"), indent=1)
 
 other = {"note": "python bench.py --config C [--batch B] --steps 3..5 --warmup 1 --no-cpu-baseline --no-extras on one "
