@@ -134,9 +134,35 @@ struct orc_solver {
 static void ensure_alm(struct orc_solver* s, int cols);
 
 /* ---------- small dense helpers: C(m x n) = A(m x k) * B(k x n), row-major ---------- */
+/* ORC_SUM4 (round 6, an EXPERIMENT flag; the shipped checkers are built without it): how a four-term inner product is
+ * associated.  The reference leaves that to Eigen (cs:211-212, 400-436, 449-451: products of 4 x 4 / 4 x 2 blocks and 4-vectors)
+ * and Eigen is neither vendored nor pinned upstream, so which of its evaluators the reference binary runs cannot be checked here:
+ *   0 (default)  index order        ((p0 + p1) + p2) + p3   Eigen's coefficient-based product without vectorisation
+ *   1            adjacent pairs     (p0 + p1) + (p2 + p3)   the shape of Eigen's redux_novec_unroller (balanced tree)
+ *   2            interleaved pairs  (p0 + p2) + (p1 + p3)   two-lane SSE2 packets accumulating even / odd terms, then predux
+ * Two-term products are the same in every mode (a + b is commutative).  tests/sum_order_tolerance.py measures how far the
+ * solves move between the modes. */
+#ifndef ORC_SUM4
+#define ORC_SUM4 0
+#endif
+int orc_sum4(void) { return ORC_SUM4; }
+
+#if ORC_SUM4 == 1
+#define ORC_SUM4_OF(p0, p1, p2, p3) (((p0) + (p1)) + ((p2) + (p3)))
+#elif ORC_SUM4 == 2
+#define ORC_SUM4_OF(p0, p1, p2, p3) (((p0) + (p2)) + ((p1) + (p3)))
+#endif
+
 static void matmul(const double* A, const double* B, double* C, int m, int k, int n) {
     for (int i = 0; i < m; ++i) {
         for (int j = 0; j < n; ++j) {
+#ifdef ORC_SUM4_OF
+            if (k == 4) {
+                C[i * n + j] = ORC_SUM4_OF(A[i * 4] * B[j], A[i * 4 + 1] * B[n + j], A[i * 4 + 2] * B[2 * n + j],
+                                           A[i * 4 + 3] * B[3 * n + j]);
+                continue;
+            }
+#endif
             double acc = A[i * k] * B[j];
             for (int t = 1; t < k; ++t) {
                 acc = acc + A[i * k + t] * B[t * n + j];
@@ -148,6 +174,12 @@ static void matmul(const double* A, const double* B, double* C, int m, int k, in
 
 /* the same product with the accumulation written as CQ_MADD: the sites F1-F3 (identical to matmul unless ORC_FUSED) */
 static void matmul_f(const double* A, const double* B, double* C, int m, int k, int n) {
+#ifdef ORC_SUM4_OF
+    if (k == 4) {
+        matmul(A, B, C, m, k, n);
+        return;
+    }
+#endif
     for (int i = 0; i < m; ++i) {
         for (int j = 0; j < n; ++j) {
             double acc = A[i * k] * B[j];

@@ -4,7 +4,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 shipped package (toy-example-of-ilqr_amd/) never does.  Two builds are wrapped:
 ``Oracle("det")``  -> liboracle_det.so  (elementary functions from csrc/detmath.h: bit-identical to
 the HIP kernels) and ``Oracle("libm")`` -> liboracle_libm.so (glibc libm, as the reference uses); ``Oracle("fused")`` ->
-liboracle_fused.so, the round-4 experiment (detmath + explicit fma at four named groups of sites).
+liboracle_fused.so, the round-4 experiment (detmath + explicit fma at four named groups of sites); ``Oracle("tree")`` /
+``Oracle("pkt")`` -> the round-6 experiment builds of the libm flavour (ORC_SUM4: another association of four-term sums).
 """
 import ctypes as C
 import pathlib
@@ -103,7 +104,7 @@ class Scene:
 
 class Oracle:
     def __init__(self, mode="det"):
-        assert mode in ("det", "libm", "fused", "rec", "det!")
+        assert mode in ("det", "libm", "fused", "rec", "det!", "tree", "pkt")
         # round-4 experiment: CILQR_ORACLE_FUSED=1 makes "det" mean the fused-flavour build (detmath + explicit fma at four
         # named groups of sites), the checker of a device library compiled with -DCILQR_FUSED; "det!" = the detmath build
         # whatever the environment says (the test that compares the two flavours)
@@ -159,9 +160,12 @@ class Oracle:
             fn.restype = res
             fn.argtypes = args
         self.lib = lib
-        assert lib.orc_math_mode() == (0 if mode in ("libm", "rec") else 1)
+        assert lib.orc_math_mode() == (0 if mode in ("libm", "rec", "tree", "pkt") else 1)
         lib.orc_fused.restype = C.c_int
         assert lib.orc_fused() == (1 if mode == "fused" else 0)
+        # round-6 experiment builds (libm flavour): four-term inner products as adjacent / interleaved pairs (ORC_SUM4)
+        lib.orc_sum4.restype = C.c_int
+        assert lib.orc_sum4() == {"tree": 1, "pkt": 2}.get(mode, 0)
 
     # ---- solver object ----
     def solver(self, params):

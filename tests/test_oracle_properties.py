@@ -191,3 +191,29 @@ def test_fused_flavour_of_the_oracle_is_a_different_but_close_arithmetic(pkg_cpu
     assert (det["res"]["iters"] == fus["res"]["iters"]).all()
     assert not np.array_equal(det["x"], fus["x"])
     assert np.abs(det["x"] - fus["x"]).max() < 1e-9 and np.abs(det["res"]["J_final"] - fus["res"]["J_final"]).max() < 1e-9
+
+
+def test_sum_order_of_eigens_inner_products_bounded(pkg):
+    """Round 6 (VERDICT r05 task 7): the one piece of the reference's arithmetic nothing upstream-runnable pins — how Eigen
+    associates the four-term inner products of cs:211-212, 400-436, 449-451 — bounded by its consequence.  The oracle's libm
+    flavour rebuilt with those sums as adjacent pairs (liboracle_tree.so) and as interleaved pairs (liboracle_pkt.so) against
+    the default index-order build (tests/sum_order_tolerance.py; full-size table: profiles/r06_sum_order_tolerance.json):
+    * the builds really differ (no row bit-identical) and every leaf without a four-term sum is untouched,
+    * three_bend starts (config 3 / 5 recipe): every row within 1e-5 with the same decision counters, whatever the association,
+    * straight-lane starts (config 2): whatever leaves the band is a row the default build does not reproduce itself on when
+      x0 moves by one ulp (the yardstick of test_libm_tolerance_diagnosis_on_the_detmath_twin)."""
+    import sum_order_tolerance as so
+    from oracle import Oracle
+    rng = np.random.default_rng(5)
+    x, u = rng.normal(size=4), rng.normal(size=2) * 0.1
+    for m in ("tree", "pkt"):  # no four-term sum in the vehicle model: identical bits
+        assert np.array_equal(Oracle(m).propagate(x, u, 0.1, 2.8, 1), Oracle("libm").propagate(x, u, 0.1, 2.8, 1))
+    r3 = so.analyse(pkg.workloads.config3(B=192, N=50), threads=4, with_spread=False)
+    for m, e in r3["modes"].items():
+        assert e["bit_identical_rows"] < 192, (m, e)
+        assert e["within_1e-5"] == 192 and e["same_decision_counters"] == 192, (m, e)
+        assert e["gap_percentiles_50_90_99_max"][-1] < 1e-8, (m, e)
+    r2 = so.analyse(pkg.workloads.config2(B=192, N=50), threads=4)
+    for m, e in r2["modes"].items():
+        assert e["well_conditioned_rows_outside_1e-5"] == 0, (m, e)
+        assert e["every_row_obeys gap <= max(1e-5, 2 x spread)"], (m, e)
