@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What could a scheduler do for the 8192-trajectory launches?  Replays the MEASURED per-trajectory solve times of a
-launch (block timeline: profiles/rNN_timeline_cK_raw.npz, written by scripts/block_timeline.py on the GPU box) through
+launch (block timeline: gpurun_out/TAG/timeline_cK.npy or an .npz of it (raw records are scratch, not tracked), written by scripts/block_timeline.py on the GPU box) through
 list schedulers on the chip's 2048 resident-wavefront slots:
 
   fifo      pull order as measured (the persistent blocks of the library)                      -> reproduces the launch
@@ -15,7 +15,7 @@ A trajectory's measured time is spread over its iterations in proportion to (a +
 fitted to the launch itself; iterations and trials per iteration come from the CPU oracle's decision trace (TEST
 INFRASTRUCTURE: this script imports oracle/, the library never does).  No GPU needed.
 
-    python scripts/schedule_sim.py --config 3 --timeline profiles/r03_v1_timeline_c3_raw.npz [--out profiles/r03_schedule_sim_c3.json]
+    python scripts/schedule_sim.py --config 3 --timeline gpurun_out/TAG/timeline_c3.npy [--out profiles/r03_schedule_sim_c3.json]
 """
 import argparse
 import heapq

@@ -222,12 +222,8 @@ for c in (3, 4, 5):
         p = os.path.join(src, f"timeline_config{c}{suffix}.json")
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, f"{tag}_timeline_config{c}{suffix}.json"))
-    # the raw per-trajectory records (start, end, block, XCC): what scripts/schedule_sim.py replays
-    p = os.path.join(src, f"timeline_c{c}.npy")
-    if os.path.exists(p) and c in (3, 4):
-        import numpy as np
-        tl = np.load(p)
-        np.savez_compressed(os.path.join(dst, f"{tag}_timeline_c{c}_raw.npz"), start_end_block_xcc=tl)
+    # the raw per-trajectory records (start, end, block, XCC: what scripts/schedule_sim.py replays) stay where the collection
+    # put them, gpurun_out/TAG/timeline_cN.npy — scratch, not tracked (round 6: profiles/ holds summaries only)
 b = last_json(os.path.join(src, "two_rank.json"))
 if b:
     json.dump({"command": "CILQR_BENCH_ONE_DEVICE=1 CILQR_BENCH_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 "

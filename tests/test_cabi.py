@@ -25,6 +25,21 @@ def test_header_symbols_are_exported(pkg):
     assert set(names) == set(pkg._lib.SIGNATURES), set(names) ^ set(pkg._lib.SIGNATURES)
 
 
+def test_nothing_but_the_cabi_is_exported(pkg):
+    """Round 6 (hygiene): the dynamic symbol table of every built library is include/cilqr_amd.h and nothing else —
+    no kernel handle, __device_stub__ wrapper or compilation-unit id (csrc/exports.map, a linker version script)."""
+    import subprocess
+    libs = [pkg._lib.LIB_PATH, pkg._lib.LIB_PATH_DEV]
+    lost = pkg._lib.LIB_PATH.parent / "libcilqr_amd_lostrows.so"
+    if lost.exists():
+        libs.append(lost)
+    for lib in libs:
+        out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert names and all(n.startswith("cilqr_") for n in names), (lib.name, [n for n in names if not n.startswith("cilqr_")][:5])
+        assert set(names) == set(declared_symbols()), (lib.name, set(names) ^ set(declared_symbols()))
+
+
 def test_development_library_exports_the_same_abi(pkg):
     """libcilqr_amd_dev.so (-DCILQR_DEV_BUILD: + testing aids, cycle accounting, CILQR_TUNE) is the same C-ABI; the
     production library carries none of the testing-aid builds of the solve kernel."""

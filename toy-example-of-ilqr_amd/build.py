@@ -62,7 +62,7 @@ def hipcc_path():
 
 def _deps():
     return [CSRC / "cilqr_amd.hip", CSRC / "cilqr_solve_inst.hip", CSRC / "scenario.cpp", CSRC / "cilqr_kernels.hpp",
-            CSRC / "cilqr_device.hpp", CSRC / "cilqr_group.hpp", CSRC / "detmath.h", ROOT / "include" / "cilqr_amd.h",
+            CSRC / "cilqr_device.hpp", CSRC / "cilqr_group.hpp", CSRC / "detmath.h", CSRC / "exports.map", ROOT / "include" / "cilqr_amd.h",
             pathlib.Path(__file__)]  # the flags live in this file
 
 
@@ -94,7 +94,8 @@ def build_library(force=False, verbose=False, dev=False, out=None, jobs=None, ex
         futs = [ex.submit(_run, [hipcc] + HIP_FLAGS + defs + extra + ["-c", src, "-o", obj], verbose) for src, obj, extra in units]
         for f in futs:
             f.result()
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--strip-all"] + [obj for _, obj, _ in units] + ["-o", lib], verbose)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--strip-all", f"-Wl,--version-script={CSRC / 'exports.map'}"]
+         + [obj for _, obj, _ in units] + ["-o", lib], verbose)
     return lib
 
 

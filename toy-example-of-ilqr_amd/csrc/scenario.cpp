@@ -162,6 +162,46 @@ extern "C" int cilqr_reference_line_position(const double* wx, const double* wy,
     return CILQR_OK;
 }
 
+namespace {
+// Where a vehicle stands on the road (mp:122-143): on every centre line the distance to the vehicle is followed sample by
+// sample from the line's start until it first grows — the sample before that is the line's candidate (a line whose distance
+// never grows has none) — and the vehicle is put on the line with the closest candidate; ties keep the earlier line.
+struct Foothold {
+    size_t lane;
+    double s;
+};
+
+inline bool first_distance_minimum(const Line& ln, double px, double py, double* dist, double* s_at) {
+    if (ln.x.empty()) return false;
+    double before = std::hypot(ln.x[0] - px, ln.y[0] - py);
+    for (size_t i = 1; i < ln.x.size(); ++i) {
+        const double here = std::hypot(ln.x[i] - px, ln.y[i] - py);
+        if (here > before) {
+            *dist = before;
+            *s_at = ln.longitude[i - 1];
+            return true;
+        }
+        before = here;
+    }
+    return false;
+}
+
+inline Foothold nearest_foothold(const std::vector<Line>& lanes, double px, double py, double s_if_none) {
+    Foothold best{0, s_if_none};
+    bool have = false;
+    double best_dist = 0.0;
+    for (size_t l = 0; l < lanes.size(); ++l) {
+        double dist, s_at;
+        if (first_distance_minimum(lanes[l], px, py, &dist, &s_at) && (!have || dist < best_dist)) {
+            have = true;
+            best_dist = dist;
+            best = Foothold{l, s_at};
+        }
+    }
+    return best;
+}
+}  // namespace
+
 extern "C" int cilqr_build_routes(const double* wx, const double* wy, int32_t n,
                                   const double* center_widths, int32_t n_center, double accuracy,
                                   const double* init_cond, int32_t V, double max_simulation_time,
@@ -175,55 +215,31 @@ extern "C" int cilqr_build_routes(const double* wx, const double* wy, int32_t n,
     std::vector<Line> center_lines;
     for (int l = 0; l < n_center; ++l) center_lines.push_back(sample_line(sp, center_widths[l], accuracy));
 
-    int32_t T = 0;
-    for (double t = 0.0; t < max_simulation_time + 10; t += delta_t) ++T;
+    // the sampling instants, accumulated exactly as upstream accumulates them (mp:146: `t += delta_t`)
+    std::vector<double> instants;
+    for (double t = 0.0; t < max_simulation_time + 10; t += delta_t) instants.push_back(t);
+    const int32_t T = static_cast<int32_t>(instants.size());
     *T_out = T;
     if (!routes) return CILQR_OK;
     if (T_cap < T) return CILQR_ERR_BAD_ARG;
 
-    for (int idx = 0; idx < V; ++idx) {
-        const double* ic = init_cond + idx * 4;
-        // nearest-sample search per centre line (motion_planning.cpp:123-143)
-        size_t line_num = 0;
-        double start_s = sp.s.back();  // center_lines[0].length()
-        double min_diff = -1.0;
-        for (size_t l = 0; l < center_lines.size(); ++l) {
-            const Line& cl = center_lines[l];
-            for (size_t i = 1; i < cl.x.size(); ++i) {
-                const double last_diff = std::hypot(cl.x[i - 1] - ic[0], cl.y[i - 1] - ic[1]);
-                const double cur_diff = std::hypot(cl.x[i] - ic[0], cl.y[i] - ic[1]);
-                if (cur_diff > last_diff) {
-                    if (min_diff < 0 || last_diff < min_diff) {
-                        min_diff = last_diff;
-                        line_num = l;
-                        start_s = cl.longitude[i - 1];
-                    }
-                    break;
-                }
-            }
-        }
-        if (line_num_out) line_num_out[idx] = static_cast<int32_t>(line_num);
-        if (start_s_out) start_s_out[idx] = start_s;
-        const Line& cl = center_lines[line_num];
-        const double width = center_widths[line_num];
-        int32_t k = 0;
-        for (double t = 0.0; t < max_simulation_time + 10; t += delta_t, ++k) {
-            double cur_s = 0.;
-            double pos[3];
-            if (ic[3] <= M_PI_2) {
-                cur_s = start_s + t * ic[2];
-                cur_s = std::min(cur_s, cl.longitude.back());
-                line_position(sp, width, cur_s, pos);
-            } else {
-                cur_s = start_s - t * ic[2];
-                cur_s = std::max(cur_s, cl.longitude.front());
-                line_position(sp, width, cur_s, pos);
-                pos[2] = std::fmod(pos[2] + M_PI, 2 * M_PI);
-            }
-            double* r = routes + (static_cast<size_t>(idx) * T_cap + k) * 3;
-            r[0] = pos[0];
-            r[1] = pos[1];
-            r[2] = pos[2];
+    for (int v = 0; v < V; ++v) {
+        const double* start = init_cond + v * 4;  // (x, y, speed, yaw)
+        const Foothold fh = nearest_foothold(center_lines, start[0], start[1], sp.s.back());
+        if (line_num_out) line_num_out[v] = static_cast<int32_t>(fh.lane);
+        if (start_s_out) start_s_out[v] = fh.s;
+        const Line& lane = center_lines[fh.lane];
+        // a lane has no driving direction upstream: it is read off the initial yaw (mp:150-158).  Travelling against the
+        // lane = arc length running down, clamped at the lane's first sample, heading turned by pi
+        const bool with_lane = start[3] <= M_PI_2;
+        const double dir = with_lane ? 1.0 : -1.0;
+        const double s_stop = with_lane ? lane.longitude.back() : lane.longitude.front();
+        double* route = routes + static_cast<size_t>(v) * T_cap * 3;
+        for (size_t k = 0; k < instants.size(); ++k, route += 3) {
+            const double s_free = fh.s + dir * (instants[k] * start[2]);  // +-1 x p is exact: == start_s -+ t * speed
+            const double s_at = with_lane ? std::min(s_free, s_stop) : std::max(s_free, s_stop);
+            line_position(sp, center_widths[fh.lane], s_at, route);
+            if (!with_lane) route[2] = std::fmod(route[2] + M_PI, 2 * M_PI);
         }
     }
     return CILQR_OK;
