@@ -92,9 +92,9 @@ int main(int argc, char** argv) {
         mix(ub.data(), ub.size() * sizeof(double));
         mix(xb.data(), xb.size() * sizeof(double));
         for (const auto& r : res) { mix(&r.J_final, sizeof(double)); mix(&r.iters, sizeof(int)); mix(&r.ls_trials, sizeof(int)); mix(&r.end_reason, sizeof(int)); }
-        std::printf("batch %lld horizon %d devices %d iters %lld ls_trials %lld converged %lld max_lamb %lld max_iter %lld bad_input %lld nan %lld "
+        std::printf("batch %lld horizon %d devices %d iters %lld ls_trials %lld converged %lld max_lamb %lld max_iter %lld bad_input %lld not_solved %lld nan %lld "
                     "sum_J_final %.17g checksum %016llx\n", batch, Nb, sh.devices(), st.iters, st.ls_trials, st.converged, st.max_lamb,
-                    st.max_iter, st.bad_input, st.nan_costs, st.sum_J_final, hsh);
+                    st.max_iter, st.bad_input, st.not_solved, st.nan_costs, st.sum_J_final, hsh);
         return 0;
     }
     if (argc > 3) p.N = std::atoi(argv[3]);

@@ -78,7 +78,16 @@ enum {
      * device-pointer entry point reports it this way (its index arrays cannot be checked on the host): u, x
      * and the costs of that trajectory are NaN, iters = 0.  The host-pointer entry points return
      * CILQR_ERR_BAD_ARG / CILQR_ERR_OBSTACLE_HORIZON before launching anything. */
-    CILQR_END_BAD_INPUT = 3
+    CILQR_END_BAD_INPUT = 3,
+    /* not solved, and not by the caller's doing: the launch never finished this trajectory.  Every launch that hands
+     * trajectories from wavefront to wavefront (pairs per wavefront: sliced solves, idle wavefronts at the tail; resumable solves
+     * and work sharing of the long-horizon builds) first marks EVERY result of the batch with this value (J_init = J_final = NaN,
+     * iters = 0) on the launch stream; whoever finishes a trajectory overwrites the mark.  A bounded wait of the hand-over
+     * protocol that expired leaves the trajectory that was in transit marked — it cannot be mistaken for a result (upstream,
+     * cs:144-152, returns every solve's (u, x): a missing one must be loud) — and the same launch is reported by cilqr_wait /
+     * cilqr_solve_batch as CILQR_ERR_DEVICE.  Never observed outside the test that forces it (development library,
+     * CILQR_TUNE=grp_wait_spins). */
+    CILQR_END_NOT_SOLVED = 4
 };
 
 /* The non-ego arguments of one solve() call, shared by many trajectories of a batch:
@@ -165,9 +174,11 @@ int cilqr_solve_cache_stats(cilqr_handle* h, int64_t* uploads, int64_t* reuses);
  * ONE LAUNCH PER HANDLE AT A TIME: the scratch areas, the persistent blocks' trajectory counter and the work-sharing
  * state belong to the handle.  Launches of one handle are therefore ordered on the device — a launch on another
  * stream than the handle's previous one waits for it (hipStreamWaitEvent) — and do not overlap; independent batches
- * that should overlap take one handle each (and one stream each).  A hand-off failure of the work sharing between
- * blocks (a bounded wait that ran out: the owner then costs the trial itself, results stay correct) is reported by
- * cilqr_solve_batch as CILQR_ERR_DEVICE and to device-entry callers through cilqr_work_sharing_stats()[3]. */
+ * that should overlap take one handle each (and one stream each).  A hand-off failure inside a launch (a bounded wait that
+ * ran out — work sharing between blocks: the owner then costs the trial itself, results stay correct; a trajectory handed from
+ * wavefront to wavefront: its result keeps the CILQR_END_NOT_SOLVED mark) is latched in the handle whichever launch slot it
+ * happened in and however many launches followed: cilqr_solve_batch and the next cilqr_wait return CILQR_ERR_DEVICE (once;
+ * the latch is cleared by the report), cilqr_work_sharing_stats()[3] shows it without clearing. */
 int cilqr_solve_batch_device(cilqr_handle* h, int32_t B, const double* d_x0,
                              const int32_t* d_scenario_id, const int32_t* d_param_id,
                              const int32_t* d_tick, const double* d_last_u, double* d_u_out,
@@ -246,9 +257,10 @@ int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
  * over the horizon) share one pass of the instruction stream and whose backward sweeps (cs:383-440) run as one, a
  * trajectory per half-wavefront; 0 or 1 = one trajectory per wavefront everywhere; 2 = two wherever that build can run (any
  * batch size).  Results are identical in every mode.  A launch in pairs hands trajectories from wavefront to wavefront
- * (sliced solves, idle wavefronts at its tail); should a bounded wait inside it ever expire, cilqr_solve_batch returns
- * CILQR_ERR_DEVICE and the device-pointer entry points report it through cilqr_work_sharing_stats out[3] (a trajectory
- * that was being handed over may then be missing from the outputs — never observed: 26 k stress launches). */
+ * (sliced solves, idle wavefronts at its tail); should a bounded wait inside it ever expire, the trajectory that was in transit
+ * keeps end_reason = CILQR_END_NOT_SOLVED in its cilqr_result (every result is pre-marked on the launch stream), and
+ * cilqr_solve_batch / the next cilqr_wait return CILQR_ERR_DEVICE — whichever launch slot it happened in (never observed in
+ * 52 k stress launches; forced by tests/test_gpu_parity.py::test_a_lost_hand_over_is_loud). */
 int cilqr_set_group_mode(cilqr_handle* h, int32_t mode);
 
 /* Work sharing between blocks (horizons above 63, batches beyond the helper range): 1 (default) = blocks that find no
@@ -257,8 +269,8 @@ int cilqr_set_group_mode(cilqr_handle* h, int32_t mode);
  * are identical either way; what changes is how long a launch waits for its slowest trajectories. */
 int cilqr_set_work_sharing(cilqr_handle* h, int32_t mode);
 /* Counters of the last launch that shared work (waits for the device): out = { line searches announced, trial costs
- * delivered by other blocks, blocks that stayed to help, 1 if a claimed trial was not delivered in time — the owner
- * then costs it itself and cilqr_solve_batch reports CILQR_ERR_DEVICE }. */
+ * delivered by other blocks, blocks that stayed to help, non-zero if a bounded wait expired in that launch OR in any launch of
+ * any slot since the latch was last reported (see cilqr_solve_batch_device) }. */
 int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]);
 /* Resumable solves (long horizons — two rows per lane — in batches that take more than one round of the chip's resident
  * blocks): a solve runs `iters` iterations at a time; in between its state (x, u, lane indices, a dozen scalars: what

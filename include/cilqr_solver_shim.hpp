@@ -164,7 +164,7 @@ class CILQRSolver {
 // thread-safe; cilqr_last_error is per thread), so the devices run concurrently.  Results do not depend on G: a trajectory's
 // solve is a function of its own inputs alone (tests: --devices 1 equals the plain call; shard arithmetic on the CPU).
 struct ShardStats {
-    long long trajectories = 0, iters = 0, ls_trials = 0, converged = 0, max_lamb = 0, max_iter = 0, bad_input = 0, nan_costs = 0;
+    long long trajectories = 0, iters = 0, ls_trials = 0, converged = 0, max_lamb = 0, max_iter = 0, bad_input = 0, not_solved = 0, nan_costs = 0;
     double sum_J_final = 0.0;
 };
 
@@ -228,6 +228,7 @@ class ShardedSolver {
             s.iters += r.iters; s.ls_trials += r.ls_trials;
             s.converged += r.end_reason == CILQR_END_CONVERGED; s.max_lamb += r.end_reason == CILQR_END_MAX_LAMB;
             s.max_iter += r.end_reason == CILQR_END_MAX_ITER; s.bad_input += r.end_reason == CILQR_END_BAD_INPUT;
+            s.not_solved += r.end_reason == CILQR_END_NOT_SOLVED; // (a trajectory lost in transit: the call has thrown already, cilqr_amd.h)
             if (std::isnan(r.J_final)) s.nan_costs += 1; else s.sum_J_final += r.J_final;
         }
         return s;

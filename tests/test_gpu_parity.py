@@ -1866,6 +1866,109 @@ def test_batches_in_flight_inside_one_handle():
 
 
 
+_LOST_HAND_OVER_SCRIPT = r"""
+import os, sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream(dev).cuda_stream
+to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+RES = pkg.RESULT_DTYPE
+NOT_SOLVED = 4
+res_of = lambda t: np.frombuffer(t.cpu().numpy().tobytes(), dtype=RES)
+def bufs(B, N):  # (results start as garbage that LOOKS like a result: the mark must come from the launch, not from the caller)
+    r = np.zeros(B, dtype=RES); r["iters"] = 7; r["end_reason"] = 0; r["J_final"] = 1.0
+    return (torch.zeros((B, N, 2), dtype=torch.float64, device=dev), torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev),
+            torch.from_numpy(np.frombuffer(r.tobytes(), dtype=np.uint8).reshape(B, RES.itemsize).copy()).to(dev))
+wl = pkg.workloads.config3(B=3000, N=30)
+B, N = wl.B, wl.N
+scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
+ref = Oracle("det").solve_batch(wl.params, scenes, wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=8)
+ins = (to(wl.x0), to(wl.scenario_id), to(wl.param_id), to(wl.tick))
+eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True)   # development library: the only one with the forcing knob
+eng.set_group_mode(2)
+def solve(out):
+    eng.solve_batch_device(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(), 0,
+                           out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), 0, 0, st)
+def check(out, must_lose):
+    r = res_of(out[2])
+    lost = r["end_reason"] == NOT_SOLVED
+    ok = ~lost
+    # every trajectory is either the oracle's, bit for bit, or carries the mark (and nothing that looks like a result)
+    assert np.array_equal(out[0].cpu().numpy()[ok], ref["u"][ok]) and np.array_equal(out[1].cpu().numpy()[ok], ref["x"][ok])
+    for f in ("iters", "end_reason", "ls_trials"):
+        assert (r[f][ok] == ref["res"][f][ok]).all(), f
+    assert (r["J_final"][ok].view(np.uint64) == ref["res"]["J_final"][ok].view(np.uint64)).all()
+    assert (r["iters"][lost] == 0).all() and np.isnan(r["J_final"][lost]).all() and np.isnan(r["J_init"][lost]).all()
+    assert bool(lost.any()) == must_lose, int(lost.sum())
+    return int(lost.sum())
+def wait_fails():
+    try:
+        eng.wait()
+    except RuntimeError as e:
+        assert "bounded wait" in str(e) and "NOT_SOLVED" in str(e), str(e)
+        return True
+    return False
+
+# 1. a healthy launch: nothing marked, nothing latched
+a = bufs(B, N); solve(a); assert not wait_fails(); check(a, False)
+assert eng.work_sharing_stats()["error"] == 0
+# 2. the hand-over wait forced to expire at once: whoever was in transit is marked, the launch is reported, the report clears the latch
+os.environ["CILQR_GRP_WAIT_SPINS"] = "1"
+b = bufs(B, N); solve(b)
+assert eng.work_sharing_stats()["error"] != 0          # (shown without clearing)
+assert wait_fails(); n_lost = check(b, True)
+assert not wait_fails()                                  # (reported once)
+parked = eng.resume_stats()
+assert 1 <= n_lost <= parked, (n_lost, parked)
+# 3. host-buffer entry point: CILQR_ERR_DEVICE, the outputs still delivered with the marks in them
+try:
+    eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+    raise SystemExit("cilqr_solve_batch did not report the expired wait")
+except RuntimeError as e:
+    assert "bounded wait" in str(e), str(e)
+# 4. three launches in flight, the failure in the FIRST slot only — the last launch's control words are clean (ADVICE r05):
+#    the latch still reports it, and the later launches' results are whole
+del os.environ["CILQR_GRP_WAIT_SPINS"]
+eng.set_batches_in_flight(3)
+outs = [bufs(B, N) for _ in range(3)]
+os.environ["CILQR_GRP_WAIT_SPINS"] = "1"
+solve(outs[0])
+del os.environ["CILQR_GRP_WAIT_SPINS"]
+solve(outs[1]); solve(outs[2])
+eng.join_device(st); torch.cuda.synchronize(dev)
+assert eng.work_sharing_stats()["error"] != 0
+assert wait_fails()
+check(outs[0], True); check(outs[1], False); check(outs[2], False)
+# 5. and the handle is healthy afterwards
+c = bufs(B, N); solve(c); assert not wait_fails(); check(c, False)
+eng.close()
+print("LOST-HAND-OVER-OK", n_lost, parked)
+"""
+
+
+def test_a_lost_hand_over_is_loud():
+    """Round 6 (VERDICT r05 task 5): a trajectory lost between wavefronts cannot be mistaken for a result.  Launches
+    that hand trajectories over pre-mark every cilqr_result CILQR_END_NOT_SOLVED on the launch stream; the development
+    library's hand-over wait is forced to expire (CILQR_GRP_WAIT_SPINS=1, read per launch): exactly the trajectories in transit
+    keep the mark, all others == oracle; cilqr_wait and cilqr_solve_batch return CILQR_ERR_DEVICE once; with three launches in
+    flight a failure in a slot that is not the last one is still reported (the latch), the other launches are whole."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("CILQR_GRP_WAIT_SPINS", None)
+    r = subprocess.run([sys.executable, "-c", _LOST_HAND_OVER_SCRIPT, root], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "LOST-HAND-OVER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+
 def test_lost_rows_shape_is_still_what_loses_rows():
     """Round 5 (VERDICT r04 task 5): the real instruction stream of round 4's lost-store anomaly.  ab/libLR.so — the library
     built with -DCILQR_LOSTROWS_REPRO: the grouped rollout pass with its 16-byte slab stores inside waterfall loops — against

@@ -27,7 +27,7 @@ DBG_UNIFORM_BACKWARD = 2
 
 STATUS_NAMES = {0: "RUNNING", 1: "CONVERGED", 2: "BACKWARD_PASS_FAIL", 3: "FORWARD_PASS_FAIL",
                 4: "FORWARD_PASS_SMALL_STEP"}
-END_NAMES = {0: "CONVERGED", 1: "MAX_LAMB", 2: "MAX_ITER", 3: "BAD_INPUT"}
+END_NAMES = {0: "CONVERGED", 1: "MAX_LAMB", 2: "MAX_ITER", 3: "BAD_INPUT", 4: "NOT_SOLVED"}
 
 
 class CilqrParams(C.Structure):

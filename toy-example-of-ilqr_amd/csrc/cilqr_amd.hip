@@ -372,6 +372,12 @@ struct cilqr_handle {
     DevBuf tl;
     int tl_B = 0;
     bool last_launch_shared = false;
+    // Hand-over failures (a bounded wait of a launch's hand-over protocol that expired) are LATCHED: one device word the launch's
+    // own stream ORs the launch's SH_ERROR into right behind the kernel (k_latch_launch) — it survives the slot's next launch,
+    // which zeroes the control words, and covers every slot.  latch = { mask of slots with an error, launches with an error }
+    DevBuf latch;
+    bool latch_pending = false; // a launch that could have set it has been enqueued since the last look
+    int grp_wait_spins = 0;     // development library: forced bound of the grouped build's hand-over wait (0 = the real one)
     int last_info[4] = {0, 0, 0, 0}; // cilqr_last_launch_info
     bool last_launch_reset_ctl = false; // the last fused launch zeroed the control words (persistent blocks): its counters are its own
     int share = 1;             // finished blocks help running ones with their line searches (k_solve's SHARE): 1 on, 0 off
@@ -487,6 +493,39 @@ static void update_window(cilqr_handle* h) {
 // One launch per SLOT at a time (scratch areas, control words and parked-solve state belong to the launch in flight; a handle
 // has one slot unless cilqr_set_batches_in_flight() gave it more): work enqueued on another stream than the slot's previous
 // launch first waits for it, on the device.
+// Every result of a batch marked "not solved" before a launch that hands trajectories from wavefront to wavefront: whoever
+// finishes a trajectory overwrites its record; one that is lost in transit keeps the mark (include/cilqr_amd.h, CILQR_END_NOT_SOLVED)
+__global__ void k_mark_unsolved(cilqr_result* __restrict__ res, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    cilqr_result r;
+    r.J_init = __builtin_nan("");
+    r.J_final = __builtin_nan("");
+    r.iters = 0;
+    r.end_reason = CILQR_END_NOT_SOLVED;
+    r.final_status = CILQR_RUNNING;
+    r.ls_trials = 0;
+    r.cost_evals = 0;
+    r.trace_len = 0;
+    res[b] = r;
+}
+// ... and the launch's error word ORed into the handle's latch, on the launch's own stream right behind the kernel
+__global__ void k_latch_launch(const unsigned* __restrict__ ctl, unsigned* __restrict__ latch, int slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (__hip_atomic_load(ctl + SH_ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        (void)__hip_atomic_fetch_or(latch, 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(latch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+static int mark_unsolved(cilqr_result* d_res, int B, hipStream_t s) {
+    if (!d_res) return CILQR_OK;
+    hipLaunchKernelGGL(k_mark_unsolved, dim3((B + 255) / 256), dim3(256), 0, s, d_res, B);
+    HIP_TRY(hipGetLastError());
+    return CILQR_OK;
+}
+static int latch_launch(cilqr_handle* h, hipStream_t s);
+static int report_latch(cilqr_handle* h, bool clear, unsigned* mask_out);
+
 static int order_after_slot(cilqr_handle* h, int k, hipStream_t s) {
     LaunchSlot& sl = h->slot[k];
     if (sl.launched && sl.last_stream != s) HIP_TRY(hipStreamWaitEvent(s, sl.done, 0));
@@ -529,6 +568,44 @@ static int check_ready(cilqr_handle* h) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     if (h->params.empty()) return fail(CILQR_ERR_BAD_ARG, "cilqr_set_params has not been called");
     if (h->scenes.empty()) return fail(CILQR_ERR_BAD_ARG, "cilqr_set_scenarios has not been called");
+    return CILQR_OK;
+}
+
+static int latch_launch(cilqr_handle* h, hipStream_t s) {
+    if (!h->latch.p) {
+        if (h->latch.ensure(sizeof(unsigned) * 4)) return fail(CILQR_ERR_DEVICE, "hipMalloc error latch");
+        HIP_TRY(hipMemset(h->latch.p, 0, sizeof(unsigned) * 4));
+    }
+    hipLaunchKernelGGL(k_latch_launch, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(SL(h).sh_ctl.p),
+                       static_cast<unsigned*>(h->latch.p), h->cur);
+    HIP_TRY(hipGetLastError());
+    h->latch_pending = true;
+    return CILQR_OK;
+}
+// The latch as the host sees it once every launch of the handle has completed (callers wait first).  clear: the report is the
+// one the caller acts on (cilqr_wait, the host-buffer entry points) — the next one starts from zero.
+static int report_latch(cilqr_handle* h, bool clear, unsigned* mask_out) {
+    *mask_out = 0;
+    if (!h->latch.p || !h->latch_pending) return CILQR_OK;
+    unsigned w[2] = {0, 0};
+    HIP_TRY(hipMemcpy(w, h->latch.p, sizeof(w), hipMemcpyDeviceToHost));
+    *mask_out = w[0];
+    if (clear) {
+        if (w[0]) HIP_TRY(hipMemset(h->latch.p, 0, sizeof(unsigned) * 4));
+        h->latch_pending = false;
+    }
+    return CILQR_OK;
+}
+static int fail_if_latched(cilqr_handle* h) {
+    unsigned mask = 0;
+    int rc = report_latch(h, true, &mask);
+    if (rc) return rc;
+    if (mask) {
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "a bounded wait inside a launch expired (launch slots 0x%x: work sharing between blocks / trajectories "
+                      "handed from wavefront to wavefront); a trajectory that was in transit has end_reason CILQR_END_NOT_SOLVED", mask);
+        return fail(CILQR_ERR_DEVICE, buf);
+    }
     return CILQR_OK;
 }
 
@@ -598,6 +675,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "group_slice_window") h->group_slice_window_pct = v;
                 else if (k == "group_loop") h->group_loop = v;
                 else if (k == "poison") h->poison_scratch = v;
+                else if (k == "grp_wait_spins") h->grp_wait_spins = v;
                 else known = false;
             }
             if (!known && !kv.empty()) std::fprintf(stderr, "cilqr_amd: CILQR_TUNE: unknown setting '%s' ignored\n", kv.c_str());
@@ -652,6 +730,7 @@ extern "C" int cilqr_destroy(cilqr_handle* h) {
     }
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     h->tl.release();
+    h->latch.release();
     h->alm_mu.release();
     h->alm_mu_next.release();
     h->alm_rho.release();
@@ -758,14 +837,24 @@ extern "C" int cilqr_work_sharing_stats(cilqr_handle* h, uint32_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     h->last_parked = 0;
     // the control words are zeroed by persistent launches only: after any other launch they still hold an earlier
-    // launch's counts, which are not this handle's last launch's — report zeros then
-    if (!SL(h).sh_ctl.p || !h->last_launch_reset_ctl) return CILQR_OK;
+    // launch's counts, which are not this handle's last launch's — report zeros then (but for the latch)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (!SL(h).sh_ctl.p || !h->last_launch_reset_ctl) {
+        unsigned mask0 = 0;
+        int rc0 = report_latch(h, false, &mask0);
+        if (rc0) return rc0;
+        out[3] = mask0 ? 1u : 0u;
+        return CILQR_OK;
+    }
     unsigned w[SH_SLOT0];
     HIP_TRY(hipMemcpy(w, SL(h).sh_ctl.p, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = w[SH_ANNOUNCED]; out[1] = w[SH_HELPED]; out[2] = w[SH_HELPERS]; out[3] = w[SH_ERROR];
     h->last_parked = w[SH_PARKED];
+    unsigned mask = 0; // (... and what any other slot's launch, or an earlier launch of this slot, latched: not cleared here)
+    int rc_l = report_latch(h, false, &mask);
+    if (rc_l) return rc_l;
+    if (mask) out[3] |= 1u;
     return CILQR_OK;
 }
 
@@ -823,7 +912,9 @@ extern "C" int cilqr_join_device(cilqr_handle* h, void* stream) {
 extern "C" int cilqr_wait(cilqr_handle* h) {
     if (!h) return fail(CILQR_ERR_BAD_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    return wait_last_launch(h);
+    int rc = wait_last_launch(h);
+    if (rc) return rc;
+    return fail_if_latched(h); // (a hand-over that failed in ANY slot's launch since the last report)
 }
 
 extern "C" int cilqr_slot_kernel_ms(cilqr_handle* h, int32_t k, float* ms) {
@@ -1453,8 +1544,25 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         }
         if (SL(h).scratch.cap < sizeof(double) * (size_t)G * grp_scratch_doubles(a.N) * (size_t)grid)
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
+        if (a.park) { // trajectories change wavefronts in this launch: every result starts as "not solved"
+            rc = mark_unsolved(d_res_out, B, s);
+            if (rc) return rc;
+#ifdef CILQR_DEV_BUILD
+            // the test of a lost hand-over forces the wait's expiry — per handle (CILQR_TUNE=grp_wait_spins=n) or, read at every
+            // launch so that ONE launch of several in flight can be made to fail, CILQR_GRP_WAIT_SPINS=n
+            int spins = h->grp_wait_spins;
+            if (const char* e = std::getenv("CILQR_GRP_WAIT_SPINS")) spins = std::atoi(e);
+            if (spins > 0)
+                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_TEST_SPINS), spins, 1, s));
+#endif
+        }
         hipLaunchKernelGGL(kg, dim3(grid), dim3(CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out, d_x_out, d_res_out, d_trace_out,
                            d_trace_out ? trace_cap : 0);
+        if (a.park) {
+            HIP_TRY(hipGetLastError());
+            rc = latch_launch(h, s);
+            if (rc) return rc;
+        }
         h->last_info[0] = G; h->last_info[1] = grid; h->last_info[2] = CILQR_WAVE; h->last_info[3] = a.W;
     } else {
         const bool two = (a.N + 1 > CILQR_WAVE);
@@ -1564,8 +1672,18 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         }
         if (SL(h).scratch.cap < sizeof(double) * scratch_doubles(a.N) * (size_t)(a.next ? grid : B))
             return fail(CILQR_ERR_DEVICE, "internal: scratch areas / launch shape mismatch");
+        const bool hands_over = a.park != nullptr || a.sh_ctl != nullptr; // (resumable solves / work sharing between blocks)
+        if (hands_over) {
+            rc = mark_unsolved(d_res_out, B, s);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(helped ? 2 * CILQR_WAVE : CILQR_WAVE), shm, s, a, d_x0, d_last_u, d_u_out,
                            d_x_out, d_res_out, d_trace_out, d_trace_out ? trace_cap : 0);
+        if (hands_over) {
+            HIP_TRY(hipGetLastError());
+            rc = latch_launch(h, s);
+            if (rc) return rc;
+        }
         h->last_info[0] = 1; h->last_info[1] = grid; h->last_info[2] = helped ? 2 * CILQR_WAVE : CILQR_WAVE; h->last_info[3] = a.W;
     }
     HIP_TRY(hipGetLastError());
@@ -1665,12 +1783,8 @@ extern "C" int cilqr_solve_batch(cilqr_handle* h, int32_t B, const double* x0,
     DL(6, x_out, nb_x);
     if (res_out) DL(7, res_out, sizeof(cilqr_result) * B);
     if (d_tr) DL(8, trace_out, sizeof(cilqr_trace_rec) * (size_t)B * trace_cap);
-    unsigned sh_err = 0;
-    if (SL(h).sh_ctl.p && h->last_launch_shared)
-        HIP_TRY(hipMemcpyAsync(&sh_err, static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (sh_err) return fail(CILQR_ERR_DEVICE, "a bounded wait inside the launch expired (work sharing between blocks / trajectories handed over at the tail)");
-    return CILQR_OK;
+    return fail_if_latched(h); // (the outputs are in the caller's buffers either way: a trajectory lost in transit says CILQR_END_NOT_SOLVED)
 }
 
 // CILQRSolver::solve as main() calls it (hpp:37-41, mp:194-196): ONE ego, all arguments handed over on every

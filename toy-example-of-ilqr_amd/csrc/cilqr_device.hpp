@@ -1409,6 +1409,7 @@ static_assert(sizeof(ShareReq) == 192, "ShareReq layout");
 enum { SH_NEXT = 0 /* persistent blocks: the next trajectory */, SH_FINISHED = 16, SH_HELPING = 32 /* blocks helping right now */,
        SH_Q_RESV = 48, SH_Q_HEAD = 64 /* queue of parked trajectories (resumable solves) */,
        SH_HELPERS = 80 /* blocks that went helping (count) */, SH_ERROR = 81, SH_ANNOUNCED = 82, SH_HELPED = 83, SH_PARKED = 84,
+       SH_TEST_SPINS = 85 /* development library: bound of the grouped build's hand-over wait when non-zero (CILQR_TUNE=grp_wait_spins) */,
        SH_SLOT0 = 96 };
 #define CILQR_SH_NSLOT 64
 #define CILQR_SH_WORDS (SH_SLOT0 + CILQR_SH_NSLOT)

@@ -194,7 +194,14 @@ __device__ __attribute__((noinline)) int grp_wait_for_work(unsigned* ctl, const 
         (void)sh_add_u(ctl + SH_HELPING, 1u, lane);
         (void)sh_add_u(ctl + SH_HELPERS, 1u, lane);
     }
-    for (int spin = 0; spin < (1 << 20); ++spin) { // (a launch lasts milliseconds; this bound is seconds)
+#ifdef CILQR_DEV_BUILD
+    // (the test of what a lost hand-over looks like from outside forces the expiry: tests/test_gpu_parity.py::test_a_lost_hand_over_is_loud)
+    const unsigned forced = sh_ld_u(ctl + SH_TEST_SPINS, lane);
+    const int bound = forced ? (int)forced : (1 << 20);
+#else
+    constexpr int bound = 1 << 20;
+#endif
+    for (int spin = 0; spin < bound; ++spin) { // (a launch lasts milliseconds; this bound is seconds)
         const int pb = rq_poll(q, cap, h, lane);
         if (pb >= 0) return pb;
         // (every wavefront polls its OWN place; the one word they all share is looked at every eighth time: the wavefronts
