@@ -833,7 +833,7 @@ def main():
                                                / (max(r["ms_per_step_one_batch_at_a_time"] for r in per_rank) * 1e-3)),
             "kernel_ms_one_batch_at_a_time": float(max(r["kernel_ms_one_batch_at_a_time"] for r in per_rank)),
             "config": {"workload": wl.name, "baseline_config": cfg_id, "batch_per_gpu": B, "batches_in_flight": args.in_flight,
-                       "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2,
+                       "global_batch": int(stats[8]), "horizon": N, "nx": 4, "nu": 2, "library": pkg.library_info(),
                        "parallelism": f"trajectory-sharded x{world}, "
                                       + {1: "one wavefront per trajectory", 2: "two trajectories per wavefront",
                                          3: "three trajectories per wavefront"}.get(

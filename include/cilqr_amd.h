@@ -222,7 +222,13 @@ int cilqr_closed_loop_batch_device(cilqr_handle* h, int32_t B, int32_t ticks, do
  *     host after cilqr_wait(h).  Every other entry point of the handle (host-buffer calls, cilqr_advance_batch_device,
  *     piecewise calls, cilqr_set_params / _scenarios) joins first, by itself;
  *   - handles in "alm" mode (multipliers per trajectory live in the handle) and the development aids keep one launch at a
- *     time whatever k.
+ *     time whatever k;
+ *   - SIDE EFFECT on the host application: the slots' internal streams are created at the device's HIGHEST stream priority (the
+ *     runtime spreads the streams of a priority level over that level's hardware queues; at normal priority the third slot
+ *     shared a queue with the caller's stream and every third launch waited behind a 60 ms kernel).  While solves are in flight
+ *     their wavefronts are therefore scheduled ahead of the process's other work on that GPU — kernels of other libraries,
+ *     copies feeding the next batch — whenever both are ready.  A planner that must keep other streams responsive uses k = 1
+ *     (the launch then rides on the caller's own stream and priority) or one handle per stream.
  * Results do not depend on k.  cilqr_slot_kernel_ms: duration of slot k's last launch when cilqr_set_timing is on. */
 int cilqr_set_batches_in_flight(cilqr_handle* h, int32_t k);
 int cilqr_join_device(cilqr_handle* h, void* stream);

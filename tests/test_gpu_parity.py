@@ -2160,6 +2160,8 @@ def test_sliced_solves_of_the_grouped_build(pkg, orc_det, cfg):
     ids = (wl.scenario_id, wl.param_id, wl.tick)
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
     eng.set_resume_iters(0)
+    if not pkg.library_info()["pairs_per_wavefront_by_default"]:
+        eng.set_group_mode(2)  # (a library built with another compiler pairs only when asked: build.py VALIDATED_HIPCC)
     whole = eng.solve_batch(wl.x0, *ids, trace_cap=128)
     assert eng.last_launch_info()["trajectories_per_wavefront"] == 2
     for iters in (1, 5, -1):

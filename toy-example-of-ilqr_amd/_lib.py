@@ -174,6 +174,16 @@ def load(dev=False):
     return lib
 
 
+def library_info(dev=False):
+    """what the loaded library says about itself: version string, and whether it was built with the compiler its kernels were
+    validated with (build.py VALIDATED_HIPCC) — only such a build pairs trajectories per wavefront BY DEFAULT (otherwise the
+    large-batch launches run one trajectory per wavefront, about half the throughput; cilqr_set_group_mode(2) still selects
+    pairs explicitly).  ADVICE r05: surfaced at run time — bench.py prints it, the GPU tests that assert pairs by default ask it."""
+    v = load(dev).cilqr_version().decode()
+    return {"version": v, "compiler_validated": "NOT the validated" not in v,
+            "pairs_per_wavefront_by_default": "NOT the validated" not in v}
+
+
 class CilqrError(RuntimeError):
     def __init__(self, code, where, lib=None):
         msg = (lib or load()).cilqr_last_error()

@@ -1486,6 +1486,8 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         // in-flight mode: the launch goes to the slot's own stream, behind (a) everything the caller's stream holds so far — the
         // launch's inputs —, (b) the slot's previous launch (stream order; an event if something else used its buffers since)
         // and (c) every launch in flight whose buffers overlap this one's with a write on either side
+        // (ONE event, re-recorded by every call: a wait captures the record that precedes it in program order — later
+        //  re-records do not move what an already enqueued hipStreamWaitEvent waits for)
         HIP_TRY(hipEventRecord(h->ev_in, s));
         s = SL(h).stream;
         HIP_TRY(hipStreamWaitEvent(s, h->ev_in, 0));
