@@ -369,7 +369,11 @@ def device_code_unchanged(manifest_rel):
         solve = [n for n in r["changed"] + r["missing"] if "k_solve" in n]
         ans = {"manifest": manifest_rel, "functions_same": r["same"], "functions_changed": len(r["changed"]),
                "functions_missing": len(r["missing"]), "functions_added": len(r["added"]),
-               "all_solve_kernels_unchanged": not solve, "everything_unchanged": not r["changed"] and not r["missing"]}
+               "functions_same_under_another_name (template parameters added)": len(r["renamed"]),
+               "all_solve_kernels_unchanged": not solve, "solve_kernels_changed": [n[:60] for n in solve][:8],
+               # the headline's kernel and its phases: k_solve_grp<50, 2, false, 1>
+               "headline_kernel_unchanged": not any("k_solve_grpILi50ELi2ELb0E" in n for n in r["changed"] + r["missing"]),
+               "everything_unchanged": not r["changed"] and not r["missing"]}
     except Exception as e:  # noqa: BLE001
         ans = {"error": f"{type(e).__name__}: {e}"[:200]}
     _DEVICE_CODE_CACHE[manifest_rel] = ans

@@ -262,7 +262,9 @@ int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
  * helper range run two trajectories per wavefront, whose line-search rollouts (src/cilqr_solver.cpp:442-461, a serial chain
  * over the horizon) share one pass of the instruction stream and whose backward sweeps (cs:383-440) run as one, a
  * trajectory per half-wavefront; 0 or 1 = one trajectory per wavefront everywhere; 2 = two wherever that build can run (any
- * batch size).  Results are identical in every mode.  A launch in pairs hands trajectories from wavefront to wavefront
+ * batch size).  Results are identical in every mode.  Handles in "alm" mode run in pairs only when mode 2 is set explicitly
+ * (round 6: those two kernels are bit-exact under the wave64 emulator of tests/ but have not yet run on a GPU; -1 keeps such batches
+ * on the lone-wavefront builds).  A launch in pairs hands trajectories from wavefront to wavefront
  * (sliced solves, idle wavefronts at its tail); should a bounded wait inside it ever expire, the trajectory that was in transit
  * keeps end_reason = CILQR_END_NOT_SOLVED in its cilqr_result (every result is pre-marked on the launch stream), and
  * cilqr_solve_batch / the next cilqr_wait return CILQR_ERR_DEVICE — whichever launch slot it happened in (never observed in

@@ -60,18 +60,24 @@ def manifest(lib):
 def compare(ref, cur, only=None):
     """symbols of `ref` missing from / different in `cur` (symbols only in `cur` are additions: reported, not failures)"""
     pat = re.compile(only) if only else None
-    missing, changed, same = [], [], 0
+    missing, changed, renamed, same = [], [], [], 0
+    # (a template that gained parameters changes the mangled NAME of every instantiation: a function whose bytes are all found
+    #  in the current library under another name is the same machine code — counted under `renamed`)
+    blobs = {tuple(x) for v in cur.values() for x in v}
     for name, v in ref.items():
         if pat and not pat.search(name):
             continue
-        if name not in cur:
-            missing.append(name)
-        elif cur[name] != v:
-            changed.append(name)
-        else:
+        if name in cur and cur[name] == v:
             same += 1
-    added = [n for n in cur if n not in ref and (not pat or pat.search(n))]
-    return {"same": same, "changed": changed, "missing": missing, "added": added}
+        elif all(tuple(x) in blobs for x in v):
+            renamed.append(name)
+        elif name not in cur:
+            missing.append(name)
+        else:
+            changed.append(name)
+    ref_blobs = {tuple(x) for v in ref.values() for x in v}
+    added = [n for n in cur if n not in ref and (not pat or pat.search(n)) and not all(tuple(x) in ref_blobs for x in cur[n])]
+    return {"same": same + len(renamed), "renamed": renamed, "changed": changed, "missing": missing, "added": added}
 
 
 def main():
@@ -89,8 +95,8 @@ def main():
         ref = json.load(open(a.against))["functions"]
         ref = {k: sorted([list(x) for x in v]) for k, v in ref.items()}
         r = compare(ref, man, a.only)
-        print(json.dumps({"same": r["same"], "changed": len(r["changed"]), "missing": len(r["missing"]),
-                          "added": len(r["added"])}))
+        print(json.dumps({"same": r["same"], "of_which_under_another_name": len(r["renamed"]), "changed": len(r["changed"]),
+                          "missing": len(r["missing"]), "added": len(r["added"])}))
         for k in ("changed", "missing", "added"):
             for n in r[k][:40]:
                 print(" ", k, n)

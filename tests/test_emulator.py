@@ -1,0 +1,295 @@
+"""The kernels' wave64 LOGIC, run without a GPU.  TEST INFRASTRUCTURE (tests/emu/): the unmodified sources of
+toy-example-of-ilqr_amd/csrc/ are compiled for the x86 host against a stand-in <hip/hip_runtime.h> and an emulator in which every
+lane of every resident block is a fibre and every cross-lane operation (DPP, ds_bpermute, v_readlane, v_readfirstlane, ballot,
+barriers) is resolved for the lanes that execute it together; raw buffers keep their range check, the buffer -> LDS DMA, the
+persistent blocks, the spin waits and the hand-over protocol between blocks behave as on the device.  The resulting library has
+the product's C-ABI and is driven through the product's own Python binding (CILQR_AMD_LIB names it, in a subprocess).
+
+What this checks: that the SOURCE the GPU library is built from computes the reference's numbers — every output == the oracle's
+detmath build, bit for bit — for the kernels that matter, on the build container, every round, whether or not a GPU can be had.
+What it cannot check: what hipcc makes of the source, and the hardware (timing, LDS bank conflicts, the lost-store anomaly of
+round 4): the `-m gpu` suite stays the parity gate.  The product never loads the emulator (test below)."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+EMU = ROOT / "tests" / "emu"
+
+PRELUDE = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+assert "tests/emu/_build" in str(pkg._lib.LIB_PATH), pkg._lib.LIB_PATH
+ORC = Oracle("det")
+EMULIB = ctypes.CDLL(str(pkg._lib.LIB_PATH))
+def scene_of(sc, tick=0): return Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, tick)
+def scenes_of(wl): return [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
+def bits(a): return np.ascontiguousarray(a).view(np.uint64)
+def same(out, ref):
+    ok = bool((bits(out["u"]) == bits(ref["u"])).all() and (bits(out["x"]) == bits(ref["x"])).all())
+    for f in ("iters", "end_reason", "final_status", "ls_trials", "cost_evals"):
+        ok = ok and bool((out["res"][f] == ref["res"][f]).all())
+    return ok and bool((bits(out["res"]["J_final"]) == bits(ref["res"]["J_final"])).all() and (bits(out["res"]["J_init"]) == bits(ref["res"]["J_init"])).all())
+def emu_stats():
+    st = (ctypes.c_longlong * 8)(); EMULIB.cilqr_emu_stats(st)
+    return dict(launches=st[0], lane_ops=st[1], groups=st[2], split_resolutions=st[3], partial_barriers=st[4], readlane_of_inactive_lane=st[5])
+def scenario(name, N, **kw):
+    cfg = pkg.GlobalConfig.get_instance(name); sc = pkg.build_scenario(cfg, name)
+    return sc, pkg.params_from_config(cfg, N=N, **kw)
+OUT = {}
+"""
+
+
+@pytest.fixture(scope="session")
+def emu_libs(built):
+    sys.path.insert(0, str(EMU))
+    import build_emu
+    return {"prod": build_emu.build(), "dev": build_emu.build(dev=True)}
+
+
+def run(emu_libs, body, timeout=600, env=None, libs=None):
+    libs = libs or emu_libs
+    e = dict(os.environ)
+    e.pop("CILQR_TUNE", None)
+    e.update({"CILQR_AMD_LIB": str(libs["prod"]), "CILQR_AMD_LIB_DEV": str(libs["dev"])})
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", PRELUDE + body + "\nprint('EMU-RESULT ' + json.dumps(OUT))\n", str(ROOT)],
+                       capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("EMU-RESULT ")][-1]
+    return json.loads(line[len("EMU-RESULT "):])
+
+
+def healthy(st):
+    """the emulator's own bookkeeping: no barrier met by part of a wavefront while the rest waited elsewhere, no v_readlane of a
+    lane that was not executing (either would mean the run did not follow the device's semantics)"""
+    assert st["partial_barriers"] == 0 and st["readlane_of_inactive_lane"] == 0, st
+    assert st["lane_ops"] > 100000, st
+
+
+def test_the_product_never_touches_the_emulator(pkg):
+    """tests/emu/ is loaded by this file alone: nothing under the package, include/, examples/, bench.py or __graft_entry__.py
+    names it, the default library path is the gfx950 build, and the emulator library is not built by build()."""
+    for p in list((ROOT / "toy-example-of-ilqr_amd").rglob("*.py")) + list((ROOT / "toy-example-of-ilqr_amd" / "csrc").iterdir()) + \
+            list((ROOT / "include").iterdir()) + list((ROOT / "examples").glob("*.cpp")) + [ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
+        if p.is_file() and p.suffix != ".so":
+            t = p.read_text(errors="ignore")
+            assert "tests/emu" not in t and "libcilqr_emu" not in t and "CILQR_EMULATED" not in t, p
+    if not os.environ.get("CILQR_AMD_LIB"):
+        assert pkg._lib.LIB_PATH == ROOT / "toy-example-of-ilqr_amd" / "libcilqr_amd.so"
+
+
+def test_pairs_per_wavefront_with_hand_overs_and_slices(emu_libs):
+    """k_solve_grp, short layout (the headline's kernel family): 40 three_bend solves of horizon 30 on 8 resident blocks — two
+    rounds of trajectories, pair sweeps, paired costs, sliced solves, idle wavefronts taking trajectories over at the tail — and
+    24 of horizon 50 (the compile-time build); every output and the whole decision trace == oracle."""
+    r = run(emu_libs, r"""
+for N, B in ((30, 40), (50, 24)):
+    sc, p = scenario("three_bend", N)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(2)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0x5A0CE)
+    out = eng.solve_batch(x0, trace_cap=128)
+    ref = [ORC.solver(p) for _ in range(B)]
+    whole = ORC.solve_batch(p, scene_of(sc), x0, n_threads=4)
+    tr_ok = True
+    for b in range(B):
+        s = ref[b]; s.reset(); rr = s.solve(x0[b], scene_of(sc), trace_cap=128)
+        n = int(out["res"]["trace_len"][b])
+        tr_ok = tr_ok and n == len(rr["trace"]) and bool((out["trace"][b][:n] == rr["trace"]).all())
+    OUT[str(N)] = dict(same=same(out, whole), traces=tr_ok, launch=eng.last_launch_info(), parked=eng.resume_stats(),
+                       error=eng.work_sharing_stats()["error"], iters_max=int(out["res"]["iters"].max()))
+    eng.close()
+OUT["stats"] = emu_stats()
+""")
+    for N in ("30", "50"):
+        assert r[N]["same"] and r[N]["traces"], r[N]
+        assert r[N]["launch"]["trajectories_per_wavefront"] == 2 and r[N]["error"] == 0, r[N]
+    assert r["30"]["parked"] > 0, r["30"]   # (trajectories did change wavefronts)
+    healthy(r["stats"])
+
+
+def test_long_layout_and_lone_builds(emu_libs):
+    """horizon 100: the grouped kernel's long layout (rows streamed through LDS rings, gains ring filled by LDS-DMA behind a counted
+    wait, two rows per lane) on the mixed scenarios of configs[3], and the lone / helper builds of k_solve on the same batch;
+    straight-lane starts (RearCenter model) of config 2 through the helper build and in pairs."""
+    r = run(emu_libs, r"""
+wl = pkg.workloads.config4(B=12, N=100)
+ref = ORC.solve_batch(wl.params, scenes_of(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=4)
+for mode in (2, 0, -1):
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes); eng.set_group_mode(mode)
+    out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+    OUT["c4 mode %d" % mode] = dict(same=same(out, ref), launch=eng.last_launch_info())
+    eng.close()
+wl = pkg.workloads.config2(B=10, N=50)
+ref = ORC.solve_batch(wl.params, scenes_of(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=4)
+for mode in (2, -1):
+    eng = pkg.BatchedCILQR(wl.params, wl.scenes); eng.set_group_mode(mode)
+    out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+    OUT["c2 mode %d" % mode] = dict(same=same(out, ref), launch=eng.last_launch_info())
+    eng.close()
+OUT["stats"] = emu_stats()
+""", timeout=900)
+    for k, v in r.items():
+        if k != "stats":
+            assert v["same"], (k, v)
+    assert r["c4 mode 2"]["launch"]["trajectories_per_wavefront"] == 2 and r["c4 mode 0"]["launch"]["trajectories_per_wavefront"] == 1
+    assert r["c2 mode -1"]["launch"]["threads_per_block"] == 128   # (the helper build)
+    healthy(r["stats"])
+
+
+def test_augmented_lagrangian_lone_and_in_pairs(emu_libs):
+    """solve_type alm (cs:88-93, 253-277, 377-378, 581-643): k_solve's builds (what the default dispatch runs) and — round 6, written
+    while the GPU pool was closed, never run on a GPU — the grouped kernel's ALM builds, two trajectories per wavefront, chosen with
+    cilqr_set_group_mode(2).  Horizons 30 and 100; a second call warm-started from the first one's plan continues from the
+    multipliers the handle kept (hpp:106-112), against stateful oracle solvers."""
+    r = run(emu_libs, r"""
+for N, B in ((30, 8), (100, 4)):
+    sc, p = scenario("three_bend", N, solve_type=1, use_last_solution=1)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xA11)
+    refs = [ORC.solver(p) for _ in range(B)]
+    first, second = [], []
+    for b in range(B):
+        refs[b].reset()
+        a = refs[b].solve(x0[b], scene_of(sc))
+        first.append(a)
+        second.append(refs[b].solve(a["x"][1], scene_of(sc, 1)))
+    stack = lambda rs: dict(u=np.stack([q["u"] for q in rs]), x=np.stack([q["x"] for q in rs]), res=np.array([q["res"] for q in rs]).reshape(-1))
+    for mode in (-1, 2):
+        eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(mode)
+        o1 = eng.solve_batch(x0)
+        info = eng.last_launch_info()
+        o2 = eng.solve_batch(o1["x"][:, 1].copy(), tick=np.ones(B, dtype=np.int32), last_u=o1["u"])
+        OUT["N%d mode %d" % (N, mode)] = dict(first=same(o1, stack(first)), second=same(o2, stack(second)), launch=info,
+                                              iters=o1["res"]["iters"].tolist())
+        eng.close()
+OUT["stats"] = emu_stats()
+""", timeout=900)
+    for k, v in r.items():
+        if k != "stats":
+            assert v["first"] and v["second"], (k, v)
+            assert v["launch"]["trajectories_per_wavefront"] == (2 if k.endswith("mode 2") else 1), (k, v)
+    healthy(r["stats"])
+
+
+def test_closed_loop_in_one_launch(emu_libs):
+    """cilqr_closed_loop_batch_device (mp:180-197 for every ego in one launch) through the device-pointer entry point — under the
+    emulator "device memory" is host memory, so numpy buffers stand in: 6 egos x 4 ticks, warm starts, == stateful oracle solvers;
+    and the tick-by-tick loop (solve + advance) gives the same."""
+    r = run(emu_libs, r"""
+sc, p = scenario("three_straight", 30, use_last_solution=1)
+B, T, N = 6, 4, 30
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC10)
+ptr = lambda a: a.ctypes.data
+for mode in (2, 0):
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(mode)
+    dx0 = x0.copy(); tick = np.zeros(B, dtype=np.int32)
+    u = np.zeros((B, N, 2)); x = np.zeros((B, N + 1, 4)); res = np.zeros(B, dtype=pkg.RESULT_DTYPE)
+    states = np.zeros((B, T, 4)); its = np.zeros((T, B), dtype=np.int32)
+    eng.closed_loop_batch_device(B, T, ptr(dx0), 0, 0, ptr(tick), 0, ptr(u), ptr(x), ptr(res), ptr(states), ptr(its), 0)
+    eng.wait()
+    ok = True
+    for b in range(B):
+        s = ORC.solver(p); s.reset(); xe = x0[b].copy()
+        for t in range(T):
+            rr = s.solve(xe, scene_of(sc, t))
+            xe = rr["x"][1].copy()
+            ok = ok and bool((bits(xe) == bits(states[b, t])).all()) and int(rr["res"]["iters"]) == int(its[t, b])
+    OUT["mode %d" % mode] = dict(same=ok, launch=eng.last_launch_info(), ticks=tick.tolist())
+    eng.close()
+OUT["stats"] = emu_stats()
+""", timeout=900)
+    for k in ("mode 2", "mode 0"):
+        assert r[k]["same"] and r[k]["ticks"] == [4] * 6, r[k]
+    healthy(r["stats"])
+
+
+def test_a_lost_hand_over_is_loud_under_emulation(emu_libs):
+    """Round 6 (VERDICT r05 task 5), the CPU twin of tests/test_gpu_parity.py::test_a_lost_hand_over_is_loud:
+    the development build's hand-over wait is forced to expire at once.  Exactly the trajectories in transit keep
+    CILQR_END_NOT_SOLVED (pre-marked on the launch stream), every other one == oracle; cilqr_wait reports CILQR_ERR_DEVICE once;
+    with three launches in flight a failure in the FIRST slot is still reported after two clean launches (the handle-wide latch)."""
+    r = run(emu_libs, r"""
+sc, p = scenario("three_bend", 30)
+B, N = 40, 30
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0x10057)
+ref = ORC.solve_batch(p, scene_of(sc), x0, n_threads=4)
+ptr = lambda a: a.ctypes.data
+ids = (np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32))
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(2)
+def bufs():
+    r_ = np.zeros(B, dtype=pkg.RESULT_DTYPE); r_["iters"] = 7; r_["J_final"] = 1.0   # garbage that LOOKS like results
+    return np.zeros((B, N, 2)), np.zeros((B, N + 1, 4)), r_
+def solve(o): eng.solve_batch_device(B, ptr(x0), ptr(ids[0]), ptr(ids[1]), ptr(ids[2]), 0, ptr(o[0]), ptr(o[1]), ptr(o[2]), 0, 0, 0)
+def check(o):
+    lost = o[2]["end_reason"] == 4
+    ok = ~lost
+    good = bool((bits(o[0][ok]) == bits(ref["u"][ok])).all() and (bits(o[1][ok]) == bits(ref["x"][ok])).all() and (o[2]["iters"][ok] == ref["res"]["iters"][ok]).all())
+    marked = bool((o[2]["iters"][lost] == 0).all() and np.isnan(o[2]["J_final"][lost]).all())
+    return dict(lost=int(lost.sum()), others_equal_oracle=good, lost_look_unsolved=marked)
+def wait_fails():
+    try: eng.wait(); return False
+    except RuntimeError as e: return "bounded wait" in str(e) and "NOT_SOLVED" in str(e)
+a = bufs(); solve(a); OUT["healthy"] = dict(wait_fails=wait_fails(), **check(a), error=eng.work_sharing_stats()["error"])
+os.environ["CILQR_GRP_WAIT_SPINS"] = "1"
+b = bufs(); solve(b)
+OUT["forced"] = dict(error_shown=eng.work_sharing_stats()["error"], wait_fails=wait_fails(), again=wait_fails(), **check(b), parked=eng.resume_stats())
+try:
+    eng.solve_batch(x0); OUT["host_entry_raises"] = False
+except RuntimeError as e:
+    OUT["host_entry_raises"] = "bounded wait" in str(e)
+del os.environ["CILQR_GRP_WAIT_SPINS"]
+eng.set_batches_in_flight(3)
+outs = [bufs() for _ in range(3)]
+os.environ["CILQR_GRP_WAIT_SPINS"] = "1"; solve(outs[0]); del os.environ["CILQR_GRP_WAIT_SPINS"]
+solve(outs[1]); solve(outs[2])
+OUT["in_flight"] = dict(error_shown=eng.work_sharing_stats()["error"], wait_fails=wait_fails(), slots=[check(o) for o in outs])
+c = bufs(); solve(c); OUT["after"] = dict(wait_fails=wait_fails(), **check(c))
+eng.close()
+""", timeout=900)
+    assert r["healthy"] == dict(wait_fails=False, lost=0, others_equal_oracle=True, lost_look_unsolved=True, error=0), r["healthy"]
+    f = r["forced"]
+    assert f["error_shown"] != 0 and f["wait_fails"] and not f["again"], f
+    assert 1 <= f["lost"] <= f["parked"] and f["others_equal_oracle"] and f["lost_look_unsolved"], f
+    assert r["host_entry_raises"] is True
+    g = r["in_flight"]
+    assert g["error_shown"] != 0 and g["wait_fails"], g
+    assert g["slots"][0]["lost"] >= 1 and g["slots"][1]["lost"] == 0 and g["slots"][2]["lost"] == 0, g
+    assert all(s["others_equal_oracle"] for s in g["slots"]), g
+    assert r["after"] == dict(wait_fails=False, lost=0, others_equal_oracle=True, lost_look_unsolved=True), r["after"]
+
+
+def test_lockstep_points_cover_every_hazard(emu_libs):
+    """The emulator runs the lanes of a wavefront one after the other between two cross-lane operations.  Where lanes exchange data
+    through memory inside such a stretch (legal on the device: a wavefront's LDS operations execute in order) the scratch copy of
+    the sources gets a rendezvous — tests/emu/build_emu.py LOCKSTEP_POINTS.  The instrumented build traces every load and store of
+    the kernels and reports words touched by two lanes of one wavefront in the same stretch with a store among them: with the
+    listed points in place nothing is left, on the pair sweep, the long layout and the helper build."""
+    sys.path.insert(0, str(EMU))
+    import build_emu
+    libs = {"prod": build_emu.build(hazards=True), "dev": build_emu.build(dev=True, hazards=True)}
+    r = run(emu_libs, r"""
+HZ = EMULIB
+def hazards_of(fn):
+    HZ.cilqr_emu_hazards_enable(1); fn(); HZ.cilqr_emu_hazards_enable(0)
+    A = (ctypes.c_void_p * 64)(); Bv = (ctypes.c_void_p * 64)(); Nn = (ctypes.c_longlong * 64)()
+    return HZ.cilqr_emu_hazards(A, Bv, Nn, 64)
+sc, p = scenario("three_bend", 30)
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True)
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, 6, 0x5A0CE)
+eng.set_group_mode(2); OUT["pairs"] = hazards_of(lambda: eng.solve_batch(x0))
+eng.set_group_mode(0); OUT["helper"] = hazards_of(lambda: eng.solve_batch(x0[:2]))
+eng.close()
+wl = pkg.workloads.config4(B=4, N=70)
+eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True); eng.set_group_mode(2)
+OUT["long"] = hazards_of(lambda: eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick))
+eng.close()
+""", timeout=1500, libs=libs, env={"CILQR_TUNE": "group_steal=0,group_slice=0"})
+    assert r == {"pairs": 0, "helper": 0, "long": 0}, r
+    assert len(build_emu.LOCKSTEP_POINTS) <= 6   # (a list that grows means the kernels lean on lockstep more and more: look again)

@@ -29,6 +29,8 @@ extern template __global__ void k_solve_grp<30, 2, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, false, 1, true, true> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, false, 2, true, true> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -402,6 +404,10 @@ struct cilqr_handle {
     int poison_scratch = 0;    // development library: fill the kernels' scratch before every launch (CILQR_TUNE=poison=1: NaN
                                // patterns, 2: zeros) — results must not depend on what the scratch held
     int group_pair_costs = 1;  // ... line-search trials after the first costed two per pass
+    int group_alm = 0;         // ... augmented-Lagrangian batches in pairs (the long layout at every horizon).  Round 6: the kernels were
+                               // written while the GPU pool was closed and are bit-exact under the wave64 emulator (tests/test_emulator.py)
+                               // but have never run on a GPU: 0 = only when pairs are asked for explicitly (cilqr_set_group_mode(2)),
+                               // the default dispatch stays on k_solve's GPU-proven builds; 1 (CILQR_TUNE=group_alm=1) = by default
     int group_long = 1;        // ... horizons of 64 ... 127 run the grouped build too (its long layout; CILQR_TUNE=group_long=0: k_solve's
                                // two-rows-per-lane builds)
     int group_slice = 16;      // ... solves run this many iterations at a time while other trajectories wait (0: to their end in one go)
@@ -480,8 +486,8 @@ static void update_window(cilqr_handle* h) {
         int wg = (int)(room / 16) / 8 * 8;
         wg = std::max(wg, grp_expansion_doubles(N) / 2 / 8 * 8);
         h->win_grp = std::max(8, std::min(want, wg));
-        if (N + 1 > CILQR_WAVE) {
-            // the long layout (two rows per lane): the window sits behind the stage-cost scratch; the largest that keeps 8
+        if (N + 1 > CILQR_WAVE || alm) {
+            // the long layout (two rows per lane, or the augmented Lagrangian at any horizon): the window sits behind the stage-cost scratch; the largest that keeps 8
             // wavefronts on a CU, as long as it is comfortable — else 7, 6, ...
             fixed = grpl_lds_bytes(N, 0, grp_n(h)) - sizeof(double) * (size_t)grpl_shared_doubles(N, 0, grp_n(h)) +
                     sizeof(double) * (size_t)grpl_cs_doubles(N);
@@ -670,6 +676,7 @@ extern "C" int cilqr_create(int device, cilqr_handle** out) {
                 else if (k == "group_pair_costs") h->group_pair_costs = v;
                 else if (k == "pair_sweep") h->group_pair_sweep = v;
                 else if (k == "group_long") h->group_long = v;
+                else if (k == "group_alm") h->group_alm = v;
                 else if (k == "group_slice") h->group_slice = v;
                 else if (k == "group_slice_long") h->group_slice_long = v;
                 else if (k == "group_slice_window") h->group_slice_window_pct = v;
@@ -1219,7 +1226,8 @@ static bool global_expansion(const cilqr_handle* h, int B) {
 // Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
 static bool grouped(const cilqr_handle* h, int B) {
     if (h->group_mode == 0 || h->group_mode == 1) return false;
-    if (h->params[0].solve_type == 1 || h->debug_flags != 0) return false;
+    if (h->debug_flags != 0) return false;
+    if (h->params[0].solve_type == 1 && ((!h->group_alm && h->group_mode < 2) || h->looping || h->profiling)) return false; // (ALM in pairs: the long layout)
     if (two_rows(h) && (!h->group_long || h->looping)) return false; // (the long layout has no closed-loop build)
     if (h->looping && (!h->group_loop || h->profiling)) return false; // (closed loop in one launch: the LOOP builds of k_solve_grp)
     if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
@@ -1522,8 +1530,9 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         // compile-time horizons: BASELINE's 50 and the 30 of the reference's own YAMLs (config/scenario_*.yaml:5)
         auto kg = (a.N == 50) ? k_solve_grp<50, 2> : (a.N == 30 ? k_solve_grp<30, 2> : k_solve_grp<0, 2>);
         if (loop.ticks >= 1) kg = (a.N == 50) ? k_solve_grp<50, 2, true> : (a.N == 30 ? k_solve_grp<30, 2, true> : k_solve_grp<0, 2, true>);
-        const bool longl = a.N + 1 > CILQR_WAVE; // two rows per lane: the long layout
+        const bool longl = a.N + 1 > CILQR_WAVE || a.alm; // two rows per lane, or the augmented Lagrangian: the long layout
         if (longl) kg = (a.N == 100) ? k_solve_grp<100, 2, false, 2> : k_solve_grp<0, 2, false, 2>;
+        if (a.alm) kg = (a.N + 1 > CILQR_WAVE) ? k_solve_grp<0, 2, false, 2, true, true> : k_solve_grp<0, 2, false, 1, true, true>;
         const size_t shm = longl ? grpl_lds_bytes(a.N, a.W, G) : grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
@@ -1534,7 +1543,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         a.next = static_cast<unsigned*>(SL(h).sh_ctl.p) + SH_NEXT;
         HIP_TRY(hipMemsetAsync(SL(h).sh_ctl.p, 0, sizeof(unsigned) * CILQR_SH_WORDS, s));
         h->last_launch_reset_ctl = true;
-        if (h->group_steal && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N &&
+        if (h->group_steal && !a.alm && SL(h).park.p && SL(h).park_B >= B && SL(h).park_N == a.N && // (ALM: multipliers are plain stores, no hand-overs)
             SL(h).rq.cap >= sizeof(unsigned long long) * (size_t)B * CILQR_GRP_Q_PER_TRAJECTORY) {
             a.park = static_cast<double*>(SL(h).park.p);
             a.rq = static_cast<unsigned long long*>(SL(h).rq.p);

@@ -1707,10 +1707,15 @@ __device__ inline void model_jacobians(const Cst& c, const Lds& l, int lane) {
 // Jacobian entries at slot 16 (l.kd then points at slot 16 of row 0)
 #define CILQR_GRP_ROW 32
 #define CILQR_GRP_ROW_JAC 16
-template <bool ALM, bool LG = false, int GROW = CILQR_GL_ROW>
+// SROW (ALM + LG, the grouped kernel): the 256-byte row also carries the step's eight Jacobian entries, at slot
+// CILQR_GLA_JAC = 24 (l.kd then points at slot 24 of row 0) — the row's zero slot moves onto l_xx[0][2], a structural zero
+#define CILQR_GLA_JAC 24
+#define CILQR_GLA_ZERO_S (CILQR_GLA_LXX + 2)
+template <bool ALM, bool LG = false, int GROW = CILQR_GL_ROW, bool SROW = false>
 __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, const AlmSt& al, int lane) {
     const int N = c.N;
     static_assert(GROW == CILQR_GL_ROW || (LG && !ALM), "wide rows: barrier mode, expansion in global memory");
+    static_assert(!SROW || (ALM && LG), "rows with the Jacobians inside: barrier mode says so through GROW");
     gdouble_w* const grows = LG ? (gdouble_w*)l.gl : nullptr;
     for (int k = lane; k <= N; k += CILQR_WAVE) {
         double xk[4] = {l.x[4 * k], l.x[4 * k + 1], l.x[4 * k + 2], l.x[4 * k + 3]};
@@ -1882,8 +1887,8 @@ __device__ inline void cost_and_model_derivatives(const Cst& c, const Lds& l, co
             hx[4] = 0.0 + g10; hx[5] = 2 * c.k->w_pos + h11; hx[6] = 0.0; hx[7] = 0.0 + h13;
             hx[8] = 0.0; hx[9] = 0.0; hx[10] = 2 * c.k->w_vel + h22; hx[11] = 0.0;
             hx[12] = 0.0 + g30; hx[13] = 0.0 + g31; hx[14] = 0.0; hx[15] = 2 * c.k->w_yaw + h33;
-            r[CILQR_GLA_ZERO] = 0.0;
-            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy);
+            if (!SROW) r[CILQR_GLA_ZERO] = 0.0;
+            if (k < N) model_jacobians_row(c, l, k, xk[2], xk[3], sy, cy, SROW ? CILQR_GL_ROW_ALM : CILQR_KD);
             continue;
         }
         if (LG) {

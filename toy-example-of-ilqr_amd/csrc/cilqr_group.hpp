@@ -116,6 +116,21 @@ typedef double __attribute__((ext_vector_type(2))) f64x2;
 typedef const f64x2 __attribute__((address_space(3))) lds_cf64x2;
 typedef const f64x2 __attribute__((address_space(1))) f64x2g;
 
+// Augmented Lagrangian in pairs (long layout only): the trajectory's penalty weight rho (hpp:106-112) lives in GrpSt::J_pair — the
+// long layout costs one trial per pass, the slot is free —, its multipliers stay in HBM ([N][C] per trajectory, BatchArgs::alm_mu)
+struct GrpAlm {
+    const double* mu;   // this trajectory's multipliers
+    double* mu_next;    // ... and the proposal cost_and_model_derivatives writes
+    int C;
+};
+__device__ inline AlmSt grp_almst(const GrpAlm& ga, double rho) {
+    AlmSt al;
+    al.mu = (double*)uniform_ptr(const_cast<double*>(ga.mu));
+    al.mu_next = (double*)uniform_ptr(ga.mu_next);
+    al.rho = rho;
+    al.C = uniform_int(ga.C);
+    return al;
+}
 __device__ inline GrpSt* grp_state(double* base, int N, int g) {
     return reinterpret_cast<GrpSt*>(base + (size_t)g * grp_pg_doubles(N) + 4 * (N + 1) + 2 * N + grp_idx_doubles(N) + CILQR_CSTK_DOUBLES);
 }
@@ -355,9 +370,13 @@ struct PairArgs {
     unsigned roffA, roffB;
     double* ringA;
 };
-template <bool BOTH = false>
+// ALM (with BOTH): the rows are the augmented-Lagrangian ones — dense, NOT symmetric l_xx (cs:701-713) at CILQR_GLA_LXX + 4 r + c,
+// l_uu / l_x / l_u at their CILQR_GLA_* slots, the Jacobians at CILQR_GLA_JAC
+template <bool BOTH = false, bool ALM = false>
 __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairArgs& pa, double* scr_blk, unsigned scr_bytes, int lane,
                                                double dVA[2], double dVB[2]) {
+    static_assert(!ALM || BOTH, "augmented-Lagrangian rows: both halves stream");
+    constexpr int JAC = ALM ? CILQR_GLA_JAC : CILQR_GRP_ROW_JAC;
     const int h = lane >> 5, q = lane & 31, r = q >> 3, cg = q & 7, hb = lane & 32;
     // this lane's two elements
     int R1, C1, R2, C2;
@@ -401,15 +420,18 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
     for (int k = 0; k < 4; ++k) {
         int off, stride;
         lane_map_M(lA, k, R1, off, stride);
-        place(k, off, stride, stride ? CILQR_GRP_ROW_JAC + (off - A5) : -1);
+        place(k, off, stride, stride ? JAC + (off - A5) : -1);
         lane_map_M(lA, k, C2, off, stride);
-        place(4 + k, off, stride, stride ? CILQR_GRP_ROW_JAC + (off - A5) : -1);
+        place(4 + k, off, stride, stride ? JAC + (off - A5) : -1);
     }
     int slotq = -1, slotv;
     {
         // L[R2][C2]: l_xx (7 packed entries 00 01 03 11 13 33 22), l_uu diagonal, zero elsewhere
         int off = CCo, stride = 0;
-        if (R2 < 4 && C2 < 4) {
+        if (ALM) {
+            if (R2 < 4 && C2 < 4) { stride = 16; slotq = CILQR_GLA_LXX + 4 * R2 + C2; }
+            else if (diag) { stride = 2; slotq = CILQR_GLA_LUU + (R2 - 4); }
+        } else if (R2 < 4 && C2 < 4) {
             const int lo = (R2 < C2) ? R2 : C2, hi = (R2 < C2) ? C2 : R2;
             int e = -1;
             if (lo == 0 && hi == 0) e = 0;
@@ -424,8 +446,8 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
             off = BOTH ? 0 : (int)(lA.luu - lA.x) + (R2 - 4); stride = 2; slotq = CILQR_GL_LUU + (R2 - 4);
         }
         place(8, off, stride, slotq);
-        if (R1 < 4) { off = BOTH ? 0 : (int)(lA.lx - lA.x) + R1; stride = 4; slotv = CILQR_GL_LX + R1; }
-        else { off = BOTH ? 0 : (int)(lA.lu - lA.x) + (R1 - 4); stride = 2; slotv = CILQR_GL_LU + (R1 - 4); }
+        if (R1 < 4) { off = BOTH ? 0 : (int)(lA.lx - lA.x) + R1; stride = 4; slotv = (ALM ? CILQR_GLA_LX : CILQR_GL_LX) + R1; }
+        else { off = BOTH ? 0 : (int)(lA.lu - lA.x) + (R1 - 4); stride = 2; slotv = (ALM ? CILQR_GLA_LU : CILQR_GL_LU) + (R1 - 4); }
         place(9, off, stride, slotv);
     }
     // cross-lane sources (ds_bpermute byte addresses)
@@ -594,9 +616,11 @@ __device__ inline unsigned backward_sweep_pair(int N, const Lds& lA, const PairA
 // backward sweep (cs:383-440) of the one trajectory that is waiting, or of both in one instruction stream.  Both read
 // everything from LDS / their arguments and leave their results in GrpSt (dV, and for a completed sweep the request for
 // the search's first rollout pass) and global memory (gains): the calls carry nothing.
-template <int NC, int G, bool STREAM, bool LONG = false>
-__device__ __attribute__((noinline)) void grp_expand(double* lds, int g, int n_rt, int lane, double* rows_rt, long long* prof) {
+template <int NC, int G, bool STREAM, bool LONG = false, bool ALM = false>
+__device__ __attribute__((noinline)) void grp_expand(double* lds, int g, int n_rt, int lane, double* rows_rt, long long* prof,
+                                                     GrpAlm ga = GrpAlm{nullptr, nullptr, 0}) {
     static_assert(STREAM || !LONG, "long layout: every expansion goes to its rows in global memory");
+    static_assert(!ALM || LONG, "augmented Lagrangian in pairs: the long layout");
     const int N = NC ? NC : uniform_int(n_rt);
     Lds l;
     carve_group_t<LONG>(l, lds, N, G, g);
@@ -604,9 +628,16 @@ __device__ __attribute__((noinline)) void grp_expand(double* lds, int g, int n_r
     load_cst_lds(c, grp_cst(lds, N, g));
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    if (ALM) al = grp_almst(ga, grp_state(lds, N, g)->J_pair);
     const long long t0 = (CILQR_GPROF && prof) ? (long long)__builtin_readcyclecounter() : 0;
     l.W = 0; // the lane window gives way to the expansion (the rows' one lane lookup each: global memory)
-    if (STREAM) {
+    if (STREAM && ALM) {
+        double* const rows = (double*)uniform_ptr(rows_rt);
+        l.gl = rows;
+        l.lxs = 16;
+        l.kd = rows + CILQR_GLA_JAC;
+        cost_and_model_derivatives<true, true, CILQR_GL_ROW, true>(c, l, al, lane);
+    } else if (STREAM) {
         double* const rows = (double*)uniform_ptr(rows_rt);
         l.gl = rows;
         l.kd = rows + CILQR_GRP_ROW_JAC; // (the Jacobians of step k at slot 16 of row k)
@@ -641,7 +672,7 @@ __device__ inline void grp_after_sweep(GrpSt* st, bool ok, double dV0, double dV
 
 // gA: the trajectory whose expansion is in LDS; gB: the one whose rows are in global memory, or -1.  Returns the number of
 // trajectories that now wait for a rollout pass.
-template <int NC, int G, bool LONG = false>
+template <int NC, int G, bool LONG = false, bool ALM = false>
 __device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int gB_rt, int n_rt, int lane, double* scr_blk_rt, int tier_rt,
                                                    long long* profA, long long* profB) {
     const int N = NC ? NC : uniform_int(n_rt);
@@ -670,7 +701,7 @@ __device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int g
         pa.roffA = (unsigned)(((size_t)gA * slot_d + grp_rows_offset(N)) * sizeof(double));
         pa.roffB = (unsigned)(((size_t)gb * slot_d + grp_rows_offset(N)) * sizeof(double));
         double dVA[2], dVB[2];
-        const unsigned ok = backward_sweep_pair<true>(N, l, pa, scr_blk, (unsigned)(G * slot_d * sizeof(double)), lane, dVA, dVB);
+        const unsigned ok = backward_sweep_pair<true, ALM>(N, l, pa, scr_blk, (unsigned)(G * slot_d * sizeof(double)), lane, dVA, dVB);
         if (lane == 0) {
             grp_after_sweep(stA, (ok & 1u) != 0u, dVA[0], dVA[1], tier);
             if (gB >= 0) grp_after_sweep(stB, (ok & 2u) != 0u, dVB[0], dVB[1], tier);
@@ -719,21 +750,23 @@ __device__ __attribute__((noinline)) int grp_sweep(double* lds, int gA_rt, int g
 // get_total_cost (cs:199-287) of trial t of the trajectory in slot g — out of line for the same reason: the trial lives in
 // global memory (src / as: the slab or the first-trial buffer), x's lane window is staged (w0, W), the result is the return
 // value; serial reference-point chains that had to be run are counted in GrpSt::nfb.
-template <int NC, int G, int NCH = 1>
+template <int NC, int G, int NCH = 1, bool LONG = (NCH > 1), bool ALM = false>
 __device__ __attribute__((noinline)) double grp_cost_trial(double* lds, int g, int n_rt, int lane, const double* src, int t, int as,
-                                                            int w0, int W) {
+                                                            int w0, int W, GrpAlm ga = GrpAlm{nullptr, nullptr, 0}) {
+    static_assert(!ALM || LONG, "augmented Lagrangian in pairs: the long layout");
     const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
-    carve_group_t<(NCH > 1)>(l, lds, N, G, g);
+    carve_group_t<LONG>(l, lds, N, G, g);
     l.w0 = w0;
     l.W = W;
     Cst c;
     load_cst_lds(c, grp_cst(lds, N, g));
     AlmSt al;
     al.mu = nullptr; al.mu_next = nullptr; al.rho = 1.0; al.C = 0;
+    if (ALM) al = grp_almst(ga, grp_state(lds, N, g)->J_pair);
     int nfb = 0;
     double J1[1];
-    total_cost_trials<false, NCH, false, 1>(c, l, al, src, t, 1, lane, w0, 0, &nfb, J1, nullptr, 0, as);
+    total_cost_trials<false, NCH, ALM, 1>(c, l, al, src, t, 1, lane, w0, 0, &nfb, J1, nullptr, 0, as);
     if (nfb != 0 && lane == 0) grp_state(lds, N, g)->nfb += nfb;
     return J1[0];
 }
@@ -770,9 +803,9 @@ __device__ __attribute__((noinline)) double grp_cost_trials2(double* lds, int g,
 // The initial trajectory of the trajectory in slot g and its cost (cs:155-197, cs:104): fills x, u, the lane indices and
 // the trial-index seeds; the row-0 lane index comes back in *idx0_out (LDS: GrpSt::idx0).  Once per solve: out of line so
 // that its serial rollout's register needs stay out of the kernel's.
-template <int NC, int G, bool LONG = false>
+template <int NC, int G, bool LONG = false, bool ALM = false>
 __device__ __attribute__((noinline)) double grp_init(double* lds, int g, int n_rt, int lane, double xs0, double xs1, double xs2,
-                                                      double xs3, const double* last_u, int Wcap) {
+                                                      double xs3, const double* last_u, int Wcap, GrpAlm ga = GrpAlm{nullptr, nullptr, 0}) {
     const int N = NC ? NC : uniform_int(n_rt); // (an argument: in a vector register — scalar again, or descriptors built from it count as divergent)
     Lds l;
     carve_group_t<LONG>(l, lds, N, G, g);
@@ -784,10 +817,27 @@ __device__ __attribute__((noinline)) double grp_init(double* lds, int g, int n_r
     int idx0 = 0;
     init_trajectory(c, l, xs, last_u, lane, idx0, Wcap);
     seed_trial_indices(l, N, 2, lane);
-    const double J = total_cost_lds<false>(c, l, al, lane);
+    if (ALM) al = grp_almst(ga, grp_state(lds, N, g)->J_pair);
+    const double J = total_cost_lds<ALM>(c, l, al, lane);
     if (lane == 0) grp_state(lds, N, g)->idx0 = idx0;
     wave_sync();
     return J;
+}
+
+// get_total_cost of the CURRENT trajectory with the current multipliers (cs:342 at the head of every iteration, cs:104 at the
+// end of the solve: under the augmented Lagrangian the multipliers may have moved since the cost was last taken).  The lane
+// window (w0, W) must be staged: the caller is on the search's side of the turn, or restages it.
+template <int NC, int G>
+__device__ __attribute__((noinline)) double grp_recost_alm(double* lds, int g, int n_rt, int lane, int w0, int W, GrpAlm ga) {
+    const int N = NC ? NC : uniform_int(n_rt);
+    Lds l;
+    carve_group_long(l, lds, N, G, g);
+    l.w0 = w0;
+    l.W = W;
+    Cst c;
+    load_cst_lds(c, grp_cst(lds, N, g));
+    const AlmSt al = grp_almst(ga, grp_state(lds, N, g)->J_pair);
+    return total_cost_lds<true>(c, l, al, lane);
 }
 
 // stage_window() for a window that is staged once per SEGMENT instead of once per solve: 16-byte loads, all of a lane's

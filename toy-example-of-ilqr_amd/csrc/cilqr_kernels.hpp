@@ -838,17 +838,30 @@ k_solve(BatchArgs a, const double* __restrict__ x0, const double* last_u,
 // LOOP: the closed planning loop in one launch (cilqr_closed_loop_batch_device; mp:180-197, cs:163-180): a trajectory slot keeps
 // its ego for all its ticks — solve, ego <- x.row(1), tick + 1, next solve warm from the plan just stored where the ego's
 // configuration says so — as k_solve's LOOP builds do, but two egos per wavefront share their rollout passes.
-template <int NC, int G, bool LOOP = false, int NCH = 1>
+template <int NC, int G, bool LOOP = false, int NCH = 1, bool LAY = (NCH > 1), bool ALM = false>
 __global__ void __launch_bounds__(CILQR_WAVE, 2)
 k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, double* u_out, double* __restrict__ x_out,
             cilqr_result* __restrict__ res_out, cilqr_trace_rec* __restrict__ trace_out, int trace_cap) {
     // NCH = 2: horizons of 64 ... 127, two rows per lane — the LONG layout of cilqr_group.hpp (both expansions and the gains in
     // global memory, streamed; trial costs one at a time)
-    constexpr bool LONG = NCH > 1;
-    static_assert(!(LONG && LOOP), "the closed loop in one launch has no long-horizon grouped build");
+    // LAY: the long layout for any horizon (NCH = 1: one row per lane) — what the augmented Lagrangian (ALM) runs in: its dense
+    // l_xx never fits LDS twice, streamed rows take it as they are; the multipliers stay in HBM, rho in GrpSt::J_pair; no
+    // hand-overs between wavefronts (the multipliers are written with plain stores): the host passes a.park = nullptr
+    constexpr bool LONG = LAY;
+    static_assert(!(LONG && LOOP), "the closed loop in one launch has no long-layout grouped build");
+    static_assert(!ALM || LONG, "augmented Lagrangian in pairs: the long layout");
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int N = NC ? NC : a.N;
     double* const scr_blk = a.scratch + (size_t)blockIdx.x * G * grp_scratch_doubles(N);
+    auto alm_of = [&](int bb) {
+        GrpAlm ga{nullptr, nullptr, 0};
+        if (ALM) {
+            ga.mu = a.alm_mu + (size_t)bb * N * a.alm_C;
+            ga.mu_next = a.alm_mu_next + (size_t)bb * N * a.alm_C;
+            ga.C = a.alm_C;
+        }
+        return ga;
+    };
     if (lane < G) {
         GrpSt* st = grp_state(g_lds, N, lane);
         st->phase = GP_EMPTY;
@@ -878,15 +891,15 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             if (gA < 0) break;
             const bool prof2 = CILQR_GPROF && a.prof != nullptr;
             if (LONG)
-                grp_expand<NC, G, true, LONG>(g_lds, gA, N, lane, scr_blk + (size_t)gA * grp_scratch_doubles(N) + grp_rows_offset(N),
-                                              prof2 ? grp_prof(g_lds, N, gA) : nullptr);
+                grp_expand<NC, G, true, LONG, ALM>(g_lds, gA, N, lane, scr_blk + (size_t)gA * grp_scratch_doubles(N) + grp_rows_offset(N),
+                                                   prof2 ? grp_prof(g_lds, N, gA) : nullptr, alm_of(uniform_int(grp_state(g_lds, N, gA)->b)));
             else
                 grp_expand<NC, G, false>(g_lds, gA, N, lane, nullptr, prof2 ? grp_prof(g_lds, N, gA) : nullptr);
             if (gB >= 0)
-                grp_expand<NC, G, true, LONG>(g_lds, gB, N, lane, scr_blk + (size_t)gB * grp_scratch_doubles(N) + grp_rows_offset(N),
-                                              prof2 ? grp_prof(g_lds, N, gB) : nullptr);
-            const int asked = uniform_int(grp_sweep<NC, G, LONG>(g_lds, gA, gB, N, lane, scr_blk, a.tier, prof2 ? grp_prof(g_lds, N, gA) : nullptr,
-                                                                 (prof2 && gB >= 0) ? grp_prof(g_lds, N, gB) : nullptr));
+                grp_expand<NC, G, true, LONG, ALM>(g_lds, gB, N, lane, scr_blk + (size_t)gB * grp_scratch_doubles(N) + grp_rows_offset(N),
+                                                   prof2 ? grp_prof(g_lds, N, gB) : nullptr, alm_of(uniform_int(grp_state(g_lds, N, gB)->b)));
+            const int asked = uniform_int(grp_sweep<NC, G, LONG, ALM>(g_lds, gA, gB, N, lane, scr_blk, a.tier, prof2 ? grp_prof(g_lds, N, gA) : nullptr,
+                                                                      (prof2 && gB >= 0) ? grp_prof(g_lds, N, gB) : nullptr));
             n_live += asked;
             if (asked == ((gB >= 0) ? 2 : 1)) break; // (nobody failed: no second pass)
         }
@@ -937,6 +950,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
             bool deep_next = false, have_all = false;
             int keep_b = -1, t_done = 0; // closed loop: the slot's next trajectory is the same ego, its next tick
             int it0 = 0;                 // sliced solves: the iteration count at which this slice began
+            bool win_ok = false;         // (ALM) this trajectory's lane window is staged in the shared area right now
             double J_cur = 0.0, J_init = 0.0, lamb = 0.0, new_J = 0.0, dV[2] = {0.0, 0.0};
             long long tl_start = 0;
             int entry = (phase == GP_SEARCH) ? 1 : (phase == GP_BPF ? 2 : 0); // where the segment takes the solve up again
@@ -983,7 +997,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                 t_done = LOOP ? uniform_int(st->t_done) : 0;
                 it0 = uniform_int(st->pad1);
                 load_cst_lds(c, grp_cst(g_lds, N, g));
-                if (entry == 1) stage_window_fast(c, l, idx0, a.W, lane); // (the window area belongs to whoever's segment it is)
+                if (entry == 1) { stage_window_fast(c, l, idx0, a.W, lane); win_ok = true; } // (the window area belongs to whoever's segment it is)
                 GPROF_ADD(PH_TC_REF); // (grouped build: slot 10 = the segment's set-up — state, constants, lane window)
             }
             for (;;) {
@@ -1055,8 +1069,20 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         } else {
                             xs0 = x0[4 * b]; xs1 = x0[4 * b + 1]; xs2 = x0[4 * b + 2]; xs3 = x0[4 * b + 3];
                         }
-                        J_cur = grp_init<NC, G, LONG>(g_lds, g, N, lane, xs0, xs1, xs2, xs3, lu ? lu + (size_t)b * N * 2 : nullptr, a.W);
+                        if (ALM) { // cs:88-93: fresh multipliers and penalty weight unless this call continues a previous solution
+                            const GrpAlm ga0 = alm_of(b);
+                            double rho0 = a.alm_rho[b];
+                            if (lu == nullptr) {
+                                rho0 = c.k->alm_rho_init;
+                                for (int e = lane; e < N * ga0.C; e += CILQR_WAVE) { const_cast<double*>(ga0.mu)[e] = 0.0; ga0.mu_next[e] = 0.0; }
+                            }
+                            if (lane == 0) st->J_pair = rho0;
+                            wave_sync();
+                        }
+                        J_cur = grp_init<NC, G, LONG, ALM>(g_lds, g, N, lane, xs0, xs1, xs2, xs3, lu ? lu + (size_t)b * N * 2 : nullptr, a.W, alm_of(b));
+                        win_ok = true;
                         idx0 = uniform_int(st->idx0);
+                        if (ALM) { l.w0 = idx0; l.W = (c.L - idx0 < a.W) ? c.L - idx0 : a.W; } // (what init_trajectory staged)
                         J_init = J_cur;
                         lamb = c.k->init_lamb;
                         status = CILQR_RUNNING;
@@ -1069,15 +1095,20 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                     if (iters < c.max_iter) {
                         // ---- iter_step ----
                         cost_evals += 1; // ori_cost (cs:342) — equals J_cur bit for bit, not recomputed
+                        if (ALM) { // ... under the augmented Lagrangian it IS recomputed: the multipliers may have moved since
+                            if (!win_ok) { stage_window_fast(c, l, idx0, a.W, lane); win_ok = true; }
+                            J_cur = grp_recost_alm<NC, G>(g_lds, g, N, lane, l.w0, l.W, alm_of(b));
+                        }
                         if (prof) { GPROF_ADD(PH_TC_STAGE); }
                         if (split) { phase = GP_EXPAND; break; } // its expansion and sweep run after every trajectory's segment
                         // (a trajectory on its own — second pass after a failed sweep, or round 4's turn: the same two functions, one
                         //  trajectory; they read lambda and leave the request in its block)
                         if (lane == 0) { st->lamb = lamb; st->deep_next = deep_next ? 1 : 0; st->J_cur = J_cur; }
                         lds_sync();
-                        if (LONG) grp_expand<NC, G, true, LONG>(g_lds, g, N, lane, scr + grp_rows_offset(N), prof ? pacc : nullptr);
+                        if (LONG) grp_expand<NC, G, true, LONG, ALM>(g_lds, g, N, lane, scr + grp_rows_offset(N), prof ? pacc : nullptr, alm_of(b));
                         else grp_expand<NC, G, false>(g_lds, g, N, lane, nullptr, prof ? pacc : nullptr);
-                        const bool ok = uniform_int(grp_sweep<NC, G, LONG>(g_lds, g, -1, N, lane, scr_blk, a.tier, prof ? pacc : nullptr, nullptr)) == 1;
+                        win_ok = false; // (the sweep's rings have been over the window's area)
+                        const bool ok = uniform_int(grp_sweep<NC, G, LONG, ALM>(g_lds, g, -1, N, lane, scr_blk, a.tier, prof ? pacc : nullptr, nullptr)) == 1;
                         if (prof) t_ph = (long long)__builtin_readcyclecounter(); // (booked inside)
                         status = CILQR_RUNNING;
                         dV[0] = st->dV0;
@@ -1113,7 +1144,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                             Jp[0] = grp_cost_trials2<NC, (G > 1 ? G : 2)>(g_lds, g, N, lane, src, t0, l.w0, l.W);
                             Jp[1] = st->J_pair;
                         } else {
-                            Jp[0] = grp_cost_trial<NC, G, NCH>(g_lds, g, N, lane, src, t0, as, l.w0, l.W);
+                            Jp[0] = grp_cost_trial<NC, G, NCH, LONG, ALM>(g_lds, g, N, lane, src, t0, as, l.w0, l.W, alm_of(b));
                             Jp[1] = 0.0;
                         }
                         GPROF_ADD(PH_TRIAL_COST);
@@ -1143,7 +1174,17 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         break; // phase stays GP_SEARCH, t0 = 1
                     }
                     deep_next = (trials > 1);
-                    if (!done) status = CILQR_FORWARD_PASS_FAIL;
+                    if (!done) {
+                        status = CILQR_FORWARD_PASS_FAIL;
+                        if (ALM) { // cs:377-378
+                            const GrpAlm ga1 = alm_of(b);
+                            for (int e = lane; e < N * ga1.C; e += CILQR_WAVE) const_cast<double*>(ga1.mu)[e] = ga1.mu_next[e];
+                            const double r = (1 + c.k->alm_gamma) * st->J_pair;
+                            wave_sync();
+                            if (lane == 0) st->J_pair = (c.k->max_rho < r) ? c.k->max_rho : r;
+                            wave_sync();
+                        }
+                    }
                 }
                 bool leave = true; // (max_iter reached before the first iteration: nothing below applies)
                 if (iters < c.max_iter) {
@@ -1225,6 +1266,11 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
                         }
                     }
                     continue;
+                }
+                if (ALM) { // J_final := get_total_cost(u_ret, x_ret) with the final multipliers; the penalty weight back to the handle
+                    if (!win_ok) { stage_window_fast(c, l, idx0, a.W, lane); win_ok = true; }
+                    J_cur = grp_recost_alm<NC, G>(g_lds, g, N, lane, l.w0, l.W, alm_of(b));
+                    if (lane == 0) a.alm_rho[b] = st->J_pair;
                 }
                 // results: u, x of the last accepted trajectory
                 for (int k = lane; k <= N; k += CILQR_WAVE) {

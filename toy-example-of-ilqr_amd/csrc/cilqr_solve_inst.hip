@@ -66,3 +66,8 @@ template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 4
 template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 #endif
+#if CILQR_INST_GROUP == 2
+// (prepared, unmeasured) augmented Lagrangian in pairs: the long layout with one row per lane / two rows per lane
+template __global__ void k_solve_grp<0, 2, false, 1, true, true> CILQR_GRP_SIGNATURE;
+template __global__ void k_solve_grp<0, 2, false, 2, true, true> CILQR_GRP_SIGNATURE;
+#endif
