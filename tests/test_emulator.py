@@ -120,7 +120,7 @@ def test_long_layout_and_lone_builds(emu_libs):
     wait, two rows per lane) on the mixed scenarios of configs[3], and the lone / helper builds of k_solve on the same batch;
     straight-lane starts (RearCenter model) of config 2 through the helper build and in pairs."""
     r = run(emu_libs, r"""
-wl = pkg.workloads.config4(B=12, N=100)
+wl = pkg.workloads.config4(B=8, N=100)
 ref = ORC.solve_batch(wl.params, scenes_of(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=4)
 for mode in (2, 0, -1):
     eng = pkg.BatchedCILQR(wl.params, wl.scenes); eng.set_group_mode(mode)
@@ -176,6 +176,42 @@ OUT["stats"] = emu_stats()
             assert v["first"] and v["second"], (k, v)
             assert v["launch"]["trajectories_per_wavefront"] == (2 if k.endswith("mode 2") else 1), (k, v)
     healthy(r["stats"])
+
+
+def test_horizons_of_128_to_255(emu_libs):
+    """Round 6 (VERDICT r05 task 9; cs:19): the long layout with four rows per lane — written without a GPU.  Horizons 128 (the
+    first with four rows), 200 and 255 (the cap), both vehicle models, both solve types == oracle; the entry points that have no
+    build at these horizons refuse."""
+    r = run(emu_libs, r"""
+for name, N in (("two_straight", 255), ("three_bend", 200), ("two_borrow", 128)):
+    cfg = pkg.GlobalConfig.get_instance(name); sc = pkg.build_scenario(cfg, name)
+    obs = np.concatenate([sc.obstacles, np.repeat(sc.obstacles[:, -1:, :], 120, axis=1)], axis=1)
+    tab = pkg.SceneTable(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity)
+    scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, 3, 0x255)
+    for st in (0, 1):
+        p = pkg.params_from_config(cfg, N=N, solve_type=st, max_iter=20)
+        eng = pkg.BatchedCILQR(p, tab)
+        out = eng.solve_batch(x0)
+        ref = ORC.solve_batch(p, scene, x0, n_threads=4)
+        refuses = 0
+        for call in (lambda: eng.total_cost(out["u"][:1], out["x"][:1]), lambda: eng.init_traj(x0[:1])):
+            try: call()
+            except pkg.CilqrError as e: refuses += int(e.code == -4)
+        OUT["%s N=%d type %d" % (name, N, st)] = dict(same=same(out, ref), launch=eng.last_launch_info(), refuses=refuses,
+                                                     iters=out["res"]["iters"].tolist())
+        eng.close()
+try:
+    pkg.BatchedCILQR(pkg.params_from_config(cfg, N=256), tab); OUT["N=256 accepted"] = True
+except pkg.CilqrError:
+    OUT["N=256 accepted"] = False
+OUT["stats"] = emu_stats()
+""", timeout=1200)
+    assert r.pop("N=256 accepted") is False
+    healthy(r.pop("stats"))
+    assert len(r) == 6
+    for k, v in r.items():
+        assert v["same"] and v["launch"]["trajectories_per_wavefront"] == 2 and v["refuses"] == 2, (k, v)
 
 
 def test_closed_loop_in_one_launch(emu_libs):

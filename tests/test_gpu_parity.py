@@ -939,7 +939,38 @@ def test_horizon_boundaries(pkg, orc_det, scenarios, N):
         eng.close()
         compare_solves(out0, refs, f"{name} N={N} (no helper)")
     with pytest.raises(Exception):
-        pkg.BatchedCILQR(pkg.params_from_config(cfg, N=128), tab)
+        pkg.BatchedCILQR(pkg.params_from_config(cfg, N=256), tab)
+
+
+@pytest.mark.parametrize("N,B", [(128, 40), (150, 300), (200, 300), (255, 24)])
+def test_horizons_above_127(pkg, orc_det, scenarios, N, B):
+    """Round 6 (VERDICT r05 task 9; cs:19: upstream's N is any int): horizons of 128 ... 255 — the grouped kernel's long layout
+    with FOUR rows per lane, the only family of builds at these horizons, so every batch size runs in pairs.  Both vehicle
+    models, both solve types, == oracle; obstacle routes extended with their last sample where they are shorter than N + 1
+    (the same arrays on both sides).  What has no build here says CILQR_ERR_UNSUPPORTED."""
+    from oracle import Scene
+    for name in ("two_straight", "three_bend"):
+        cfg, sc = scenarios[name]
+        obs = np.concatenate([sc.obstacles, np.repeat(sc.obstacles[:, -1:, :], 120, axis=1)], axis=1)
+        tab = pkg.SceneTable(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity)
+        scene = Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity)
+        x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 2000 + N)
+        for st in (0, 1):
+            if st == 1 and B > 64:
+                continue   # (the augmented Lagrangian on a sample: its oracle solves take the longest)
+            p = pkg.params_from_config(cfg, N=N, solve_type=st, max_iter=40)
+            eng = pkg.BatchedCILQR(p, tab)
+            out = eng.solve_batch(x0)
+            assert eng.last_launch_info()["trajectories_per_wavefront"] == 2
+            ref = orc_det.solve_batch(p, scene, x0, n_threads=8)
+            eq_bits(out["u"], ref["u"], f"{name} N={N} type {st} u")
+            eq_bits(out["x"], ref["x"], f"{name} N={N} type {st} x")
+            for f in ("iters", "end_reason", "ls_trials", "cost_evals"):
+                assert (out["res"][f] == ref["res"][f]).all(), (name, N, st, f)
+            eq_bits(out["res"]["J_final"], ref["res"]["J_final"], "J_final")
+            with pytest.raises(pkg.CilqrError):
+                eng.total_cost(out["u"][:1], out["x"][:1])
+            eng.close()
 
 
 _CONCURRENT_SCRIPT = r"""

@@ -19,7 +19,7 @@ ERR_DEVICE = -3
 ERR_UNSUPPORTED = -4
 ERR_NO_DEVICE = -5
 
-MAX_HORIZON = 127
+MAX_HORIZON = 255
 MAX_ALPHA_TRIALS = 20
 PROF_SLOTS = 17
 DBG_SERIAL_REF_SCAN = 1

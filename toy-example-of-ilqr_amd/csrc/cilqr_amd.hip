@@ -31,6 +31,8 @@ extern template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATUR
 extern template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 1, true, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 2, true, true> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, false, 4> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, false, 4, true, true> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
 // piecewise kernels
@@ -967,7 +969,7 @@ extern "C" int cilqr_set_params(cilqr_handle* h, const cilqr_params* params, int
     if (!h || !params || n_params < 1) return fail(CILQR_ERR_BAD_ARG, "bad params table");
     for (int i = 0; i < n_params; ++i) {
         const cilqr_params& p = params[i];
-        if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 127]");
+        if (p.N < 2 || p.N > CILQR_MAX_HORIZON) return fail(CILQR_ERR_BAD_ARG, "N must be in [2, 255]");
         if (p.N != params[0].N) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share N");
         if (p.solve_type != 0 && p.solve_type != 1) return fail(CILQR_ERR_BAD_ARG, "solve_type must be 0 (barrier) or 1 (alm)");
         if (p.solve_type != params[0].solve_type) return fail(CILQR_ERR_BAD_ARG, "all parameter sets of a handle must share solve_type");
@@ -1182,7 +1184,12 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
 // expansion in global memory (two rows per lane, large batches) shares work; the helper range of the others grows with
 // the horizon as measured before work sharing existed.
 static bool two_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE; }
+// horizons of 128 ... 255 (round 6): four rows per lane.  ONE family of builds takes them — the grouped kernel's long layout, both
+// solve types — so every launch of such a handle runs in pairs whatever the batch size and the group mode; what has no build
+// at these horizons (closed loop in one launch, piecewise entry points, testing aids, cycle accounting) says CILQR_ERR_UNSUPPORTED
+static bool four_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > 2 * CILQR_WAVE; }
 static bool wants_helper(const cilqr_handle* h, int B) {
+    if (four_rows(h)) return false;
     if (h->helper_mode >= 0) return h->helper_mode == 1;
     if (!two_rows(h)) return B <= h->helper_max_batch;
     if (h->helper_max_batch_two_rows >= 0) return B <= h->helper_max_batch_two_rows;
@@ -1225,6 +1232,7 @@ static bool global_expansion(const cilqr_handle* h, int B) {
 // does this batch run the grouped build (k_solve_grp: CILQR_GROUP trajectories per wavefront, one rollout pass for all)?
 // Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
 static bool grouped(const cilqr_handle* h, int B) {
+    if (four_rows(h)) return !h->looping && h->debug_flags == 0 && !h->profiling && h->persistent_blocks;
     if (h->group_mode == 0 || h->group_mode == 1) return false;
     if (h->debug_flags != 0) return false;
     if (h->params[0].solve_type == 1 && ((!h->group_alm && h->group_mode < 2) || h->looping || h->profiling)) return false; // (ALM in pairs: the long layout)
@@ -1452,6 +1460,9 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     } fused_scope(h);
     if (loop.ticks >= 1 && (h->debug_flags != 0 || h->profiling))
         return fail(CILQR_ERR_UNSUPPORTED, "the closed loop has no testing-aid / cycle-accounting builds");
+    if (four_rows(h) && !grouped(h, B))
+        return fail(CILQR_ERR_UNSUPPORTED, "horizons above 127 run the grouped kernel's long layout only: no closed loop in one launch, no "
+                                           "testing aids / cycle accounting, persistent blocks on");
     // Which launch slot: slot 0 on the caller's stream, one launch of the handle at a time — or, after
     // cilqr_set_batches_in_flight(k > 1), the next of k slots round robin, each with a stream, scratch areas and control words
     // of its own.  Not for the augmented Lagrangian (its multipliers live in the handle, indexed by trajectory: two launches
@@ -1533,6 +1544,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         const bool longl = a.N + 1 > CILQR_WAVE || a.alm; // two rows per lane, or the augmented Lagrangian: the long layout
         if (longl) kg = (a.N == 100) ? k_solve_grp<100, 2, false, 2> : k_solve_grp<0, 2, false, 2>;
         if (a.alm) kg = (a.N + 1 > CILQR_WAVE) ? k_solve_grp<0, 2, false, 2, true, true> : k_solve_grp<0, 2, false, 1, true, true>;
+        if (a.N + 1 > 2 * CILQR_WAVE) kg = a.alm ? k_solve_grp<0, 2, false, 4, true, true> : k_solve_grp<0, 2, false, 4>;
         const size_t shm = longl ? grpl_lds_bytes(a.N, a.W, G) : grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);
@@ -1918,6 +1930,7 @@ static int piece_begin(cilqr_handle* h, int B, const int32_t* scenario_id, const
     int rc = check_ready(h);
     if (rc) return rc;
     if (B < 1) return fail(CILQR_ERR_BAD_ARG, "B < 1");
+    if (four_rows(h)) return fail(CILQR_ERR_UNSUPPORTED, "the stage-by-stage entry points hold one or two rows per lane: horizons up to 127");
     rc = validate_ids(h, B, scenario_id, param_id, tick);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));

@@ -66,6 +66,13 @@ template __global__ void k_solve_grp<100, 2, false, 2> CILQR_GRP_SIGNATURE;
 #elif CILQR_INST_GROUP == 4
 template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 #endif
+#if CILQR_INST_GROUP == 1
+// round 6: horizons of 128 ... 255 — the long layout with FOUR rows per lane (cs:19: N is any int upstream); barrier and ALM
+template __global__ void k_solve_grp<0, 2, false, 4> CILQR_GRP_SIGNATURE;
+#endif
+#if CILQR_INST_GROUP == 0
+template __global__ void k_solve_grp<0, 2, false, 4, true, true> CILQR_GRP_SIGNATURE;
+#endif
 #if CILQR_INST_GROUP == 2
 // (prepared, unmeasured) augmented Lagrangian in pairs: the long layout with one row per lane / two rows per lane
 template __global__ void k_solve_grp<0, 2, false, 1, true, true> CILQR_GRP_SIGNATURE;
