@@ -198,11 +198,13 @@ def det_identity(gpu_u, gpu_x, gpu_res, det):
 class GpuRun:
     """One workload resident in HBM + the timed loop over it."""
 
-    def __init__(self, pkg, torch, wl, B, local_rank):
+    def __init__(self, pkg, torch, wl, B, local_rank, group_mode=None):
         self.pkg, self.torch, self.wl, self.B = pkg, torch, wl, B
         N = self.N = wl.N
         self.dev = dev = torch.device("cuda", local_rank)
         self.eng = pkg.BatchedCILQR(wl.params, wl.scenes, device=local_rank)
+        if group_mode is not None:
+            self.eng.set_group_mode(group_mode)
         self.d_x0 = torch.from_numpy(wl.x0).to(dev)
         self.d_sid = torch.from_numpy(wl.scenario_id).to(dev)
         self.d_pid = torch.from_numpy(wl.param_id).to(dev)
@@ -724,12 +726,12 @@ def main():
 
     # the other workloads of the default command: config 2 (1024 trajectories per GPU), a latency measurement, and —
     # on several GPUs — BASELINE configs[3] (8192 trajectories of horizon 100 per rank)
-    def side_run(cfg, steps_side, note, alm=False, cpu_check_rows=0, in_flight=1):
+    def side_run(cfg, steps_side, note, alm=False, cpu_check_rows=0, in_flight=1, group_mode=None):
         wl_s, B_s = _make_workload(pkg, cfg, 0, 0, rank)
         if alm:
             wl_s = pkg.workloads.Workload(wl_s.name + "_alm", [pkg.copy_params(q, solve_type=1) for q in wl_s.params],
                                           wl_s.scenes, wl_s.x0, wl_s.scenario_id, wl_s.param_id, wl_s.tick)
-        run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank)
+        run_s = GpuRun(pkg, torch, wl_s, B_s, local_rank, group_mode=group_mode)
         el_s, kms_s, res_s = run_s.timed(steps_side, min(args.warmup, 2), barrier, in_flight=in_flight,
                                          seq_steps=max(3, steps_side // 3) if in_flight > 1 else 0)
         li_s = getattr(run_s, "launch_info", None)
@@ -806,7 +808,7 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported in the line
             return {"error": f"{type(e).__name__}: {e}"[:500]} if rank == 0 else None
 
-    second = third = fourth = closed = closed30 = alm5 = None
+    second = third = fourth = closed = closed30 = alm5 = alm5p = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
         third = guarded(side_run, 3, max(args.steps, 20), "BASELINE configs[2]: 8192 three_bend trajectories = two rounds of the "
                         "chip's trajectory slots; one launch at a time a third of it is tail (`in_flight.sequential`)",
@@ -821,6 +823,10 @@ def main():
         alm5 = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm (cs:88-93, 253-261, "
                        "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True,
                        cpu_check_rows=1024)
+        # round 6: the same batch on the grouped kernel's ALM builds (two trajectories per wavefront; opt-in until measured here)
+        alm5p = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm IN PAIRS per wavefront "
+                        "(cilqr_set_group_mode(2): the grouped kernel's long layout with dense rows; written without a GPU, bit-exact "
+                        "on the wave64 emulator of tests/emu/)", alm=True, cpu_check_rows=1024, group_mode=2)
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
@@ -851,7 +857,7 @@ def main():
                       "converged": int(stats[2]), "max_lamb": int(stats[3]), "max_iter": int(stats[4]),
                       "nan_costs": int(stats[6]), "sum_J_final": float(stats[5]), "pipelined": pipelined,
                       ("config2_latency" if world == 1 else "config2_weak_scaling"): second,
-                      "config3": third, "config4_sharded": fourth, "closed_loop": closed, "closed_loop_N30": closed30, "config5_alm": alm5,
+                      "config3": third, "config4_sharded": fourth, "closed_loop": closed, "closed_loop_N30": closed30, "config5_alm": alm5, "config5_alm_pairs": alm5p,
                       "ranks": ranks, "distinct_devices": distinct, "per_rank": per_rank,
                       "kernel_ms_min_max_over_ranks": [float(min(r["kernel_ms"] for r in per_rank)),
                                                        float(max(r["kernel_ms"] for r in per_rank))]},

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: the hand-over protocol of the grouped kernel (tickets, claims, pushes, sliced solves, bounded waits) run on
+the wave64 emulator (tests/emu/) under ADVERSARIAL scheduling — resident blocks visited in random order, stalled or given bursts
+of turns (CILQR_EMU_SCHED_SEED) — over random launch shapes: batch size, horizon, resident blocks, slice length.  The same REAL
+device code the GPU runs, in interleavings a GPU stress run only samples by luck.  Every trajectory must come back == oracle,
+no bounded wait may expire, nothing may stay CILQR_END_NOT_SOLVED.
+
+    python scripts/emu_stress.py [--cases 40] [--seed 1] [--lib tests/emu/_build/libcilqr_emu_dev.so] [--long]
+prints one JSON line per case and a summary; exit 1 on any mismatch."""
+import argparse
+import json
+import os
+import random
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASE = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+c = json.loads(sys.argv[2])
+cfg = pkg.GlobalConfig.get_instance(c["scenario"]); sc = pkg.build_scenario(cfg, c["scenario"])
+p = pkg.params_from_config(cfg, N=c["N"], solve_type=c.get("solve_type", 0), max_iter=c.get("max_iter", 100))
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(2)
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, c["B"], c["x0_seed"])
+ok_wait = True
+try:
+    out = eng.solve_batch(x0)
+except RuntimeError as e:
+    ok_wait = False; out = None; err = str(e)
+ref = Oracle("det").solve_batch(p, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity), x0, n_threads=2)
+r = dict(c)
+if out is None:
+    r.update(ok=False, error=err[:200])
+else:
+    bad = [int(b) for b in range(c["B"]) if not (np.array_equal(out["u"][b], ref["u"][b]) and np.array_equal(out["x"][b], ref["x"][b]) and out["res"]["iters"][b] == ref["res"]["iters"][b])]
+    r.update(ok=not bad, mismatching=bad[:8], not_solved=int((out["res"]["end_reason"] == 4).sum()), parked=eng.resume_stats(),
+             launch_error=eng.work_sharing_stats()["error"], blocks=eng.last_launch_info()["blocks"], iters_max=int(out["res"]["iters"].max()))
+    r["ok"] = r["ok"] and r["not_solved"] == 0 and r["launch_error"] == 0
+print("CASE " + json.dumps(r))
+"""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lib", default=os.path.join(ROOT, "tests", "emu", "_build", "libcilqr_emu_dev.so"))
+    ap.add_argument("--long", action="store_true", help="horizons above 63 too (the long layout: slower)")
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    bad = 0
+    tot_parked = 0
+    for i in range(a.cases):
+        N = rng.choice([20, 30, 37, 50] + ([70, 100] if a.long else []))
+        c = {"scenario": rng.choice(["three_bend", "two_straight", "two_borrow"]), "N": N,
+             "B": rng.choice([3, 5, 9, 16, 17, 24, 33, 48] if N <= 63 else [3, 5, 9, 12]), "x0_seed": rng.randrange(1 << 30),
+             "max_iter": rng.choice([100, 100, 40]), "sched_seed": rng.randrange(1, 1 << 30),
+             "blocks_per_cu": rng.choice([1, 2, 3, 4, 8]), "cus": rng.choice([1, 1, 2]),
+             "slice": rng.choice([1, 2, 5, 16, 0]), "window": rng.choice([0, 50, 200, 1000]), "wait_model": "real"}
+        env = dict(os.environ)
+        env.update({"CILQR_AMD_LIB": a.lib, "CILQR_AMD_LIB_DEV": a.lib, "CILQR_EMU_SCHED_SEED": str(c["sched_seed"]),
+                    "CILQR_EMU_BLOCKS_PER_CU": str(c["blocks_per_cu"]), "CILQR_EMU_CUS": str(c["cus"]),
+                    "CILQR_TUNE": "group_slice=%d,group_slice_long=%d,group_slice_window=%d" % (c["slice"], c["slice"], c["window"])})
+        r = subprocess.run([sys.executable, "-c", CASE, ROOT, json.dumps(c)], capture_output=True, text=True, timeout=1800, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE ")]
+        if not line:
+            print(json.dumps(dict(c, ok=False, crashed=r.stderr[-400:])), flush=True)
+            bad += 1
+            continue
+        res = json.loads(line[-1][5:])
+        tot_parked += res.get("parked", 0)
+        print(json.dumps(res), flush=True)
+        bad += 0 if res["ok"] else 1
+    print(json.dumps({"cases": a.cases, "failed": bad, "hand_overs": tot_parked}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,11 @@ double* lds_base() { return reinterpret_cast<double*>(g_cur->blk->lds); }
 int lane_id() { return g_cur->lane; }
 long long clock_ticks() { return ++g_clock; }
 
+static unsigned long long g_sched_seed = 0;
+static unsigned sched_rand() {  // xorshift64*
+    g_sched_seed ^= g_sched_seed >> 12; g_sched_seed ^= g_sched_seed << 25; g_sched_seed ^= g_sched_seed >> 27;
+    return (unsigned)((g_sched_seed * 2685821657736338717ULL) >> 33);
+}
 static int env_int(const char* name, int dflt) {
     const char* e = std::getenv(name);
     return e ? std::atoi(e) : dflt;
@@ -296,6 +301,10 @@ void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
     }
     if (shm > LDS_PER_BLOCK) { std::fprintf(stderr, "emu: %zu bytes of LDS asked for, a CU has %zu\n", shm, LDS_PER_BLOCK); std::abort(); }
     ++g_stats.launches;
+    {
+        const int seed = env_int("CILQR_EMU_SCHED_SEED", 0);
+        g_sched_seed = seed ? (0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)g_stats.launches) | 1ULL : 0ULL;
+    }
     const int threads = (int)(block.x * block.y * block.z);
     const long long n_blocks = (long long)grid.x * grid.y * grid.z;
     const int max_res = std::max(1, std::min<int>((int)(LDS_ARENA / LDS_PER_BLOCK), env_int("CILQR_EMU_RESIDENT_BLOCKS", 16)));
@@ -330,6 +339,25 @@ void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
             res.push_back(b);
         }
         bool any = false;
+        if (g_sched_seed) {
+            // ADVERSARIAL SCHEDULING (CILQR_EMU_SCHED_SEED): the resident blocks are visited in random order and a block is given a
+            // random number of turns — or none: it stalls for a while — so that protocols between blocks (tickets, claims, pushes,
+            // bounded waits) meet interleavings a fair round robin never produces.  Results must not depend on it.
+            std::vector<Block*> order(res);
+            for (size_t i = order.size(); i > 1; --i) std::swap(order[i - 1], order[sched_rand() % i]);
+            for (Block* b : order) {
+                const unsigned r = sched_rand() % 16;
+                const int turns = r < 4 ? 0 : (r < 12 ? 1 : (r < 15 ? 4 : 64));
+                for (int t = 0; t < turns; ++t) {
+                    bool a2 = false;
+                    for (int w = 0; w < b->n_waves; ++w) a2 |= visit_wave(*b, w);
+                    a2 |= visit_block_barrier(*b);
+                    any |= a2;
+                    if (!a2) break;
+                }
+                if (turns == 0 && b->live > 0) any = true;  // (a stalled block is not a deadlock)
+            }
+        } else
         for (Block* b : res) {
             for (int w = 0; w < b->n_waves; ++w) any |= visit_wave(*b, w);
             any |= visit_block_barrier(*b);

@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 TOL_LIBM = 1e-5  # north_star: trajectories and final cost within 1e-5 of the reference CPU solver
 
 
+def rehearsal_size(B):
+    """CILQR_TEST_SHRINK=k divides the batch sizes of the round-6 tests by k (never below 8): the same test bodies rehearsed on the
+    wave64 emulator of tests/emu/, where a solve takes a tenth of a second instead of microseconds.  Unset on a GPU."""
+    import os
+    k = int(os.environ.get("CILQR_TEST_SHRINK", "1"))
+    return max(8, B // k) if k > 1 else B
+
+
 def eq_bits(a, b, what=""):
     """equal as IEEE values (+0 == -0, NaN == NaN positionally)"""
     a, b = np.asarray(a), np.asarray(b)
@@ -558,6 +566,45 @@ def test_alm_closed_loop_keeps_multipliers(pkg, orc_det, engines):
         x0 = out["x"][0, 1].copy()
 
 
+@pytest.mark.parametrize("name,N,B", [("three_bend", 50, 600), ("two_borrow", 100, 200), ("three_straight", 30, 300)])
+def test_alm_in_pairs_per_wavefront(pkg, orc_det, scenarios, name, N, B):
+    """Round 6 (VERDICT r05 task 2): the augmented Lagrangian on the grouped kernel — two trajectories per wavefront, the long
+    layout at every horizon, dense 32-double rows, rho per trajectory in GrpSt, multipliers in HBM — chosen with
+    cilqr_set_group_mode(2) (the kernels were written while the GPU pool was closed and are bit-exact on the wave64 emulator,
+    tests/test_emulator.py; the default dispatch stays on k_solve's builds until this test has passed on a GPU).  Cold solves with
+    the decision trace, then a second call warm-started from the first one's plan, which continues from the multipliers the
+    handle kept (hpp:106-112, cs:88-93): == stateful oracle solvers on a sample, == the lone-wavefront builds on every row."""
+    cfg, sc = scenarios[name]
+    B = rehearsal_size(B)
+    p = pkg.params_from_config(cfg, N=N, solve_type=1, use_last_solution=1)
+    tab = pkg.SceneTable.from_scenario(sc)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xA1A + N)
+    outs = {}
+    for mode in (2, 0):
+        eng = pkg.BatchedCILQR(p, tab)
+        eng.set_group_mode(mode)
+        first = eng.solve_batch(x0, trace_cap=128)
+        assert eng.last_launch_info()["trajectories_per_wavefront"] == (2 if mode == 2 else 1)
+        second = eng.solve_batch(first["x"][:, 1].copy(), tick=np.ones(B, np.int32), last_u=first["u"], trace_cap=128)
+        mu, _mu_next, rho = eng.get_alm_state(B)
+        outs[mode] = (first, second, mu, rho)
+        eng.close()
+    for k in (0, 1):
+        a, b = outs[2][k], outs[0][k]
+        eq_bits(a["u"], b["u"], f"pairs vs lone, call {k}: u")
+        eq_bits(a["x"], b["x"], f"pairs vs lone, call {k}: x")
+        assert (a["res"] == b["res"]).all() and (a["trace"] == b["trace"]).all(), k
+    eq_bits(outs[2][2], outs[0][2], "multipliers after two calls")
+    eq_bits(outs[2][3], outs[0][3], "rho after two calls")
+    for b in range(0, B, max(1, B // 24)):   # the oracle on a sample (its ALM solves are the slow ones)
+        s = orc_det.solver(p)
+        s.reset()
+        r1 = s.solve(x0[b], oracle_scene(sc))
+        compare_solves({k: v[b:b + 1] for k, v in outs[2][0].items()}, [r1], f"alm pairs {name} b={b} first")
+        r2 = s.solve(r1["x"][1], oracle_scene(sc, 1))
+        compare_solves({k: v[b:b + 1] for k, v in outs[2][1].items()}, [r2], f"alm pairs {name} b={b} second")
+
+
 # ---- BASELINE.json configurations at (or near) full size ------------------------------------------
 def test_config2_full_batch_bitexact(pkg, orc_det):
     """configs[1], the benchmark workload: all 1024 trajectories, every output field, against the oracle."""
@@ -949,6 +996,7 @@ def test_horizons_above_127(pkg, orc_det, scenarios, N, B):
     models, both solve types, == oracle; obstacle routes extended with their last sample where they are shorter than N + 1
     (the same arrays on both sides).  What has no build here says CILQR_ERR_UNSUPPORTED."""
     from oracle import Scene
+    B = rehearsal_size(B)
     for name in ("two_straight", "three_bend"):
         cfg, sc = scenarios[name]
         obs = np.concatenate([sc.obstacles, np.repeat(sc.obstacles[:, -1:, :], 120, axis=1)], axis=1)
