@@ -826,7 +826,7 @@ def main():
         # round 6: the same batch on the grouped kernel's ALM builds (two trajectories per wavefront; opt-in until measured here)
         alm5p = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm IN PAIRS per wavefront "
                         "(cilqr_set_group_mode(2): the grouped kernel's long layout with dense rows; written without a GPU, bit-exact "
-                        "on the wave64 emulator of tests/emu/)", alm=True, cpu_check_rows=1024, group_mode=2)
+                        "on the wave64 emulator of the CPU test suite)", alm=True, cpu_check_rows=1024, group_mode=2)
 
     if rank == 0:
         my_iters = float(res["iters"].sum())

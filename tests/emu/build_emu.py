@@ -81,13 +81,13 @@ def generate(csrc, gen):
     return total
 
 
-def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1", hazards=False):
+def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1", hazards=False, coverage=False):
     csrc = pathlib.Path(csrc)
-    tag = ("dev" if dev else "prod") + ("_hazards" if hazards else "") + ("" if csrc == CSRC else "_" + re.sub(r"\W", "_", str(csrc))[-40:])
+    tag = ("dev" if dev else "prod") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ("" if csrc == CSRC else "_" + re.sub(r"\W", "_", str(csrc))[-40:])
     gen = HERE / "_gen" / tag
     objdir = HERE / "_build" / tag
     objdir.mkdir(parents=True, exist_ok=True)
-    lib = pathlib.Path(out) if out else HERE / "_build" / ("libcilqr_emu" + ("_dev" if dev else "") + ("_hazards" if hazards else "") + ".so")
+    lib = pathlib.Path(out) if out else HERE / "_build" / ("libcilqr_emu" + ("_dev" if dev else "") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ".so")
     generate(csrc, gen)
     deps = list(gen.iterdir()) + [HERE / "emu_runtime.cpp", HERE / "include" / "hip" / "hip_runtime.h", ROOT / "include" / "cilqr_amd.h",
                                   pathlib.Path(__file__)]
@@ -103,6 +103,8 @@ def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1",
 
     # the lockstep-hazard detector (emu_runtime.cpp): every load and store of the KERNEL sources traced
     cov = ["-fsanitize-coverage=trace-pc-guard,trace-loads,trace-stores"] if hazards else []
+    if coverage:  # basic-block coverage of the kernel sources (emu_runtime.cpp, scripts/emu_coverage.py)
+        cov = ["-fsanitize-coverage=trace-pc-guard,pc-table", "-g"]
 
     def cc(src, obj, extra):
         if src.name != "emu_runtime.cpp":
@@ -119,7 +121,7 @@ def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1",
             f.result()
     # (noinline device functions defined in the headers exist once per compilation unit — one code object each on the GPU; here the
     #  identical copies meet in one link)
-    subprocess.run([CLANG, "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in units] + ["-lm", "-lstdc++", "-Wl,--allow-multiple-definition"], check=True)
+    subprocess.run([CLANG, "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in units] + ["-lm", "-lstdc++", "-ldl", "-Wl,--allow-multiple-definition"], check=True)
     return lib
 
 
@@ -132,5 +134,6 @@ if __name__ == "__main__":
     ap.add_argument("-v", action="store_true")
     ap.add_argument("--opt", default="-O1")
     ap.add_argument("--hazards", action="store_true", help="instrumented build for the lockstep-hazard detector")
+    ap.add_argument("--coverage", action="store_true", help="instrumented build for basic-block coverage of the kernel sources")
     a = ap.parse_args()
-    print(build(a.dev, pathlib.Path(a.csrc), a.out, a.force, a.v, a.opt, a.hazards))
+    print(build(a.dev, pathlib.Path(a.csrc), a.out, a.force, a.v, a.opt, a.hazards, a.coverage))

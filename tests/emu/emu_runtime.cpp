@@ -14,7 +14,9 @@
 // what the emulator cannot show are hardware effects (LDS bank conflicts, the lost-store anomaly of round 4, timing).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -428,8 +430,44 @@ static void hazard_access(const void* addr, int bytes, bool store, const void* p
     extern "C" void __sanitizer_cov_load##n(void* a) { emu::hazard_access(a, n, false, __builtin_return_address(0)); } \
     extern "C" void __sanitizer_cov_store##n(void* a) { emu::hazard_access(a, n, true, __builtin_return_address(0)); }
 EMU_COV(1) EMU_COV(2) EMU_COV(4) EMU_COV(8) EMU_COV(16)
-extern "C" void __sanitizer_cov_trace_pc_guard(unsigned*) {}
-extern "C" void __sanitizer_cov_trace_pc_guard_init(unsigned*, unsigned*) {}
+// ---- basic-block coverage of the kernel sources (build_emu.py --coverage: trace-pc-guard + pc-table) --------------------------
+// Which blocks of the DEVICE code do the emulator tests execute?  (There is no coverage tool for gfx950 code; here the same source
+// runs as host code.)  Guards and the table of block addresses are parallel arrays; at exit the table is written with a hit flag
+// per block to $CILQR_EMU_COV_DIR/<pid>.cov — scripts/emu_coverage.py symbolises and merges.
+namespace emu {
+static unsigned* g_guard_beg = nullptr; static unsigned* g_guard_end = nullptr;
+static const unsigned long* g_pcs_beg = nullptr; static const unsigned long* g_pcs_end = nullptr;
+static std::vector<unsigned char>* g_hit = nullptr;
+static void cov_dump() {
+    const char* dir = std::getenv("CILQR_EMU_COV_DIR");
+    if (!dir || !g_hit || !g_pcs_beg) return;
+    char path[512];
+    std::snprintf(path, sizeof(path), "%s/%d.cov", dir, (int)getpid());
+    FILE* f = std::fopen(path, "w");
+    if (!f) return;
+    Dl_info info;
+    unsigned long base = 0;
+    if (dladdr(reinterpret_cast<const void*>(&cov_dump), &info)) base = reinterpret_cast<unsigned long>(info.dli_fbase);
+    const size_t n = (size_t)(g_pcs_end - g_pcs_beg) / 2;
+    for (size_t i = 0; i < n && i + 1 < g_hit->size(); ++i)
+        std::fprintf(f, "%lx %d\n", g_pcs_beg[2 * i] - base, (int)(*g_hit)[i + 1]);
+    std::fclose(f);
+}
+}  // namespace emu
+extern "C" void __sanitizer_cov_trace_pc_guard_init(unsigned* start, unsigned* stop) {
+    if (start == stop || *start) return;
+    emu::g_guard_beg = start; emu::g_guard_end = stop;
+    unsigned id = 0;
+    for (unsigned* g = start; g < stop; ++g) *g = ++id;
+    emu::g_hit = new std::vector<unsigned char>(id + 2, 0);
+    std::atexit(emu::cov_dump);
+}
+extern "C" void __sanitizer_cov_trace_pc_guard(unsigned* guard) {
+    if (!*guard) return;
+    if (emu::g_hit && *guard < emu::g_hit->size()) (*emu::g_hit)[*guard] = 1;
+    *guard = 0;  // (once is enough)
+}
+extern "C" void __sanitizer_cov_pcs_init(const unsigned long* beg, const unsigned long* end) { emu::g_pcs_beg = beg; emu::g_pcs_end = end; }
 extern "C" void cilqr_emu_hazards_enable(int on) { emu::g_haz_on = on != 0; if (emu::g_shadow) emu::g_shadow->clear(); }
 extern "C" int cilqr_emu_hazards(const void** a, const void** b, long long* n, int cap) {
     int i = 0;

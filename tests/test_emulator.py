@@ -51,6 +51,9 @@ OUT = {}
 def emu_libs(built):
     sys.path.insert(0, str(EMU))
     import build_emu
+    if os.environ.get("CILQR_EMU_COVERAGE") == "1":   # scripts/emu_coverage.py: the same tests on the block-coverage build
+        lib = build_emu.build(dev=True, coverage=True)
+        return {"prod": lib, "dev": lib}
     return {"prod": build_emu.build(), "dev": build_emu.build(dev=True)}
 
 
