@@ -34,6 +34,8 @@ GROUPS = 8
 LOCKSTEP_POINTS = [
     ("cilqr_group.hpp", "        double m1[4], m2[4];\n", 1,
      "backward_sweep_pair: every lane stores its element of the streamed trajectory's ring chunk, then reads other lanes' elements"),
+    ("cilqr_device.hpp", "        double m1[4], m2[4];\n", 1,
+     "backward_sweep_lanes with the expansion in global rows (k_solve's two-row builds): the same ring refill, lone sweep"),
     ("cilqr_kernels.hpp", "            // what the trajectory carries to its next segment\n", 1,
      "k_solve_grp: lane 0 stores the trajectory's scalars into GrpSt, which every lane has read as wave-uniform values in the same stretch"),
 ]

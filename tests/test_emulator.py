@@ -147,6 +147,28 @@ OUT["stats"] = emu_stats()
     healthy(r["stats"])
 
 
+def test_lone_long_horizon_builds_share_work_and_resume(emu_libs):
+    """k_solve's two-row build with the expansion in global rows (what runs at horizons 64 ... 127 when pairs are switched off):
+    four persistent blocks for 14 trajectories of the configs[3] mix — finished blocks cost open line-search trials of running
+    ones (work sharing between blocks), solves run in slices and are parked / resumed by whoever is free (resumable solves).
+    Whatever the slice length, == oracle; the counters say the machinery was used."""
+    r = run(emu_libs, r"""
+wl = pkg.workloads.config4(B=14, N=100)
+ref = ORC.solve_batch(wl.params, scenes_of(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=4)
+eng = pkg.BatchedCILQR(wl.params, wl.scenes); eng.set_group_mode(0); eng.set_helper_mode(0)
+for res in (-1, 3, 0):
+    eng.set_resume_iters(res)
+    out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
+    OUT["slice %d" % res] = dict(same=same(out, ref), launch=eng.last_launch_info(), parked=eng.resume_stats(), share=eng.work_sharing_stats())
+eng.close()
+OUT["stats"] = emu_stats()
+""", timeout=900, env={"CILQR_EMU_BLOCKS_PER_CU": "4"})
+    healthy(r.pop("stats"))
+    for k, v in r.items():
+        assert v["same"] and v["launch"]["trajectories_per_wavefront"] == 1 and v["launch"]["blocks"] == 4 and v["share"]["error"] == 0, (k, v)
+    assert r["slice 3"]["parked"] > 20 and r["slice 0"]["parked"] == 0 and r["slice 0"]["share"]["helped"] > 0, r
+
+
 def test_augmented_lagrangian_lone_and_in_pairs(emu_libs):
     """solve_type alm (cs:88-93, 253-277, 377-378, 581-643): k_solve's builds (what the default dispatch runs) and — round 6, written
     while the GPU pool was closed, never run on a GPU — the grouped kernel's ALM builds, two trajectories per wavefront, chosen with
@@ -325,10 +347,14 @@ x0 = pkg.workloads.perturbed_starts(sc.ego_state, 6, 0x5A0CE)
 eng.set_group_mode(2); OUT["pairs"] = hazards_of(lambda: eng.solve_batch(x0))
 eng.set_group_mode(0); OUT["helper"] = hazards_of(lambda: eng.solve_batch(x0[:2]))
 eng.close()
+wl = pkg.workloads.config4(B=2, N=70)
+eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True); eng.set_group_mode(0); eng.set_helper_mode(0); eng.set_work_sharing(0)
+OUT["lone two rows"] = hazards_of(lambda: eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick))
+eng.close()
 wl = pkg.workloads.config4(B=4, N=70)
 eng = pkg.BatchedCILQR(wl.params, wl.scenes, dev=True); eng.set_group_mode(2)
 OUT["long"] = hazards_of(lambda: eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick))
 eng.close()
 """, timeout=1500, libs=libs, env={"CILQR_TUNE": "group_steal=0,group_slice=0"})
-    assert r == {"pairs": 0, "helper": 0, "long": 0}, r
+    assert r == {"pairs": 0, "helper": 0, "long": 0, "lone two rows": 0}, r
     assert len(build_emu.LOCKSTEP_POINTS) <= 6   # (a list that grows means the kernels lean on lockstep more and more: look again)
