@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -294,7 +295,9 @@ static bool visit_block_barrier(Block& b) {
     return true;
 }
 
+static std::recursive_mutex g_launch_mutex;  // one launch at a time: host threads (one per shard of ShardedSolver) take turns
 void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
+    std::lock_guard<std::recursive_mutex> lock(g_launch_mutex);
     if (g_cur) { std::fprintf(stderr, "emu: nested launch\n"); std::abort(); }
     if (!g_lds_arena) {
         void* p = mmap(nullptr, LDS_ARENA, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_32BIT | MAP_NORESERVE, -1, 0);
@@ -500,7 +503,8 @@ extern "C" int cilqr_emu_split_sites(const void** a, const void** b, long long* 
 struct emu_stream { int id; };
 struct emu_event { long long t; };
 int emu_blocks_per_cu() { return std::max(1, emu::env_int("CILQR_EMU_BLOCKS_PER_CU", 8)); }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// CILQR_EMU_DEVICES: how many devices the emulated box shows (cilqr_amd::ShardedSolver, one handle and host thread per device)
+hipError_t hipGetDeviceCount(int* n) { *n = std::max(1, emu::env_int("CILQR_EMU_DEVICES", 1)); return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = std::max(1, emu::env_int("CILQR_EMU_CUS", 1));
