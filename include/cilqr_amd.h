@@ -36,9 +36,9 @@ extern "C" {
 /* Largest lqr/N a handle accepts (cilqr_set_params answers CILQR_ERR_BAD_ARG beyond it).  Upstream's N is any int
  * (src/cilqr_solver.cpp:19); here the horizon-parallel phases hold one, two or — round 6: horizons of 128 ... 255, one family
  * of builds: two trajectories per wavefront, both solve types — four rows of the trajectory per lane of a 64-lane wavefront
- * (N + 1 <= 256).  At horizons above 127 the closed loop in one launch and the stage-by-stage entry points answer
- * CILQR_ERR_UNSUPPORTED (cilqr_solve, cilqr_solve_batch, cilqr_solve_batch_device and cilqr_advance_batch_device cover the
- * planning loop tick by tick).  The YAMLs upstream ships use 30; BASELINE's configurations 50 and 100.  A
+ * (N + 1 <= 256).  At horizons above 127 the stage-by-stage entry points and the closed loop in one launch UNDER THE AUGMENTED
+ * LAGRANGIAN answer CILQR_ERR_UNSUPPORTED (cilqr_solve, cilqr_solve_batch, cilqr_solve_batch_device and
+ * cilqr_advance_batch_device cover that planning loop tick by tick; in barrier mode cilqr_closed_loop_batch_device runs).  The YAMLs upstream ships use 30; BASELINE's configurations 50 and 100.  A
  * documented limit of this drop-in, not a silent one: nothing is truncated.  All parameter sets of one handle share N
  * and the solve type (one kernel build per launch); use one handle per (N, solve type). */
 #define CILQR_MAX_HORIZON 255

@@ -303,13 +303,13 @@ def test_register_budget_of_the_shipped_kernels(pkg, tmp_path):
     # 8 of k_solve_grp (horizons 50, 30 and any up to 63, each also as the closed loop in one launch; the long layout for
     # horizon 100 and any from 64 to 127)
     # round 6: + the augmented Lagrangian in pairs (2 kernels, opt-in) and the four-rows-per-lane builds of horizons 128 ... 255
-    # (2 kernels: barrier, ALM) — the only ones at those horizons
-    assert 20 <= len(ks) <= 31, [k["variant"] for k in ks]
+    # (2 kernels: barrier, ALM) — the only ones at those horizons — and the closed loop in one launch on the long layout (2 kernels)
+    assert 20 <= len(ks) <= 33, [k["variant"] for k in ks]
     # (3.99 MB before the pair sweep; its three functions per compile-time horizon — expansion into LDS / into global rows, the
     #  sweep of one or two trajectories — replaced round 4's combined one and added 80 KB; the two long-layout kernels replaced
     #  two of k_solve's two-row builds)
-    # (round 6: the four new kernels and their phases, +0.58 MB)
-    assert (ROOT / "toy-example-of-ilqr_amd" / "libcilqr_amd.so").stat().st_size < 4_700_000
+    # (round 6: the six new kernels and their phases, +0.67 MB)
+    assert (ROOT / "toy-example-of-ilqr_amd" / "libcilqr_amd.so").stat().st_size < 4_900_000
     # the lone-wavefront build of short horizons (what runs when the grouped kernel is switched off, and the reference of
     # the pairing-invariance tests): the one whose spills VERDICT r02 bounded, then the headline
     head = [k for k in ks if k["variant"] == "lone rows/lane=1 waves/SIMD=2"]

@@ -241,20 +241,24 @@ OUT["stats"] = emu_stats()
 
 def test_closed_loop_in_one_launch(emu_libs):
     """cilqr_closed_loop_batch_device (mp:180-197 for every ego in one launch) through the device-pointer entry point — under the
-    emulator "device memory" is host memory, so numpy buffers stand in: 6 egos x 4 ticks, warm starts, == stateful oracle solvers;
-    and the tick-by-tick loop (solve + advance) gives the same."""
+    emulator "device memory" is host memory, so numpy buffers stand in.  Horizon 30: 6 egos x 4 ticks in pairs and on lone
+    wavefronts; round 6 (never run on a GPU): the loop on the grouped kernel's LONG layout — horizon 100 in pairs (opt-in) and
+    horizon 150 (four rows per lane, the only build there).  Ego states and iteration counts of every tick and the last tick's
+    plan == stateful oracle solvers; under the augmented Lagrangian horizons above 127 refuse."""
     r = run(emu_libs, r"""
-sc, p = scenario("three_straight", 30, use_last_solution=1)
-B, T, N = 6, 4, 30
-x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC10)
 ptr = lambda a: a.ctypes.data
-for mode in (2, 0):
+def loop(N, B, T, mode, st=0):
+    sc, p = scenario("three_straight", N, use_last_solution=1, max_iter=40, solve_type=st)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0xC10)
     eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(mode)
     dx0 = x0.copy(); tick = np.zeros(B, dtype=np.int32)
     u = np.zeros((B, N, 2)); x = np.zeros((B, N + 1, 4)); res = np.zeros(B, dtype=pkg.RESULT_DTYPE)
     states = np.zeros((B, T, 4)); its = np.zeros((T, B), dtype=np.int32)
-    eng.closed_loop_batch_device(B, T, ptr(dx0), 0, 0, ptr(tick), 0, ptr(u), ptr(x), ptr(res), ptr(states), ptr(its), 0)
-    eng.wait()
+    try:
+        eng.closed_loop_batch_device(B, T, ptr(dx0), 0, 0, ptr(tick), 0, ptr(u), ptr(x), ptr(res), ptr(states), ptr(its), 0)
+        eng.wait()
+    except pkg.CilqrError as e:
+        eng.close(); return dict(refused=e.code)
     ok = True
     for b in range(B):
         s = ORC.solver(p); s.reset(); xe = x0[b].copy()
@@ -262,13 +266,21 @@ for mode in (2, 0):
             rr = s.solve(xe, scene_of(sc, t))
             xe = rr["x"][1].copy()
             ok = ok and bool((bits(xe) == bits(states[b, t])).all()) and int(rr["res"]["iters"]) == int(its[t, b])
-    OUT["mode %d" % mode] = dict(same=ok, launch=eng.last_launch_info(), ticks=tick.tolist())
+        ok = ok and bool((bits(rr["x"]) == bits(x[b])).all() and (bits(rr["u"]) == bits(u[b])).all())
+    out = dict(same=ok, launch=eng.last_launch_info(), ticks=tick.tolist())
     eng.close()
+    return out
+OUT["N30 pairs"] = loop(30, 6, 4, 2); OUT["N30 lone"] = loop(30, 6, 4, 0)
+OUT["N100 pairs"] = loop(100, 5, 3, 2); OUT["N100 default"] = loop(100, 3, 2, -1)
+OUT["N150"] = loop(150, 3, 2, -1); OUT["N150 alm"] = loop(150, 2, 2, -1, st=1)
 OUT["stats"] = emu_stats()
-""", timeout=900)
-    for k in ("mode 2", "mode 0"):
-        assert r[k]["same"] and r[k]["ticks"] == [4] * 6, r[k]
-    healthy(r["stats"])
+""", timeout=1200)
+    healthy(r.pop("stats"))
+    assert r.pop("N150 alm") == {"refused": -4}
+    for k, v in r.items():
+        assert v["same"] and len(set(v["ticks"])) == 1, (k, v)
+    assert r["N100 pairs"]["launch"]["trajectories_per_wavefront"] == 2 and r["N150"]["launch"]["trajectories_per_wavefront"] == 2
+    assert r["N100 default"]["launch"]["trajectories_per_wavefront"] == 1   # (k_solve's GPU-proven loop builds stay the default)
 
 
 def test_a_lost_hand_over_is_loud_under_emulation(emu_libs):

@@ -1021,6 +1021,70 @@ def test_horizons_above_127(pkg, orc_det, scenarios, N, B):
             eng.close()
 
 
+def test_closed_loop_on_the_long_layout():
+    """Round 6: cilqr_closed_loop_batch_device on the grouped kernel's long layout — horizon 100 in pairs (cilqr_set_group_mode(2);
+    the default keeps k_solve's loop builds) and horizon 150 (four rows per lane: the only build) — 600 egos x 6 ticks, the egos'
+    states and iteration counts of every tick == the tick-by-tick loop of solve + advance on the same handle, and == stateful
+    oracle solvers on a sample."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LONG_LOOP_SCRIPT, root], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "LONG-LOOP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+_LONG_LOOP_SCRIPT = r"""
+import os, sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import cilqr_amd as pkg
+from oracle import Oracle, Scene
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream(dev).cuda_stream
+to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+RES = pkg.RESULT_DTYPE
+cfg = pkg.GlobalConfig.get_instance("three_straight"); sc = pkg.build_scenario(cfg, "three_straight")
+for N, mode in ((100, 2), (150, -1)):
+    B, T = 600, 6
+    p = pkg.params_from_config(cfg, N=N, use_last_solution=1, max_iter=40)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0x100B + N)
+    eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(mode)
+    z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=dev)
+    # one launch
+    dx0, tick = to(x0), z(B, dt=torch.int32)
+    u, x, res = z(B, N, 2), z(B, N + 1, 4), torch.zeros((B, RES.itemsize), dtype=torch.uint8, device=dev)
+    states, its = z(B, T, 4), z(T, B, dt=torch.int32)
+    eng.closed_loop_batch_device(B, T, dx0.data_ptr(), 0, 0, tick.data_ptr(), 0, u.data_ptr(), x.data_ptr(), res.data_ptr(),
+                                 states.data_ptr(), its.data_ptr(), st)
+    eng.wait()
+    assert eng.last_launch_info()["trajectories_per_wavefront"] == 2
+    # tick by tick on the same handle
+    ex0, etick = to(x0), z(B, dt=torch.int32)
+    eu, ex, eres = z(B, N, 2), z(B, N + 1, 4), torch.zeros((B, RES.itemsize), dtype=torch.uint8, device=dev)
+    off = RES.fields["iters"][1]
+    for t in range(T):
+        eng.solve_batch_device(B, ex0.data_ptr(), 0, 0, etick.data_ptr(), eu.data_ptr() if t else 0, eu.data_ptr(), ex.data_ptr(), eres.data_ptr(), 0, 0, st)
+        eng.advance_batch_device(B, ex.data_ptr(), ex0.data_ptr(), etick.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        it_t = np.frombuffer(eres.cpu().numpy().tobytes(), dtype=RES)["iters"]
+        assert np.array_equal(it_t, its[t].cpu().numpy()), (N, t)
+        assert np.array_equal(ex0.cpu().numpy(), states[:, t].cpu().numpy()), (N, t)
+    assert np.array_equal(ex.cpu().numpy(), x.cpu().numpy()) and np.array_equal(eu.cpu().numpy(), u.cpu().numpy())
+    o = Oracle("det"); hs = states.cpu().numpy()
+    for b in range(0, B, 75):
+        s = o.solver(p); s.reset(); xe = x0[b].copy()
+        for t in range(T):
+            rr = s.solve(xe, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t))
+            xe = rr["x"][1].copy()
+            assert np.array_equal(xe, hs[b, t]), (N, b, t)
+    eng.close()
+print("LONG-LOOP-OK")
+"""
+
+
 _CONCURRENT_SCRIPT = r"""
 import sys, numpy as np
 import torch                      # first: the process then has ONE HIP runtime (torch's), as in bench.py

@@ -32,6 +32,8 @@ extern template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 1, true, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 2, true, true> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 4> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, true, 4> CILQR_GRP_SIGNATURE;
+extern template __global__ void k_solve_grp<0, 2, true, 2> CILQR_GRP_SIGNATURE;
 extern template __global__ void k_solve_grp<0, 2, false, 4, true, true> CILQR_GRP_SIGNATURE;
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,8 +1187,9 @@ static int alloc_out(cilqr_handle* h, int slot, size_t bytes, void** out) {
 // the horizon as measured before work sharing existed.
 static bool two_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > CILQR_WAVE; }
 // horizons of 128 ... 255 (round 6): four rows per lane.  ONE family of builds takes them — the grouped kernel's long layout, both
-// solve types — so every launch of such a handle runs in pairs whatever the batch size and the group mode; what has no build
-// at these horizons (closed loop in one launch, piecewise entry points, testing aids, cycle accounting) says CILQR_ERR_UNSUPPORTED
+// solve types, and the closed loop in one launch in barrier mode — so every launch of such a handle runs in pairs whatever the batch
+// size and the group mode; what has no build at these horizons (closed loop under the augmented Lagrangian, piecewise entry points,
+// testing aids, cycle accounting) says CILQR_ERR_UNSUPPORTED
 static bool four_rows(const cilqr_handle* h) { return !h->params.empty() && h->params[0].N + 1 > 2 * CILQR_WAVE; }
 static bool wants_helper(const cilqr_handle* h, int B) {
     if (four_rows(h)) return false;
@@ -1232,11 +1235,13 @@ static bool global_expansion(const cilqr_handle* h, int B) {
 // does this batch run the grouped build (k_solve_grp: CILQR_GROUP trajectories per wavefront, one rollout pass for all)?
 // Barrier mode, one row per lane, persistent lone wavefronts two per SIMD, no closed loop, no testing aids.
 static bool grouped(const cilqr_handle* h, int B) {
-    if (four_rows(h)) return !h->looping && h->debug_flags == 0 && !h->profiling && h->persistent_blocks;
+    if (four_rows(h)) return !(h->looping && h->params[0].solve_type == 1) && h->debug_flags == 0 && !h->profiling && h->persistent_blocks;
     if (h->group_mode == 0 || h->group_mode == 1) return false;
     if (h->debug_flags != 0) return false;
     if (h->params[0].solve_type == 1 && ((!h->group_alm && h->group_mode < 2) || h->looping || h->profiling)) return false; // (ALM in pairs: the long layout)
-    if (two_rows(h) && (!h->group_long || h->looping)) return false; // (the long layout has no closed-loop build)
+    // (the closed loop in one launch on the long layout — round 6, not yet run on a GPU — only when pairs are asked for explicitly;
+    //  by default horizons of 64 ... 127 loop on k_solve's builds)
+    if (two_rows(h) && (!h->group_long || (h->looping && h->group_mode < 2))) return false;
     if (h->looping && (!h->group_loop || h->profiling)) return false; // (closed loop in one launch: the LOOP builds of k_solve_grp)
     if (h->profiling && !(CILQR_GPROF && h->group_mode >= 2)) return false; // (cycle accounting: development library, when forced)
     if (!h->persistent_blocks) return false;
@@ -1461,8 +1466,8 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
     if (loop.ticks >= 1 && (h->debug_flags != 0 || h->profiling))
         return fail(CILQR_ERR_UNSUPPORTED, "the closed loop has no testing-aid / cycle-accounting builds");
     if (four_rows(h) && !grouped(h, B))
-        return fail(CILQR_ERR_UNSUPPORTED, "horizons above 127 run the grouped kernel's long layout only: no closed loop in one launch, no "
-                                           "testing aids / cycle accounting, persistent blocks on");
+        return fail(CILQR_ERR_UNSUPPORTED, "horizons above 127 run the grouped kernel's long layout only: no closed loop in one launch under "
+                                           "the augmented Lagrangian, no testing aids / cycle accounting, persistent blocks on");
     // Which launch slot: slot 0 on the caller's stream, one launch of the handle at a time — or, after
     // cilqr_set_batches_in_flight(k > 1), the next of k slots round robin, each with a stream, scratch areas and control words
     // of its own.  Not for the augmented Lagrangian (its multipliers live in the handle, indexed by trajectory: two launches
@@ -1545,6 +1550,7 @@ static int solve_batch_device_impl(cilqr_handle* h, int32_t B, const double* d_x
         if (longl) kg = (a.N == 100) ? k_solve_grp<100, 2, false, 2> : k_solve_grp<0, 2, false, 2>;
         if (a.alm) kg = (a.N + 1 > CILQR_WAVE) ? k_solve_grp<0, 2, false, 2, true, true> : k_solve_grp<0, 2, false, 1, true, true>;
         if (a.N + 1 > 2 * CILQR_WAVE) kg = a.alm ? k_solve_grp<0, 2, false, 4, true, true> : k_solve_grp<0, 2, false, 4>;
+        if (longl && !a.alm && loop.ticks >= 1) kg = (a.N + 1 > 2 * CILQR_WAVE) ? k_solve_grp<0, 2, true, 4> : k_solve_grp<0, 2, true, 2>;
         const size_t shm = longl ? grpl_lds_bytes(a.N, a.W, G) : grp_lds_bytes(a.N, a.W, G);
         int per_cu = 0;
         rc = blocks_per_cu(h, reinterpret_cast<const void*>(kg), shm, &per_cu);

@@ -848,7 +848,7 @@ k_solve_grp(BatchArgs a, const double* __restrict__ x0, const double* last_u, do
     // l_xx never fits LDS twice, streamed rows take it as they are; the multipliers stay in HBM, rho in GrpSt::J_pair; no
     // hand-overs between wavefronts (the multipliers are written with plain stores): the host passes a.park = nullptr
     constexpr bool LONG = LAY;
-    static_assert(!(LONG && LOOP), "the closed loop in one launch has no long-layout grouped build");
+    static_assert(!(ALM && LOOP), "the closed loop in one launch has no augmented-Lagrangian grouped build");
     static_assert(!ALM || LONG, "augmented Lagrangian in pairs: the long layout");
     const int lane = threadIdx.x & (CILQR_WAVE - 1);
     const int N = NC ? NC : a.N;

@@ -69,6 +69,9 @@ template __global__ void k_solve_grp<0, 2, false, 2> CILQR_GRP_SIGNATURE;
 #if CILQR_INST_GROUP == 1
 // round 6: horizons of 128 ... 255 — the long layout with FOUR rows per lane (cs:19: N is any int upstream); barrier and ALM
 template __global__ void k_solve_grp<0, 2, false, 4> CILQR_GRP_SIGNATURE;
+// ... and the closed planning loop in one launch on the long layout (two / four rows per lane), barrier mode
+template __global__ void k_solve_grp<0, 2, true, 4> CILQR_GRP_SIGNATURE;
+template __global__ void k_solve_grp<0, 2, true, 2> CILQR_GRP_SIGNATURE;
 #endif
 #if CILQR_INST_GROUP == 0
 template __global__ void k_solve_grp<0, 2, false, 4, true, true> CILQR_GRP_SIGNATURE;
