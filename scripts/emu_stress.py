@@ -27,11 +27,38 @@ p = pkg.params_from_config(cfg, N=c["N"], solve_type=c.get("solve_type", 0), max
 eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(2)
 x0 = pkg.workloads.perturbed_starts(sc.ego_state, c["B"], c["x0_seed"])
 ok_wait = True
+scene = lambda t=0: Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t)
+if c.get("kind") == "loop":
+    # the closed planning loop in one launch (egos change wavefronts between ticks and inside solves), against stateful oracles
+    p = pkg.params_from_config(cfg, N=c["N"], use_last_solution=1, max_iter=c.get("max_iter", 100))
+    eng.close(); eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(2)
+    B, N, T = c["B"], c["N"], c["ticks"]
+    ptr = lambda a: a.ctypes.data
+    dx0 = x0.copy(); tick = np.zeros(B, dtype=np.int32)
+    u = np.zeros((B, N, 2)); x = np.zeros((B, N + 1, 4)); res = np.zeros(B, dtype=pkg.RESULT_DTYPE)
+    states = np.zeros((B, T, 4)); its = np.zeros((T, B), dtype=np.int32)
+    r = dict(c)
+    try:
+        eng.closed_loop_batch_device(B, T, ptr(dx0), 0, 0, ptr(tick), 0, ptr(u), ptr(x), ptr(res), ptr(states), ptr(its), 0)
+        eng.wait()
+        bad = []
+        o = Oracle("det")
+        for b in range(B):
+            s = o.solver(p); s.reset(); xe = x0[b].copy()
+            for t in range(T):
+                rr = s.solve(xe, scene(t)); xe = rr["x"][1].copy()
+                if not (np.array_equal(xe, states[b, t]) and int(rr["res"]["iters"]) == int(its[t, b])): bad.append(b); break
+        r.update(ok=not bad and (tick == T).all(), mismatching=bad[:8], not_solved=int((res["end_reason"] == 4).sum()), parked=eng.resume_stats(),
+                 launch_error=eng.work_sharing_stats()["error"], blocks=eng.last_launch_info()["blocks"], iters_max=int(its.max()))
+        r["ok"] = bool(r["ok"]) and r["not_solved"] == 0 and r["launch_error"] == 0
+    except RuntimeError as e:
+        r.update(ok=False, error=str(e)[:200])
+    print("CASE " + json.dumps(r)); sys.exit(0)
 try:
     out = eng.solve_batch(x0)
 except RuntimeError as e:
     ok_wait = False; out = None; err = str(e)
-ref = Oracle("det").solve_batch(p, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity), x0, n_threads=2)
+ref = Oracle("det").solve_batch(p, scene(), x0, n_threads=2)
 r = dict(c)
 if out is None:
     r.update(ok=False, error=err[:200])
@@ -50,13 +77,16 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lib", default=os.path.join(ROOT, "tests", "emu", "_build", "libcilqr_emu_dev.so"))
     ap.add_argument("--long", action="store_true", help="horizons above 63 too (the long layout: slower)")
+    ap.add_argument("--kinds", default="solve", help="comma list of solve (barrier), alm (augmented Lagrangian in pairs), loop (closed loop in one launch)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     bad = 0
     tot_parked = 0
     for i in range(a.cases):
-        N = rng.choice([20, 30, 37, 50] + ([70, 100] if a.long else []))
-        c = {"scenario": rng.choice(["three_bend", "two_straight", "two_borrow"]), "N": N,
+        N = rng.choice([20, 30, 37, 50] + ([70, 100, 130] if a.long else []))
+        kind = rng.choice(a.kinds.split(","))
+        c = {"kind": kind, "solve_type": 1 if kind == "alm" else 0, "ticks": rng.choice([2, 3]),
+             "scenario": rng.choice(["three_bend", "two_straight", "two_borrow"]) if kind != "loop" else "three_straight", "N": N,
              "B": rng.choice([3, 5, 9, 16, 17, 24, 33, 48] if N <= 63 else [3, 5, 9, 12]), "x0_seed": rng.randrange(1 << 30),
              "max_iter": rng.choice([100, 100, 40]), "sched_seed": rng.randrange(1, 1 << 30),
              "blocks_per_cu": rng.choice([1, 2, 3, 4, 8]), "cus": rng.choice([1, 1, 2]),
