@@ -3,7 +3,8 @@
 swapped (CILQR_AMD_LIB / CILQR_AMD_LIB_DEV).  Not a substitute for the GPU run (tests/emu/README.md says what the emulator cannot
 see); it tells, without a GPU, whether the sources still compute the oracle's numbers along every path the GPU tests take.
 
-Left out, by name: tests that need torch.cuda tensors or a second HIP runtime in the process, the binaries linked against the
+The torch-based tests see a numpy-backed stand-in for `torch` (tests/emu/fake_torch: device memory is host memory here).
+Left out, by name: torch-based tests with fixed sizes in the thousands of solves, the binaries linked against the
 gfx950 library, the BASELINE configurations at full size (tens of thousands of solves: hours here), block timelines (a clock), and
 two testing aids the emulator does not model (float -> int conversion of 1e300 in detmath's argument reduction: undefined on x86;
 the wave-uniform backward sweep of the development build, which zero-fills and stores in one lockstep stretch).
@@ -19,8 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SKIP = ["detmath_device", "uniform_and_lane_parallel", "full_size", "config2_full", "config4_every", "at_scale", "libm_gap", "concurrent_handles",
-        "resident_on_the_device", "device_pointer_entry", "one_handle_on_two", "in_one_launch", "in_flight", "lost_rows", "lost_hand_over",
-        "closed_loop_on_the_long_layout", "cpp_headless_planner", "sharded_solver_in_one_process", "block_timeline", "pairs_at_scale",
+        "resident_on_the_device", "device_pointer_entry", "one_handle_on_two", "in_one_launch", "in_flight", "lost_rows",
+        "cpp_headless_planner", "sharded_solver_in_one_process", "block_timeline", "pairs_at_scale",
         "scratch_held", "fuzz_random", "long_horizon_builds", "resumable_solves", "work_sharing_between", "sliced_solves",
         "two_trajectories_per_wavefront_at_long"]
 
@@ -36,6 +37,7 @@ def main():
     import build_emu
     libs = (build_emu.build(), build_emu.build(dev=True))
     env = dict(os.environ, CILQR_AMD_LIB=str(libs[0]), CILQR_AMD_LIB_DEV=str(libs[1]), CILQR_TEST_SHRINK=str(a.shrink))
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests", "emu", "fake_torch") + os.pathsep + env.get("PYTHONPATH", "")
     env.pop("CILQR_TUNE", None)
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-p", "no:cacheprovider",

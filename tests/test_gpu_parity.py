@@ -1047,8 +1047,9 @@ st = torch.cuda.current_stream(dev).cuda_stream
 to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 RES = pkg.RESULT_DTYPE
 cfg = pkg.GlobalConfig.get_instance("three_straight"); sc = pkg.build_scenario(cfg, "three_straight")
+SHRINK = int(os.environ.get("CILQR_TEST_SHRINK", "1"))   # (rehearsals on the emulator: tests/emu/)
 for N, mode in ((100, 2), (150, -1)):
-    B, T = 600, 6
+    B, T = max(8, 600 // SHRINK), (6 if SHRINK == 1 else 3)
     p = pkg.params_from_config(cfg, N=N, use_last_solution=1, max_iter=40)
     x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0x100B + N)
     eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc)); eng.set_group_mode(mode)
@@ -1074,7 +1075,7 @@ for N, mode in ((100, 2), (150, -1)):
         assert np.array_equal(ex0.cpu().numpy(), states[:, t].cpu().numpy()), (N, t)
     assert np.array_equal(ex.cpu().numpy(), x.cpu().numpy()) and np.array_equal(eu.cpu().numpy(), u.cpu().numpy())
     o = Oracle("det"); hs = states.cpu().numpy()
-    for b in range(0, B, 75):
+    for b in range(0, B, max(1, B // 8)):
         s = o.solver(p); s.reset(); xe = x0[b].copy()
         for t in range(T):
             rr = s.solve(xe, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, sc.obstacles, sc.road_borders, sc.target_velocity, t))
@@ -2027,7 +2028,7 @@ def bufs(B, N):  # (results start as garbage that LOOKS like a result: the mark 
     r = np.zeros(B, dtype=RES); r["iters"] = 7; r["end_reason"] = 0; r["J_final"] = 1.0
     return (torch.zeros((B, N, 2), dtype=torch.float64, device=dev), torch.zeros((B, N + 1, 4), dtype=torch.float64, device=dev),
             torch.from_numpy(np.frombuffer(r.tobytes(), dtype=np.uint8).reshape(B, RES.itemsize).copy()).to(dev))
-wl = pkg.workloads.config3(B=3000, N=30)
+wl = pkg.workloads.config3(B=max(40, 3000 // int(os.environ.get("CILQR_TEST_SHRINK", "1"))), N=30)   # (shrunk in emulator rehearsals)
 B, N = wl.B, wl.N
 scenes = [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes]
 ref = Oracle("det").solve_batch(wl.params, scenes, wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=8)
