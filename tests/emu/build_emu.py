@@ -83,15 +83,17 @@ def generate(csrc, gen):
     return total
 
 
-def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1", hazards=False, coverage=False):
+def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1", hazards=False, coverage=False, sanitize=False, planted_bug=False):
     csrc = pathlib.Path(csrc)
-    tag = ("dev" if dev else "prod") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ("" if csrc == CSRC else "_" + re.sub(r"\W", "_", str(csrc))[-40:])
+    tag = ("dev" if dev else "prod") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ("_san" if sanitize else "") + ("" if csrc == CSRC else "_" + re.sub(r"\W", "_", str(csrc))[-40:])
     gen = HERE / "_gen" / tag
     objdir = HERE / "_build" / tag
     objdir.mkdir(parents=True, exist_ok=True)
-    lib = pathlib.Path(out) if out else HERE / "_build" / ("libcilqr_emu" + ("_dev" if dev else "") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ".so")
+    lib = pathlib.Path(out) if out else HERE / "_build" / ("libcilqr_emu" + ("_dev" if dev else "") + ("_hazards" if hazards else "") + ("_cov" if coverage else "") + ("_san" if sanitize else "") + ".so")
+    if planted_bug:
+        lib = lib.with_name(lib.stem + "_planted.so")
     generate(csrc, gen)
-    deps = list(gen.iterdir()) + [HERE / "emu_runtime.cpp", HERE / "include" / "hip" / "hip_runtime.h", ROOT / "include" / "cilqr_amd.h",
+    deps = [d for d in gen.iterdir() if d.is_file()] + [HERE / "emu_runtime.cpp", HERE / "include" / "hip" / "hip_runtime.h", ROOT / "include" / "cilqr_amd.h",
                                   pathlib.Path(__file__)]
     if not force and lib.exists() and all(d.stat().st_mtime <= lib.stat().st_mtime for d in deps):
         return lib
@@ -108,7 +110,15 @@ def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1",
     if coverage:  # basic-block coverage of the kernel sources (emu_runtime.cpp, scripts/emu_coverage.py)
         cov = ["-fsanitize-coverage=trace-pc-guard,pc-table", "-g"]
 
+    # AddressSanitizer + UndefinedBehaviorSanitizer on the KERNEL sources (there are no sanitizers for gfx950 code): out-of-bounds
+    # accesses of "device" buffers (hipMalloc = the instrumented malloc) and of the block's LDS (the emulator poisons what lies
+    # beyond the launch's dynamic LDS size), signed overflow, bad shifts, misaligned or null accesses.  The library then needs
+    # LD_PRELOAD of the ASan runtime (tests/test_emulator.py does that)
+    san = ["-fsanitize=address,undefined", "-fno-sanitize=float-cast-overflow,function", "-fno-omit-frame-pointer", "-fsanitize-recover=all",
+           "-shared-libsan", "-mllvm", "-asan-globals=false", "-DCILQR_EMU_SANITIZE=1"] if sanitize else []
+
     def cc(src, obj, extra):
+        extra = extra + san
         if src.name != "emu_runtime.cpp":
             extra = extra + cov
         if not force and obj.exists() and all(d.stat().st_mtime <= obj.stat().st_mtime for d in deps):
@@ -118,12 +128,24 @@ def build(dev=False, csrc=CSRC, out=None, force=False, verbose=False, opt="-O1",
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    if planted_bug:
+        # the sanitizer build's self-check: ONE compilation unit rebuilt from a copy with an out-of-bounds store planted in
+        # k_mark_unsolved (one record past the end of the caller's result array), linked with the other units as they are
+        bug = gen / "planted" / "cilqr_amd.hip"
+        bug.parent.mkdir(exist_ok=True)
+        t = (gen / "cilqr_amd.hip").read_text()
+        assert t.count("    if (b >= B) return;\n    cilqr_result r;") == 1
+        t = t.replace("    if (b >= B) return;\n    cilqr_result r;", "    if (b > B) return;   /* PLANTED BUG */\n    cilqr_result r;")
+        if not bug.exists() or bug.read_text() != t:
+            bug.write_text(t)
+        units[0] = (bug, objdir / "cilqr_amd_planted.o", ["-I", str(gen)])
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as ex:
         for f in [ex.submit(cc, *u) for u in units]:
             f.result()
     # (noinline device functions defined in the headers exist once per compilation unit — one code object each on the GPU; here the
     #  identical copies meet in one link)
-    subprocess.run([CLANG, "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in units] + ["-lm", "-lstdc++", "-ldl", "-Wl,--allow-multiple-definition"], check=True)
+    subprocess.run([CLANG, "-shared", "-fPIC", "-o", str(lib)] + [str(o) for _, o, _ in units] + ["-lm", "-lstdc++", "-ldl", "-Wl,--allow-multiple-definition"]
+                   + (["-fsanitize=address,undefined", "-shared-libsan"] if sanitize else []), check=True)
     return lib
 
 
@@ -137,5 +159,6 @@ if __name__ == "__main__":
     ap.add_argument("--opt", default="-O1")
     ap.add_argument("--hazards", action="store_true", help="instrumented build for the lockstep-hazard detector")
     ap.add_argument("--coverage", action="store_true", help="instrumented build for basic-block coverage of the kernel sources")
+    ap.add_argument("--sanitize", action="store_true", help="AddressSanitizer + UBSan build of the kernel sources")
     a = ap.parse_args()
-    print(build(a.dev, pathlib.Path(a.csrc), a.out, a.force, a.v, a.opt, a.hazards, a.coverage))
+    print(build(a.dev, pathlib.Path(a.csrc), a.out, a.force, a.v, a.opt, a.hazards, a.coverage, a.sanitize))

@@ -24,6 +24,14 @@
 #include <mutex>
 #include <vector>
 
+#ifdef CILQR_EMU_SANITIZE
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#else
+#define ASAN_POISON_MEMORY_REGION(p, n) ((void)0)
+#define ASAN_UNPOISON_MEMORY_REGION(p, n) ((void)0)
+#endif
+
 namespace emu {
 
 extern "C" void emu_swap(void** save_sp, void* load_sp);
@@ -49,6 +57,7 @@ struct Fiber {
     const void* site = nullptr;
     const void* ret = nullptr;
     size_t depth = 0;  // stack pointer at the operation (lower = deeper)
+    void* asan_fake = nullptr; // (sanitizer build: the fibre's fake-stack handle across switches)
     long long nops = 0; // cross-lane operations executed so far: the lane's SEGMENT number (lockstep-hazard detector)
 };
 struct Block {
@@ -94,6 +103,21 @@ static int env_int(const char* name, int dflt) {
     return e ? std::atoi(e) : dflt;
 }
 
+#ifdef CILQR_EMU_SANITIZE
+static const void* g_sched_stack_bottom = nullptr;
+static size_t g_sched_stack_size = 0;
+#endif
+// fibre -> scheduler (AddressSanitizer is told about every stack switch)
+static inline void to_scheduler(Fiber* f, bool last) {
+#ifdef CILQR_EMU_SANITIZE
+    __sanitizer_start_switch_fiber(last ? nullptr : &f->asan_fake, g_sched_stack_bottom, g_sched_stack_size);
+#endif
+    emu_swap(&f->sp, g_sched_sp);
+#ifdef CILQR_EMU_SANITIZE
+    __sanitizer_finish_switch_fiber(f->asan_fake, &g_sched_stack_bottom, &g_sched_stack_size);
+#endif
+}
+
 __attribute__((noinline)) long long xlane(int kind, long long v, int p1, int p2, int p3, int p4, const void* tag) {
     Fiber* f = g_cur;
     if (!f) {
@@ -107,15 +131,18 @@ __attribute__((noinline)) long long xlane(int kind, long long v, int p1, int p2,
     f->st = XWAIT;
     ++f->nops;
     ++g_clock;
-    emu_swap(&f->sp, g_sched_sp);
+    to_scheduler(f, false);
     return f->result;
 }
 
 static void fiber_main() {
     Fiber* f = g_cur;
+#ifdef CILQR_EMU_SANITIZE
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack_bottom, &g_sched_stack_size);
+#endif
     (*g_body)();
     f->st = DONE;
-    emu_swap(&f->sp, g_sched_sp);
+    to_scheduler(f, true);
     std::abort();  // (a finished fibre is never resumed)
 }
 
@@ -145,7 +172,14 @@ static void start_fiber(Fiber* f) {
 
 static void run_fiber(Fiber* f) {
     g_cur = f;
+#ifdef CILQR_EMU_SANITIZE
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, f->stack, STACK_BYTES);
+#endif
     emu_swap(&g_sched_sp, f->sp);
+#ifdef CILQR_EMU_SANITIZE
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
     g_cur = nullptr;
 }
 
@@ -329,7 +363,9 @@ void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
             free_slots.pop_back();
             slot_of[b] = slot;
             b->lds = g_lds_arena + (size_t)slot * LDS_PER_BLOCK;
+            ASAN_UNPOISON_MEMORY_REGION(b->lds, LDS_PER_BLOCK);
             if (env_int("CILQR_EMU_POISON_LDS", 1)) std::memset(b->lds, 0xff, shm);  // (uninitialised LDS reads as NaNs)
+            ASAN_POISON_MEMORY_REGION(b->lds + shm, LDS_PER_BLOCK - shm);  // (sanitizer build: an access beyond the launch's dynamic LDS is reported)
             const unsigned bi = (unsigned)next_block++;
             b->bidx = Idx{bi % grid.x, (bi / grid.x) % grid.y, bi / (grid.x * grid.y)};
             b->n_waves = (threads + 63) / 64;

@@ -379,6 +379,81 @@ def test_cpp_drop_in_and_sharded_solver_on_the_emulator(emu_libs, pkg, orc_det, 
     assert int(field(lines["1"], "iters")) > 21 and field(lines["1"], "not_solved") == "0"
 
 
+def test_kernels_under_address_and_ub_sanitizers(emu_libs):
+    """There are no sanitizers for gfx950 code; on the emulator the kernel sources are host code.  The --sanitize build
+    (AddressSanitizer + UBSan, fibre switches announced to ASan, everything beyond a launch's dynamic LDS poisoned, "device"
+    buffers = instrumented heap blocks of exactly the caller's size) runs one launch of every kernel family through the
+    device-pointer entry points: no out-of-bounds access of outputs, tables, scratch or LDS, no undefined behaviour — and the
+    results are still the oracle's.  That the tool is live is shown first: a hipMemset 16 bytes past a 64-byte device buffer is
+    reported.  (An out-of-bounds store injected into a kernel is reported with the kernel's file:line — tests/emu/README.md.)"""
+    sys.path.insert(0, str(EMU))
+    import build_emu
+    import glob
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("no shared AddressSanitizer runtime next to the ROCm clang")
+    lib = build_emu.build(dev=True, sanitize=True)
+    env = {"LD_PRELOAD": rt[-1], "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:exitcode=0",
+           "UBSAN_OPTIONS": "print_stacktrace=1"}
+    e = dict(os.environ, **env)
+    probe = subprocess.run([sys.executable, "-c", "import ctypes,sys; l=ctypes.CDLL(sys.argv[1]); p=ctypes.c_void_p(); "
+                            "l._Z9hipMallocPPvm(ctypes.byref(p), ctypes.c_size_t(64)); l._Z9hipMemsetPvim(p, 0, ctypes.c_size_t(80))", str(lib)],
+                           capture_output=True, text=True, env=e)
+    assert "heap-buffer-overflow" in probe.stderr and "64-byte region" in probe.stderr, probe.stderr[-800:]
+    body = r"""
+ptr = lambda a: a.ctypes.data
+def dev_solve(p, tab, x0, mode, ids=None, helper=None):
+    B, N = len(x0), (p[0] if isinstance(p, (list, tuple)) else p).N
+    eng = pkg.BatchedCILQR(p, tab, dev=True); eng.set_group_mode(mode)
+    if helper is not None: eng.set_helper_mode(helper)
+    z = np.zeros(B, dtype=np.int32) if ids is None else None
+    sid, pid, tk = (z, z, z) if ids is None else ids
+    u = np.zeros((B, N, 2)); x = np.zeros((B, N + 1, 4)); res = np.zeros(B, dtype=pkg.RESULT_DTYPE)
+    eng.solve_batch_device(B, ptr(x0), ptr(sid), ptr(pid), ptr(tk), 0, ptr(u), ptr(x), ptr(res), 0, 0, 0); eng.wait()
+    info = eng.last_launch_info(); eng.close()
+    return dict(u=u, x=x, res=res), info
+for name, N, B, st, mode in (("three_bend", 30, 10, 0, 2), ("three_bend", 30, 3, 0, 0), ("two_straight", 50, 6, 0, 2), ("three_bend", 30, 6, 1, 2),
+                             ("three_bend", 30, 3, 1, -1), ("two_borrow", 130, 3, 0, -1)):
+    cfg = pkg.GlobalConfig.get_instance(name); sc = pkg.build_scenario(cfg, name)
+    obs = np.concatenate([sc.obstacles, np.repeat(sc.obstacles[:, -1:, :], 20, axis=1)], axis=1)
+    p = pkg.params_from_config(cfg, N=N, solve_type=st, max_iter=25)
+    x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 0x5A9)
+    out, info = dev_solve(p, pkg.SceneTable(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity), x0, mode)
+    ref = ORC.solve_batch(p, Scene(sc.lane.x, sc.lane.y, sc.lane.yaw, obs, sc.road_borders, sc.target_velocity), x0, n_threads=2)
+    OUT["%s N=%d type %d mode %d" % (name, N, st, mode)] = dict(same=same(out, ref), launch=info)
+wl = pkg.workloads.config4(B=6, N=100)
+ref = ORC.solve_batch(wl.params, scenes_of(wl), wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=2)
+for mode, helper in ((2, None), (0, 0)):
+    out, info = dev_solve(wl.params, wl.scenes, wl.x0, mode, ids=(wl.scenario_id, wl.param_id, wl.tick), helper=helper)
+    OUT["config4 N=100 mode %d" % mode] = dict(same=same(out, ref), launch=info)
+"""
+    e2 = dict(os.environ)
+    e2.pop("CILQR_TUNE", None)
+    e2.update(env, CILQR_AMD_LIB=str(lib), CILQR_AMD_LIB_DEV=str(lib), CILQR_EMU_BLOCKS_PER_CU="2")
+    r = subprocess.run([sys.executable, "-c", PRELUDE + body + "\nprint('EMU-RESULT ' + json.dumps(OUT))\n", str(ROOT)], capture_output=True,
+                       text=True, timeout=1500, env=e2)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("EMU-RESULT ")][-1][len("EMU-RESULT "):])
+    assert len(res) == 8
+    for k, v in res.items():
+        assert v["same"], (k, v)
+    # ... and a PLANTED bug is found: one compilation unit rebuilt with k_mark_unsolved storing one record past the end of the
+    # caller's result array — reported as a heap-buffer-overflow inside k_mark_unsolved, with the source line
+    bug = build_emu.build(dev=True, sanitize=True, planted_bug=True)
+    small = r"""
+sc, p = scenario("three_bend", 30)
+B = 6; x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 3)
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(2)
+z = np.zeros(B, dtype=np.int32); u = np.zeros((B, 30, 2)); x = np.zeros((B, 31, 4)); res = np.zeros(B, dtype=pkg.RESULT_DTYPE)
+ptr = lambda a: a.ctypes.data
+eng.solve_batch_device(B, ptr(x0), ptr(z), ptr(z), ptr(z), 0, ptr(u), ptr(x), ptr(res), 0, 0, 0); eng.wait()
+"""
+    e3 = dict(e2, CILQR_AMD_LIB=str(bug), CILQR_AMD_LIB_DEV=str(bug))
+    r = subprocess.run([sys.executable, "-c", PRELUDE + small, str(ROOT)], capture_output=True, text=True, timeout=600, env=e3)
+    assert "heap-buffer-overflow" in r.stderr and "k_mark_unsolved" in r.stderr and "cilqr_amd.hip:" in r.stderr, r.stderr[-3000:]
+
+
 def test_lockstep_points_cover_every_hazard(emu_libs):
     """The emulator runs the lanes of a wavefront one after the other between two cross-lane operations.  Where lanes exchange data
     through memory inside such a stretch (legal on the device: a wavefront's LDS operations execute in order) the scratch copy of
