@@ -147,6 +147,22 @@ OUT["stats"] = emu_stats()
     healthy(r["stats"])
 
 
+def test_serial_reference_chain_forced(emu_libs):
+    """The serial first-local-minimum chain (cs:289-314 as written) is the fallback of the lane-parallel reference search and
+    rarely runs; the development build forces it (a testing aid).  scripts/emu_mutants.py showed that no other emulator test
+    reaches it: a planted off-by-one in the chain survived until this case was added."""
+    r = run(emu_libs, r"""
+sc, p = scenario("three_bend", 30)
+x0 = pkg.workloads.perturbed_starts(sc.ego_state, 4, 0x5E21A1)
+ref = ORC.solve_batch(p, scene_of(sc), x0, n_threads=2)
+eng = pkg.BatchedCILQR(p, pkg.SceneTable.from_scenario(sc), dev=True); eng.set_group_mode(0)
+eng.set_debug_flags(pkg._lib.DBG_SERIAL_REF_SCAN)
+OUT["same"] = same(eng.solve_batch(x0), ref); OUT["launch"] = eng.last_launch_info()
+eng.close()
+""")
+    assert r["same"], r
+
+
 def test_lone_long_horizon_builds_share_work_and_resume(emu_libs):
     """k_solve's two-row build with the expansion in global rows (what runs at horizons 64 ... 127 when pairs are switched off):
     four persistent blocks for 14 trajectories of the configs[3] mix — finished blocks cost open line-search trials of running
