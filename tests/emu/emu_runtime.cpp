@@ -340,6 +340,8 @@ void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
     }
     if (shm > LDS_PER_BLOCK) { std::fprintf(stderr, "emu: %zu bytes of LDS asked for, a CU has %zu\n", shm, LDS_PER_BLOCK); std::abort(); }
     ++g_stats.launches;
+    if (env_int("CILQR_EMU_DEBUG", 0))
+        std::fprintf(stderr, "emu: launch %lld grid %u block %u dynamic LDS %zu bytes\n", g_stats.launches, grid.x, block.x, shm);
     {
         const int seed = env_int("CILQR_EMU_SCHED_SEED", 0);
         g_sched_seed = seed ? (0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)g_stats.launches) | 1ULL : 0ULL;
