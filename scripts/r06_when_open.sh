@@ -29,3 +29,5 @@ try:
 except Exception as ex:
     print('no bench line', ex)
 PY
+# 4. stress of the grouped kernel incl. round 6's shapes (ALM lone vs pairs, horizons 128 ... 200), five minutes
+timeout 420 python scripts/stress_grouped.py 300 "$OUT/stress_grouped.json" 2>&1 | tail -2

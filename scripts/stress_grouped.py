@@ -47,9 +47,13 @@ def main():
     launches = handed_over = waiting = 0
     shapes = []
     while time.time() < t_end:
-        N = int(rng.choice([5, 12, 30, 41, 50, 50, 50, 63, 64, 77, 100, 100, 127]))
+        N = int(rng.choice([5, 12, 30, 41, 50, 50, 50, 63, 64, 77, 100, 100, 127, 128, 160, 200]))  # round 6: + four rows per lane
         B = int(rng.choice([1, 2, 3, 7, 64, 333, 1024, 2049, 4100, 6200, 9000, 17000]))
+        if os.environ.get("STRESS_MAX_B"):  # (rehearsals on the CPU emulator: scripts/emu_rehearse.py)
+            B = min(B, int(os.environ["STRESS_MAX_B"]))
         kind = int(rng.integers(0, 3))
+        # round 6: a third of the launches under the augmented Lagrangian — lone wavefronts (k_solve) against pairs (opt-in)
+        alm = N <= 127 and rng.integers(0, 3) == 0
         first = int(rng.integers(0, 50000))
         if N > 63:
             kind = 3
@@ -63,7 +67,9 @@ def main():
             wl = pkg.workloads.config5(B_base=max(1, B // 16), N=N, first=first)
         else:
             wl = pkg.workloads.config2(B=B, N=N, first=first)
-        over = {}
+        over = {"solve_type": 1} if alm else {}
+        if N > 127:
+            over["max_iter"] = int(rng.choice([5, 17, 40]))
         if rng.integers(0, 3) == 0:
             over["max_iter"] = int(rng.choice([0, 1, 2, 5, 17, 40]))
         if rng.integers(0, 4) == 0:
@@ -77,15 +83,22 @@ def main():
         rollout = int(rng.choice([-1, -1, 0, 1]))
         ref = None
         slice_a, slice_b = int(rng.choice([1, 2, 3, 5, 8])), int(rng.choice([0, 13, 40]))
-        for tune in ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0", "group=2,pair_sweep=0",
-                     f"group=2,group_slice={slice_a},group_slice_long={slice_a},group_slice_window=300",
-                     f"group=2,group_slice={slice_b},group_slice_long={slice_b}"):
+        tunes = ("group=0", "group=2", "group=2,group_steal=0", "group=2,group_pair_costs=0", "group=2,pair_sweep=0",
+                 f"group=2,group_slice={slice_a},group_slice_long={slice_a},group_slice_window=300",
+                 f"group=2,group_slice={slice_b},group_slice_long={slice_b}")
+        if alm:
+            tunes = ("group=0", "group=2")       # (no hand-overs, no slices under ALM: lone wavefronts vs pairs)
+        elif N > 127:
+            tunes = tunes[1:2] + tunes[2:3] + tunes[5:]   # (no lone build at these horizons: pairs against pairs without hand-overs / other slices)
+        for tune in tunes:
             eng = engine(wl, tune)
             eng.set_helper_mode(0)
             eng.set_rollout_mode(rollout)
             out = eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick, last_u=warm, trace_cap=48)
             info = eng.last_launch_info()
             want = {"group=0": 1}.get(tune, 2)
+            if tune == "group=0" and N > 127:
+                want = 2
             assert info["trajectories_per_wavefront"] == want, (tune, info)
             st = eng.work_sharing_stats()
             assert st["error"] == 0, (wl.name, tune, st)
