@@ -5,8 +5,10 @@
 // (CILQR_EMU_CUS x CILQR_EMU_BLOCKS_PER_CU), the others start as resident ones finish — persistent kernels, spin waits between
 // blocks and hand-over protocols behave as on the device.  A lane runs until its next CROSS-LANE operation (DPP move,
 // ds_bpermute, v_readlane, v_readfirstlane, ballot, wave barrier, __syncthreads) and blocks there.  When no lane of a wavefront
-// can run, the lanes blocked at the same call site form a group — the lanes that execute the instruction together, i.e. its
-// EXEC mask — and the group is resolved at once: sources outside the group read as zero / keep `old`, as on the hardware.
+// can run, the lanes blocked at the same operation OF THE SOURCE (a static tag per macro expansion and enclosing function
+// instantiation — not the return address: the optimiser duplicates calls into both arms of an `if (lane == 0)`) form a group —
+// the lanes that execute the instruction together, i.e. its EXEC mask — and the group is resolved at once: sources outside the
+// group read as zero / keep `old`, as on the hardware.
 // Divergence: groups at different sites are resolved innermost first (deeper stack, then lower code address: loop bodies and
 // if-branches before the code after them); a barrier is only resolved when every live lane of the wavefront (block) stands at
 // one — a barrier met by part of the live lanes while the others wait elsewhere is counted (`partial_barriers`) and reported,
