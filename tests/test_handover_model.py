@@ -447,7 +447,7 @@ def _replay_rollout(N, hand_over_at):
     assert fetched == set(range(N))
 
 
-@pytest.mark.parametrize("N", [64, 65, 71, 72, 73, 96, 100, 120, 127])
+@pytest.mark.parametrize("N", [64, 65, 71, 72, 73, 96, 100, 120, 127, 128, 129, 200, 255])  # (round 6: up to 255)
 def test_counted_wait_of_the_long_rollout_covers_its_dma(N):
     for h in list(range(0, N, 5)) + [N - 2, N - 1, N + 1]:   # N + 1: the small-angle loop runs to the end
         _replay_rollout(N, h)

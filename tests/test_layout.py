@@ -16,7 +16,7 @@ PROG = r"""
 #include <cstdio>
 using namespace cilqr;
 int main() {
-    for (int N = 1; N <= 127; ++N) {
+    for (int N = 1; N <= 255; ++N) {
         if (N <= 63)
             std::printf("S %d %zu %d %d %d\n", N, grp_lds_bytes(N, 0, 2), grp_expansion_doubles(N), grp_pg_doubles(N), kd_doubles(N, 1));
         else
@@ -45,6 +45,10 @@ def rows(tmp_path_factory):
     return [l.split() for l in out if l]
 
 
+def fixed_of(L, N):
+    return int(L[N][2]) - 8 * int(L[N][3]) + 8 * int(L[N][4])
+
+
 def test_grouped_layouts_keep_eight_wavefronts_on_a_cu(rows):
     per_block = 163840 // 8
     S = {int(r[1]): r for r in rows if r[0] == "S"}
@@ -62,6 +66,12 @@ def test_grouped_layouts_keep_eight_wavefronts_on_a_cu(rows):
     assert (per_block - fixed100) // 16 >= 256, fixed100
     fixed127 = int(L[127][2]) - 8 * int(L[127][3]) + 8 * int(L[127][4])
     assert (163840 // 7 - fixed127) // 16 >= 128, fixed127
+    # round 6: horizons of 128 ... 255 (four rows per lane) — the block with a 128-sample window stays under the 64 KB a launch may
+    # ask for without opting in, and at least three blocks (six trajectories) share a CU at the cap
+    for N in (128, 200, 255):
+        fixedN = int(L[N][2]) - 8 * int(L[N][3]) + 8 * int(L[N][4])
+        assert fixedN + 16 * 128 <= 65536, (N, fixedN)
+    assert (163840 // 3 - fixed_of(L, 255)) // 16 >= 128
     K = [r for r in rows if r[0] == "K"][0]
     chunk, kd, ring, xch = int(K[1]), int(K[2]), int(K[3]), int(K[4])
     for N, r in L.items():
