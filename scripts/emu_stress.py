@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lib", default=os.path.join(ROOT, "tests", "emu", "_build", "libcilqr_emu_dev.so"))
     ap.add_argument("--long", action="store_true", help="horizons above 63 too (the long layout: slower)")
+    ap.add_argument("--focus", default="", help="'claims': tiny launches that maximise racing claims on the queue of parked trajectories (two or "
+                    "three blocks, slices of one or two iterations, every end of slice a hand-over)")
     ap.add_argument("--kinds", default="solve", help="comma list of solve (barrier), alm (augmented Lagrangian in pairs), loop (closed loop in one launch)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
@@ -91,6 +93,9 @@ def main():
              "max_iter": rng.choice([100, 100, 40]), "sched_seed": rng.randrange(1, 1 << 30),
              "blocks_per_cu": rng.choice([1, 2, 3, 4, 8]), "cus": rng.choice([1, 1, 2]),
              "slice": rng.choice([1, 2, 5, 16, 0]), "window": rng.choice([0, 50, 200, 1000]), "wait_model": "real"}
+        if a.focus == "claims":
+            c.update(N=rng.choice([12, 20]), B=rng.choice([5, 6, 7, 9, 12]), blocks_per_cu=rng.choice([2, 3]), cus=1, slice=rng.choice([1, 1, 2]),
+                     window=1000, max_iter=rng.choice([20, 40]), kind="solve", solve_type=0, scenario=rng.choice(["three_bend", "two_borrow"]))
         env = dict(os.environ)
         env.update({"CILQR_AMD_LIB": a.lib, "CILQR_AMD_LIB_DEV": a.lib, "CILQR_EMU_SCHED_SEED": str(c["sched_seed"]),
                     "CILQR_EMU_BLOCKS_PER_CU": str(c["blocks_per_cu"]), "CILQR_EMU_CUS": str(c["cus"]),
