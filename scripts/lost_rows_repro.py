@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 5, time-boxed: the REAL instruction stream that lost store data in round 4 (profiles/r04_experiments/
 tiled_slab_lost_rows.txt), run again.  toy-example-of-ilqr_amd/libcilqr_amd_lostrows.so = the library built with -DCILQR_LOSTROWS_REPRO: the grouped rollout pass
-with its slab stores inside waterfall loops (scripts/probes/lost_rows_failing_pass.s is that function's code).  What the anomaly
+with its slab stores inside waterfall loops (scripts/probes/lost_rows_failing_pass.s.gz is that function's code).  What the anomaly
 changes are line-search costs, hence sometimes trajectories: the check is pairing invariance — lone wavefronts (k_solve, whose
 rollout has no such loop) against pairs per wavefront, same library, same inputs.
 

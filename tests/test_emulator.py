@@ -51,6 +51,9 @@ OUT = {}
 def emu_libs(built):
     sys.path.insert(0, str(EMU))
     import build_emu
+    if os.environ.get("CILQR_EMU_SANITIZE_ALL") == "1":   # every emulator test on the ASan + UBSan build (a one-off sweep, slow)
+        lib = build_emu.build(dev=True, sanitize=True)
+        return {"prod": lib, "dev": lib}
     if os.environ.get("CILQR_EMU_COVERAGE") == "1":   # scripts/emu_coverage.py: the same tests on the block-coverage build
         lib = build_emu.build(dev=True, coverage=True)
         return {"prod": lib, "dev": lib}
@@ -63,6 +66,12 @@ def run(emu_libs, body, timeout=600, env=None, libs=None):
     e.pop("CILQR_TUNE", None)
     e.update({"CILQR_AMD_LIB": str(libs["prod"]), "CILQR_AMD_LIB_DEV": str(libs["dev"])})
     e.update(env or {})
+    if os.environ.get("CILQR_EMU_SANITIZE_ALL") == "1":
+        import glob
+        e.update({"LD_PRELOAD": sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))[-1],
+                  "ASAN_OPTIONS": "detect_leaks=0:halt_on_error=0:detect_stack_use_after_return=0:exitcode=0:log_path=" +
+                                  str(ROOT / "scratch" / "asan_sweep"),
+                  "UBSAN_OPTIONS": "print_stacktrace=1:log_path=" + str(ROOT / "scratch" / "ubsan_sweep")})
     r = subprocess.run([sys.executable, "-c", PRELUDE + body + "\nprint('EMU-RESULT ' + json.dumps(OUT))\n", str(ROOT)],
                        capture_output=True, text=True, timeout=timeout, env=e)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
