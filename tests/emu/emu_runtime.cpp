@@ -186,7 +186,7 @@ static void run_fiber(Fiber* f) {
 }
 
 // ---- resolving a group -----------------------------------------------------------------------------------------------------
-static inline bool is_barrier(int k) { return k == X_WAVE_BARRIER || k == X_BLOCK_BARRIER; }
+static inline bool is_barrier(int k) { return k == X_WAVE_BARRIER || k == X_BLOCK_BARRIER || k == X_SLEEP; }
 
 static Fiber** g_dbg_lanes = nullptr;
 static int g_dbg_nl = 0;
@@ -309,6 +309,11 @@ static bool visit_wave(Block& b, int w) {
         for (Fiber* f : waiting)
             if (!h2 || f->depth < depth || (f->depth == depth && f->ret < ret)) { h2 = true; depth = f->depth; site = f->site; ret = f->ret; }
         for (Fiber* f : waiting) if (f->site == site) grp.push_back(f);
+        if (grp[0]->kind == X_SLEEP) {  // the wavefront sleeps: n / 4 more visits before it goes on
+            bool awake = true;
+            for (Fiber* f : grp) { f->p1 -= 4; awake = awake && f->p1 <= 0; }
+            if (!awake) return true;  // (time passes: not a deadlock)
+        }
         g_stats.xops += (long long)grp.size();
         resolve(grp);
         return true;

@@ -44,7 +44,7 @@ const Idx& grid_dim();
 double* lds_base();  // the current block's dynamic LDS (allocated below 4 GB: kernels keep LDS addresses in 32 bits)
 int lane_id();
 
-enum XKind { X_READFIRSTLANE, X_READLANE, X_BPERMUTE, X_DPP, X_BALLOT, X_WAVE_BARRIER, X_BLOCK_BARRIER };
+enum XKind { X_READFIRSTLANE, X_READLANE, X_BPERMUTE, X_DPP, X_BALLOT, X_WAVE_BARRIER, X_BLOCK_BARRIER, X_SLEEP };
 // one cross-lane operation of the calling lane; returns when the lanes that execute it together have all arrived
 // `tag`: the identity of the operation in the SOURCE — the address of a static object of the macro expansion (one per enclosing
 // function instantiation).  The return address will not do: the optimiser duplicates a call into both arms of an `if (lane == 0)`
@@ -74,7 +74,9 @@ struct BufferRsrc { char* base; unsigned num_records; };
 #define __builtin_amdgcn_wave_barrier() ((void)emu::xlane(emu::X_WAVE_BARRIER, 0, 0, 0, 0, 0, EMU_TAG()))
 #define __syncthreads() ((void)emu::xlane(emu::X_BLOCK_BARRIER, 0, 0, 0, 0, 0, EMU_TAG()))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+// s_sleep n: the wavefront stays off the scheduler for about n / 4 of its turns (64 n cycles on the device) — a spin wait that polls
+// with s_sleep in its loop then burns its bounded poll count as slowly, relative to working wavefronts, as it does on the GPU
+#define __builtin_amdgcn_s_sleep(n) ((void)emu::xlane(emu::X_SLEEP, 0, (int)(n), 0, 0, 0, EMU_TAG()))
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_s_dcache_inv() ((void)0)
 #define __builtin_amdgcn_s_memrealtime() ((unsigned long long)emu::clock_ticks())
