@@ -270,7 +270,9 @@ int cilqr_set_helper_mode(cilqr_handle* h, int32_t mode);
  * on the lone-wavefront builds).  A launch in pairs hands trajectories from wavefront to wavefront
  * (sliced solves, idle wavefronts at its tail); should a bounded wait inside it ever expire, the trajectory that was in transit
  * keeps end_reason = CILQR_END_NOT_SOLVED in its cilqr_result (every result is pre-marked on the launch stream), and
- * cilqr_solve_batch / the next cilqr_wait return CILQR_ERR_DEVICE — whichever launch slot it happened in (never observed in
+ * cilqr_solve_batch / the next cilqr_wait return CILQR_ERR_DEVICE — whichever launch slot it happened in.  The bound is 2^20 polls of
+ * ~5 us: an idle wavefront gives up when the REST of a launch lasts longer than about five seconds — launches are milliseconds;
+ * a closed loop of many ticks at horizons in the hundreds is the one shape that can approach it: cut such loops into several calls (never observed in
  * 52 k stress launches; forced by tests/test_gpu_parity.py::test_a_lost_hand_over_is_loud). */
 int cilqr_set_group_mode(cilqr_handle* h, int32_t mode);
 
