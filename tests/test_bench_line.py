@@ -59,3 +59,27 @@ def test_counter_stamp_names_the_device_code():
     r = bench.roofline_block(pkg, wl, res, 59.7, 1, None, None)
     assert r["traffic_collected"]["device_code"] == ans
     assert r["traffic_collected"]["stale"] == (meta["csrc_sha16"] != bench.csrc_fingerprint())
+
+
+def test_bench_command_walks_through_on_the_emulator():
+    """bench.py end to end — workload in "device" memory, warm-up, the timed region with three batches in flight, the sequential leg,
+    statistics, roofline object, the line — REHEARSED on the wave64 emulator of tests/emu/ through a numpy-backed stand-in for torch
+    (scripts/emu_rehearse.py): the driver's contract keys are there and consistent.  Numbers of such a run mean nothing; what is
+    checked is that the command the driver runs does not first meet its own code on the GPU box."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_rehearse.py"), "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                        "--config", "3", "--batch", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "value_one_batch_at_a_time", "kernel_ms_one_batch_at_a_time"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["steps"] == 2 and b["warmup"] == 1 and b["higher_is_better"] is True and b["vs_baseline"] is None
+    assert b["config"]["workload"] == "config3_bend_B6_N50" and b["config"]["batches_in_flight"] == 3 and "model" not in b["config"]
+    rl = b["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+    assert rl["in_flight"]["buffer_sets_identical"] is True and rl["in_flight"]["sequential"]["results_identical_to_in_flight"] is True
+    assert rl["kernel_ms"] == rl["in_flight"]["sequential"]["kernel_ms"] == b["kernel_ms_one_batch_at_a_time"]
+    its = b["extra"]["iterations_per_step_rank0"]
+    assert abs(b["value"] - its * b["steps"] / b["extra"]["timed_region_s"]) < 1e-6 * b["value"]
+    assert abs(rl["algorithmic_bytes_per_launch"] - its * 8536) < 1e-6
