@@ -156,6 +156,13 @@ OUT["stats"] = emu_stats()
     healthy(r["stats"])
 
 
+def test_smoke_entry_point_on_the_emulator(emu_libs):
+    """__graft_entry__.smoke() — what the driver runs on the GPU box before the bench — rehearsed with the library swapped."""
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "emu_rehearse.py"), "--", sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"],
+                       capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0 and "smoke ok: 8 solves" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
 def test_serial_reference_chain_forced(emu_libs):
     """The serial first-local-minimum chain (cs:289-314 as written) is the fallback of the lane-parallel reference search and
     rarely runs; the development build forces it (a testing aid).  scripts/emu_mutants.py showed that no other emulator test
