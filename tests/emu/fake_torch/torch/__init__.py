@@ -106,8 +106,16 @@ class _Event:
 
 
 def _props(i=0):
+    # (one emulated device per local rank: a multi-rank rehearsal must show distinct devices, as a real node does)
     return _types.SimpleNamespace(name="wave64 emulator (rehearsal)", gcnArchName="x86-emulated-gfx950", multi_processor_count=1, pci_domain_id=0,
-                                  pci_bus_id=0, pci_device_id=0, uuid="emu-0")
+                                  pci_bus_id=int(i), pci_device_id=0, uuid="emu-%d" % int(i))
+
+
+def tensor(data, dtype=float64, device=None):
+    return Tensor(_np.array(data, dtype=dtype))
+
+
+Tensor.item = lambda self: self.a.reshape(-1)[0].item()
 
 
 cuda = _types.SimpleNamespace(is_available=lambda: True, init=lambda: None, set_device=lambda i: None, synchronize=lambda dev=None: None,

@@ -83,3 +83,37 @@ def test_bench_command_walks_through_on_the_emulator():
     its = b["extra"]["iterations_per_step_rank0"]
     assert abs(b["value"] - its * b["steps"] / b["extra"]["timed_region_s"]) < 1e-6 * b["value"]
     assert abs(rl["algorithmic_bytes_per_launch"] - its * 8536) < 1e-6
+
+
+def test_bench_multi_rank_path_walks_through_on_the_emulator():
+    """bench.py --gpus 2 as the driver launches it (one process per device: RANK / LOCAL_RANK / WORLD_SIZE) — no multi-GPU node has
+    been available in six rounds, so the N > 1 code path is REHEARSED: two processes, one emulated device each, the statistics
+    exchanged by a file-based stand-in for torch.distributed.  Each rank solves its own shard (rows first = rank * B of one global
+    batch), rank 0 prints ONE line: n_gpus 2, the global batch and iteration count of both shards, distinct devices, the slowest
+    rank's clock.  (tests/test_distributed.py covers the reduction itself over gloo.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_rehearse.py"), "--ranks", "2", "--", sys.executable,
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "3", "--batch", "5", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines            # rank 0 alone prints
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["config"]["global_batch"] == 10 and b["config"]["batch_per_gpu"] == 5
+    e = b["extra"]
+    assert e["distinct_devices"] is True and len(e["ranks"]) == 2 and len({d["pci_bus_id"] for d in e["ranks"]}) == 2
+    assert [p["rank"] for p in e["per_rank"]] == [0, 1]
+    # the two shards are different rows of one global batch: their iteration counts differ, the line carries the sum
+    its = [p["iterations_per_step"] for p in e["per_rank"]]
+    assert its[0] != its[1] and its[0] == e["iterations_per_step_rank0"]
+    assert abs(b["value"] - sum(its) * b["steps"] / e["timed_region_s"]) < 1e-6 * b["value"]
+    assert e["timed_region_s"] >= max(p["elapsed_s"] for p in e["per_rank"]) - 1e-9
+    # ... and equal to what one process computes for the same rows (shard offsets: first = rank * B)
+    sys.path.insert(0, ROOT)
+    import cilqr_amd as pkg
+    from oracle import Oracle, Scene
+    for rank in (0, 1):
+        wl = pkg.workloads.config3(B=5, N=50, first=rank * 5)
+        ref = Oracle("det").solve_batch(wl.params, [Scene(s.lane_x, s.lane_y, s.lane_yaw, s.obs, s.road_borders, s.ref_velo) for s in wl.scenes],
+                                       wl.x0, wl.scenario_id, wl.param_id, wl.tick, n_threads=2)
+        assert float(ref["res"]["iters"].sum()) == its[rank], (rank, its)
