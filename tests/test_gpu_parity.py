@@ -783,7 +783,7 @@ def test_work_sharing_between_blocks_is_transparent(pkg, orc_det):
     With and without it: the same outputs, counters and decision traces, bit for bit, and equal to the oracle's on a
     sample; the launch's own counters show that searches were announced and served, and no hand-over timed out."""
     from oracle import Scene
-    wl = pkg.workloads.config4(B=640, N=100)
+    wl = pkg.workloads.config4(B=rehearsal_size(640), N=100)
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
     eng.set_group_mode(0)  # (k_solve's two-rows-per-lane builds: by default such a batch now runs two trajectories per wavefront)
     out = {}
@@ -820,7 +820,7 @@ def test_long_horizon_builds_across_horizons(pkg, orc_det, N, B):
     Against the helper-wavefront build (work sharing off) on every trajectory, against the oracle on a sample; warm
     start from a shifted previous solution included (last_u)."""
     from oracle import Scene
-    wl = pkg.workloads.config3(B=B)
+    wl = pkg.workloads.config3(B=rehearsal_size(B))
     if wl.scenes[0].obs.shape[1] < N + 1:
         pytest.skip("obstacle routes shorter than the horizon")
     params = [pkg.copy_params(q, N=N, max_iter=30) for q in wl.params]
@@ -1487,19 +1487,21 @@ sys.path.insert(0, sys.argv[1])
 import cilqr_amd as pkg
 dev = torch.device("cuda", 0)
 # large batches: persistent blocks, whose trajectory counter and scratch areas belong to the launch in flight
-wa, wb = pkg.workloads.config3(B=4096), pkg.workloads.config3(B=4096, first=4096)
+import os
+B2 = max(24, 4096 // int(os.environ.get("CILQR_TEST_SHRINK", "1")))   # (shrunk in rehearsals on the CPU emulator)
+wa, wb = pkg.workloads.config3(B=B2), pkg.workloads.config3(B=B2, first=4096)
 N = wa.N
 eng = pkg.BatchedCILQR(wa.params, wa.scenes)
 refs = [eng.solve_batch(w.x0) for w in (wa, wb)]
 strs = [torch.cuda.Stream(dev) for _ in range(2)]
 d_x0 = [torch.from_numpy(w.x0).to(dev) for w in (wa, wb)]
-outs = [(torch.empty((4096, N, 2), dtype=torch.float64, device=dev), torch.empty((4096, N + 1, 4), dtype=torch.float64, device=dev),
-         torch.zeros((4096, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)) for _ in range(2)]
+outs = [(torch.empty((B2, N, 2), dtype=torch.float64, device=dev), torch.empty((B2, N + 1, 4), dtype=torch.float64, device=dev),
+         torch.zeros((B2, pkg.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)) for _ in range(2)]
 torch.cuda.synchronize(dev)
 for rep in range(3):   # the SAME handle, alternating streams, no host synchronisation in between
     for i in range(2):
         u, x, r = outs[i]
-        eng.solve_batch_device(4096, d_x0[i].data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, 0, strs[i].cuda_stream)
+        eng.solve_batch_device(B2, d_x0[i].data_ptr(), 0, 0, 0, 0, u.data_ptr(), x.data_ptr(), r.data_ptr(), 0, 0, strs[i].cuda_stream)
 torch.cuda.synchronize(dev)
 for (u, x, r), ref in zip(outs, refs):
     assert np.array_equal(u.cpu().numpy(), ref["u"]) and np.array_equal(x.cpu().numpy(), ref["x"])
@@ -1542,7 +1544,7 @@ def test_resumable_solves_are_transparent(pkg, orc_det):
     the state parked in HBM (x, u, lane indices, the scalars cs:110-141 carries), the solve queued and picked up again by
     whichever block is free — fresh trajectories first.  Whatever the slice length, with and without the work sharing
     between blocks, every output — decision traces included — is the one of the unsliced solve and of the oracle."""
-    wl = pkg.workloads.config4(B=4096)
+    wl = pkg.workloads.config4(B=rehearsal_size(4096))
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
     eng.set_group_mode(0)  # (k_solve's builds; the grouped build's sliced solves: test_sliced_solves_of_the_grouped_build)
     ids = (wl.scenario_id, wl.param_id, wl.tick)
@@ -1590,7 +1592,11 @@ from oracle import Oracle, Scene
 dev = torch.device("cuda", 0)
 cfg = pkg.GlobalConfig.get_instance("three_straight")
 sc = pkg.build_scenario(cfg, "three_straight")
+import os
+SHR = int(os.environ.get("CILQR_TEST_SHRINK", "1"))   # (rehearsals on the CPU emulator divide the batch sizes and cut the ticks)
 for N, B, ticks, alm in ((30, 300, 12, 0), (30, 3000, 12, 0), (50, 2600, 9, 0), (30, 200, 6, 1), (30, 2500, 5, 1), (70, 2200, 4, 0), (30, 64, 1, 0)):
+    if SHR > 1:
+        B, ticks = max(6, B // SHR), min(ticks, 3)
     p = pkg.params_from_config(cfg, N=N, use_last_solution=1, solve_type=alm)
     x0 = pkg.workloads.perturbed_starts(sc.ego_state, B, 515151 + N)
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -1859,7 +1865,7 @@ def test_results_do_not_depend_on_what_the_scratch_held(pkg, monkeypatch):
     bit — for lone wavefronts, helper wavefronts and pairs, horizons 50 and 100."""
     import os
     W = pkg.workloads
-    for wl, modes in ((W.config3(B=2100), (0, 2)), (W.config2(B=700), (0,)), (W.config4(B=600), (0,))):
+    for wl, modes in ((W.config3(B=rehearsal_size(2100)), (0, 2)), (W.config2(B=rehearsal_size(700)), (0,)), (W.config4(B=rehearsal_size(600)), (0,))):
         outs = []
         for tune in ("", "poison=1", "poison=2"):
             if tune:
@@ -1899,9 +1905,11 @@ def bufs(B, N):
 def same(a, b):
     return bool(torch.equal(a[0], b[0])) and bool(torch.equal(a[1], b[1])) and bool(torch.equal(a[2], b[2]))
 
-for wl_of, what in ((lambda f: pkg.workloads.config3(B=3000, first=f), "config 3 geometry (pairs per wavefront, persistent blocks, hand-over at the tail)"),
-                    (lambda f: pkg.workloads.config4(B=2400, N=100, first=f), "horizon 100 (work sharing between blocks, resumable solves)"),
-                    (lambda f: pkg.workloads.config2(B=700, first=f), "helper wavefronts")):
+import os
+SHR = int(os.environ.get("CILQR_TEST_SHRINK", "1"))   # (rehearsals on the CPU emulator divide the batch sizes)
+for wl_of, what in ((lambda f: pkg.workloads.config3(B=max(12, 3000 // SHR), first=f), "config 3 geometry (pairs per wavefront, persistent blocks, hand-over at the tail)"),
+                    (lambda f: pkg.workloads.config4(B=max(8, 2400 // SHR), N=100, first=f), "horizon 100 (work sharing between blocks, resumable solves)"),
+                    (lambda f: pkg.workloads.config2(B=max(4, 700 // SHR), first=f), "helper wavefronts")):
     wls = [wl_of(f) for f in (0, 5000, 10000, 15000, 20000)]
     B, N = wls[0].B, wls[0].N
     eng = pkg.BatchedCILQR(wls[0].params, wls[0].scenes)
@@ -2246,7 +2254,7 @@ def test_two_trajectories_per_wavefront_at_long_horizons(pkg, orc_det, N, B, mon
     one of them with the rear-axle model), two parameter sets per scenario with different dt, a negative control weight on
     some rows (non-PD Q_uu: one half of a sweep fails while the other goes on), odd batches (a trajectory that sweeps alone)."""
     from oracle import Scene
-    wl = pkg.workloads.config4(B=B, N=N)
+    wl = pkg.workloads.config4(B=rehearsal_size(B), N=N)
     for s in wl.scenes:
         if s.obs.shape[1] < N + 1:
             pytest.skip("obstacle routes shorter than the horizon")
@@ -2300,7 +2308,7 @@ def test_sliced_solves_of_the_grouped_build(pkg, orc_det, cfg):
     entry yet looks again every turn.  Whatever the slice length — 1 iteration (every trajectory changes slots after every
     iteration once the final round has begun), 5, the automatic one, none — every output and the whole decision trace are the
     ones of the unsliced launch, of lone wavefronts (group mode 0) and, on a sample, of the oracle; no wait expired."""
-    wl = pkg.workloads.config3(B=5000) if cfg == "3" else pkg.workloads.config4(B=4600)
+    wl = pkg.workloads.config3(B=rehearsal_size(5000)) if cfg == "3" else pkg.workloads.config4(B=rehearsal_size(4600))
     ids = (wl.scenario_id, wl.param_id, wl.tick)
     eng = pkg.BatchedCILQR(wl.params, wl.scenes)
     eng.set_resume_iters(0)
