@@ -1093,7 +1093,8 @@ torch.cuda.init()
 sys.path.insert(0, sys.argv[1])
 import cilqr_amd as pkg
 dev = torch.device("cuda", 0)
-wl = pkg.workloads.config2(B=256)
+import os
+wl = pkg.workloads.config2(B=max(12, 256 // int(os.environ.get("CILQR_TEST_SHRINK", "1"))))   # (shrunk in rehearsals on the CPU emulator)
 N, B = wl.N, wl.B
 ref_eng = pkg.BatchedCILQR(wl.params, wl.scenes)
 ref = ref_eng.solve_batch(wl.x0)
