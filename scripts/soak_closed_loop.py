@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import cilqr_amd as pkg  # noqa: E402
 from oracle import Oracle, Scene  # noqa: E402
 
+SHRINK = int(os.environ.get("CILQR_TEST_SHRINK", "0"))
 NAMES = ("two_straight", "three_bend", "two_borrow", "three_straight")
 
 
@@ -51,6 +52,8 @@ def main():
         B = int(rng.choice([1, 7, 64, 300, 1100, 2300, 2600, 5000]))
         if N >= 80:
             B = min(B, 2300)
+        if SHRINK:  # (rehearsal on the emulator, tests/emu: the same shapes with fewer egos; never set on a GPU box)
+            B = max(1, B // SHRINK)
         names = list(rng.choice(NAMES, size=int(rng.integers(1, 5)), replace=False))
         params = [pkg.params_from_config(scen[n][0], N=N, use_last_solution=warm, solve_type=alm, reference_point=rp,
                                          max_iter=int(rng.choice([20, 100]))) for n in names]

@@ -13,6 +13,15 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "not_yet_run_on_hardware: GPU tests of round 6 whose kernels were only ever run on the CPU emulator "
+                            "(tests/emu; the GPU pool was closed): collected LAST, so that `pytest -m gpu -x` has proven every test that "
+                            "has hardware history before it reaches them")
+
+
+def pytest_collection_modifyitems(config, items):
+    last = [it for it in items if it.get_closest_marker("not_yet_run_on_hardware")]
+    if last:
+        items[:] = [it for it in items if not it.get_closest_marker("not_yet_run_on_hardware")] + last
 
 
 @pytest.fixture(scope="session")

@@ -566,6 +566,7 @@ def test_alm_closed_loop_keeps_multipliers(pkg, orc_det, engines):
         x0 = out["x"][0, 1].copy()
 
 
+@pytest.mark.not_yet_run_on_hardware
 @pytest.mark.parametrize("name,N,B", [("three_bend", 50, 600), ("two_borrow", 100, 200), ("three_straight", 30, 300)])
 def test_alm_in_pairs_per_wavefront(pkg, orc_det, scenarios, name, N, B):
     """Round 6 (VERDICT r05 task 2): the augmented Lagrangian on the grouped kernel — two trajectories per wavefront, the long
@@ -989,6 +990,7 @@ def test_horizon_boundaries(pkg, orc_det, scenarios, N):
         pkg.BatchedCILQR(pkg.params_from_config(cfg, N=256), tab)
 
 
+@pytest.mark.not_yet_run_on_hardware
 @pytest.mark.parametrize("N,B", [(128, 40), (150, 300), (200, 300), (255, 24)])
 def test_horizons_above_127(pkg, orc_det, scenarios, N, B):
     """Round 6 (VERDICT r05 task 9; cs:19: upstream's N is any int): horizons of 128 ... 255 — the grouped kernel's long layout
@@ -1021,6 +1023,7 @@ def test_horizons_above_127(pkg, orc_det, scenarios, N, B):
             eng.close()
 
 
+@pytest.mark.not_yet_run_on_hardware
 def test_closed_loop_on_the_long_layout():
     """Round 6: cilqr_closed_loop_batch_device on the grouped kernel's long layout — horizon 100 in pairs (cilqr_set_group_mode(2);
     the default keeps k_solve's loop builds) and horizon 150 (four rows per lane: the only build) — 600 egos x 6 ticks, the egos'
@@ -2057,7 +2060,7 @@ def check(out, must_lose):
         assert (r[f][ok] == ref["res"][f][ok]).all(), f
     assert (r["J_final"][ok].view(np.uint64) == ref["res"]["J_final"][ok].view(np.uint64)).all()
     assert (r["iters"][lost] == 0).all() and np.isnan(r["J_final"][lost]).all() and np.isnan(r["J_init"][lost]).all()
-    assert bool(lost.any()) == must_lose, int(lost.sum())
+    assert must_lose is None or bool(lost.any()) == must_lose, int(lost.sum())
     return int(lost.sum())
 def wait_fails():
     try:
@@ -2071,13 +2074,20 @@ def wait_fails():
 a = bufs(B, N); solve(a); assert not wait_fails(); check(a, False)
 assert eng.work_sharing_stats()["error"] == 0
 # 2. the hand-over wait forced to expire at once: whoever was in transit is marked, the launch is reported, the report clears the latch
+#    (the expiry is certain — some wavefront runs dry first and gives up after one look; that a trajectory is pushed to the place it
+#     left behind is a matter of timing on hardware: all but certain with hundreds of hand-overs per launch, so a few launches
+#     are allowed for it.  On the emulator's schedule the first launch loses some.)
 os.environ["CILQR_GRP_WAIT_SPINS"] = "1"
-b = bufs(B, N); solve(b)
-assert eng.work_sharing_stats()["error"] != 0          # (shown without clearing)
-assert wait_fails(); n_lost = check(b, True)
-assert not wait_fails()                                  # (reported once)
-parked = eng.resume_stats()
-assert 1 <= n_lost <= parked, (n_lost, parked)
+for attempt in range(6):
+    b = bufs(B, N); solve(b)
+    assert eng.work_sharing_stats()["error"] != 0          # (shown without clearing)
+    assert wait_fails(); n_lost = check(b, None)
+    assert not wait_fails()                                  # (reported once)
+    parked = eng.resume_stats()
+    assert n_lost <= parked, (n_lost, parked)
+    if n_lost:
+        break
+assert n_lost >= 1, "six launches with the wait forced to expire and no trajectory was in transit"
 # 3. host-buffer entry point: CILQR_ERR_DEVICE, the outputs still delivered with the marks in them
 try:
     eng.solve_batch(wl.x0, wl.scenario_id, wl.param_id, wl.tick)
@@ -2096,7 +2106,7 @@ solve(outs[1]); solve(outs[2])
 eng.join_device(st); torch.cuda.synchronize(dev)
 assert eng.work_sharing_stats()["error"] != 0
 assert wait_fails()
-check(outs[0], True); check(outs[1], False); check(outs[2], False)
+check(outs[0], None); check(outs[1], False); check(outs[2], False)   # (whether slot 0 LOST one is timing; that it expired is not)
 # 5. and the handle is healthy afterwards
 c = bufs(B, N); solve(c); assert not wait_fails(); check(c, False)
 eng.close()
@@ -2104,6 +2114,7 @@ print("LOST-HAND-OVER-OK", n_lost, parked)
 """
 
 
+@pytest.mark.not_yet_run_on_hardware
 def test_a_lost_hand_over_is_loud():
     """Round 6 (VERDICT r05 task 5): a trajectory lost between wavefronts cannot be mistaken for a result.  Launches
     that hand trajectories over pre-mark every cilqr_result CILQR_END_NOT_SOLVED on the launch stream; the development
