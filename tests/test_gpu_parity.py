@@ -821,7 +821,8 @@ def test_long_horizon_builds_across_horizons(pkg, orc_det, N, B):
     Against the helper-wavefront build (work sharing off) on every trajectory, against the oracle on a sample; warm
     start from a shifted previous solution included (last_u)."""
     from oracle import Scene
-    wl = pkg.workloads.config3(B=rehearsal_size(B))
+    B = rehearsal_size(B)
+    wl = pkg.workloads.config3(B=B)
     if wl.scenes[0].obs.shape[1] < N + 1:
         pytest.skip("obstacle routes shorter than the horizon")
     params = [pkg.copy_params(q, N=N, max_iter=30) for q in wl.params]
@@ -2266,7 +2267,8 @@ def test_two_trajectories_per_wavefront_at_long_horizons(pkg, orc_det, N, B, mon
     one of them with the rear-axle model), two parameter sets per scenario with different dt, a negative control weight on
     some rows (non-PD Q_uu: one half of a sweep fails while the other goes on), odd batches (a trajectory that sweeps alone)."""
     from oracle import Scene
-    wl = pkg.workloads.config4(B=rehearsal_size(B), N=N)
+    B = rehearsal_size(B)
+    wl = pkg.workloads.config4(B=B, N=N)
     for s in wl.scenes:
         if s.obs.shape[1] < N + 1:
             pytest.skip("obstacle routes shorter than the horizon")
