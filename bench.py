@@ -68,6 +68,7 @@ def parse():
                          "each) and report it under extra.pipelined — never the headline value.  Off by default so that "
                          "every k_solve launch of the default command is a sequential one (rocprofv3 averages agree).")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--only-extra", default="", dest="only_extra", help=argparse.SUPPRESS)  # (the child of isolated_extra below)
     ap.add_argument("--ticks", type=int, default=120, help="--config 1: closed-loop ticks")
     return ap.parse_args()
 
@@ -817,6 +818,32 @@ def main():
         except Exception as e:  # noqa: BLE001 - reported in the line
             return {"error": f"{type(e).__name__}: {e}"[:500]} if rank == 0 else None
 
+    # Round 6's kernels have never run on hardware (the GPU pool was closed all round; they are bit-exact on the wave64 emulator of
+    # the CPU test suite).  A side measurement on such a kernel runs in a PROCESS OF ITS OWN with a time limit: a fault or a hang
+    # there — which no `except` catches — costs that entry, not the line.
+    ALM_PAIRS = ("the headline batch with solve_type alm IN PAIRS per wavefront (cilqr_set_group_mode(2): the grouped kernel's long "
+                 "layout with dense rows; written without a GPU, bit-exact on the wave64 emulator of the CPU test suite)")
+    if args.only_extra == "alm_pairs":
+        r = guarded(side_run, 5, max(3, args.steps // 4), ALM_PAIRS, alm=True, cpu_check_rows=1024, group_mode=2)
+        if rank == 0:
+            print("ONLY-EXTRA " + json.dumps(r), flush=True)
+        return
+
+    def isolated_extra(name, limit_s):
+        if world != 1:
+            return {"skipped": "measured at N = 1 only (it runs in a process of its own)"} if rank == 0 else None
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--only-extra", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--cpu-threads", str(args.cpu_threads)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s * (20 if REHEARSAL > 1 else 1))
+        got = [ln for ln in r.stdout.splitlines() if ln.startswith("ONLY-EXTRA ")]
+        if r.returncode != 0 or not got:
+            return {"error": f"the child process ended with code {r.returncode}: " + (r.stderr or r.stdout)[-400:]}
+        out_x = json.loads(got[-1][len("ONLY-EXTRA "):])
+        if isinstance(out_x, dict):
+            out_x["measured_in"] = "a process of its own (a kernel without hardware history cannot take the line down)"
+        return out_x
+
     second = third = fourth = closed = closed30 = alm5 = alm5p = None
     if not args.no_extras and args.config == 0 and not args.batch and not args.horizon:
         third = guarded(side_run, 3, max(args.steps, 20), "BASELINE configs[2]: 8192 three_bend trajectories = two rounds of the "
@@ -833,9 +860,7 @@ def main():
                        "581-643): multipliers [B][N][8 + 2M] in HBM, kept by the handle across calls", alm=True,
                        cpu_check_rows=1024)
         # round 6: the same batch on the grouped kernel's ALM builds (two trajectories per wavefront; opt-in until measured here)
-        alm5p = guarded(side_run, 5, max(3, args.steps // 4), "the headline batch with solve_type alm IN PAIRS per wavefront "
-                        "(cilqr_set_group_mode(2): the grouped kernel's long layout with dense rows; written without a GPU, bit-exact "
-                        "on the wave64 emulator of the CPU test suite)", alm=True, cpu_check_rows=1024, group_mode=2)
+        alm5p = guarded(isolated_extra, "alm_pairs", 600)
 
     if rank == 0:
         my_iters = float(res["iters"].sum())
