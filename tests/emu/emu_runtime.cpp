@@ -547,6 +547,14 @@ extern "C" int cilqr_emu_split_sites(const void** a, const void** b, long long* 
 // ---- the HIP host API ------------------------------------------------------------------------------------------------------
 struct emu_stream { int id; };
 struct emu_event { long long t; };
+// What the HOST side asks of the runtime (cilqr_emu_api_counts): on the device every one of these calls costs microseconds — the
+// budget of the latency-bound entry points (the single-ego solve of the drop-in class) is counted here, where no clock is.
+enum { API_MALLOC, API_FREE, API_MEMCPY_SYNC, API_MEMCPY_ASYNC, API_MEMSET, API_SYNC, API_EVENT_RECORD, API_STREAM_WAIT, API_BYTES_COPIED, API_N };
+static long long g_api[API_N];
+extern "C" void cilqr_emu_api_counts(long long out[10]) {
+    out[0] = emu::g_stats.launches;
+    for (int i = 0; i < API_N; ++i) out[1 + i] = g_api[i];
+}
 int emu_blocks_per_cu() { return std::max(1, emu::env_int("CILQR_EMU_BLOCKS_PER_CU", 8)); }
 // CILQR_EMU_DEVICES: how many devices the emulated box shows (cilqr_amd::ShardedSolver, one handle and host thread per device)
 hipError_t hipGetDeviceCount(int* n) { *n = std::max(1, emu::env_int("CILQR_EMU_DEVICES", 1)); return hipSuccess; }
@@ -557,6 +565,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return hipSuccess;
 }
 hipError_t hipMalloc(void** p, size_t n) {
+    ++g_api[API_MALLOC];
     // 0xff fill: memory the kernels never wrote reads as NaNs, not as zeros (as the poisoned-scratch stress runs do on the GPU)
     void* q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
@@ -564,29 +573,30 @@ hipError_t hipMalloc(void** p, size_t n) {
     *p = q;
     return hipSuccess;
 }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipFree(void* p) { ++g_api[API_FREE]; std::free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { ++g_api[API_MEMCPY_SYNC]; g_api[API_BYTES_COPIED] += (long long)n; std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { ++g_api[API_MEMCPY_ASYNC]; g_api[API_BYTES_COPIED] += (long long)n; std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { ++g_api[API_MEMSET]; std::memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { ++g_api[API_MEMSET]; std::memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t) {
+    ++g_api[API_MEMSET];
     for (size_t i = 0; i < count; ++i) static_cast<int*>(d)[i] = v;
     return hipSuccess;
 }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated HIP error"; }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { ++g_api[API_SYNC]; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { ++g_api[API_SYNC]; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new emu_stream{1}; return hipSuccess; }
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new emu_stream{2}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { ++g_api[API_STREAM_WAIT]; return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::clock_ticks(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { ++g_api[API_EVENT_RECORD]; e->t = emu::clock_ticks(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { ++g_api[API_SYNC]; return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t) * 1e-6f; return hipSuccess; }
