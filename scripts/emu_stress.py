@@ -78,7 +78,10 @@ def main():
     ap.add_argument("--lib", default=os.path.join(ROOT, "tests", "emu", "_build", "libcilqr_emu_dev.so"))
     ap.add_argument("--long", action="store_true", help="horizons above 63 too (the long layout: slower)")
     ap.add_argument("--focus", default="", help="'claims': tiny launches that maximise racing claims on the queue of parked trajectories (two or "
-                    "three blocks, slices of one or two iterations, every end of slice a hand-over)")
+                    "three blocks, slices of one or two iterations, every end of slice a hand-over); 'places': shapes in which slots end up "
+                    "holding a place in the queue (with --preempt)")
+    ap.add_argument("--preempt", type=int, default=0, help="n > 0: a lane hands the processor back before one atomic operation in n (CILQR_EMU_PREEMPT): "
+                    "other blocks run INSIDE the protocols' windows, e.g. between a push's reservation and the store of its entry")
     ap.add_argument("--kinds", default="solve", help="comma list of solve (barrier), alm (augmented Lagrangian in pairs), loop (closed loop in one launch)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
@@ -96,8 +99,14 @@ def main():
         if a.focus == "claims":
             c.update(N=rng.choice([12, 20]), B=rng.choice([5, 6, 7, 9, 12]), blocks_per_cu=rng.choice([2, 3]), cus=1, slice=rng.choice([1, 1, 2]),
                      window=1000, max_iter=rng.choice([20, 40]), kind="solve", solve_type=0, scenario=rng.choice(["three_bend", "two_borrow"]))
+        if a.focus == "places":
+            # slots that CLAIM a place in the queue beyond the pushes so far and keep it (GP_CLAIMED; an idle wavefront waiting with
+            # a place): needs two takers racing for the last unclaimed push — use with --preempt — and pushes that then stop coming
+            c.update(N=rng.choice([12, 20]), B=rng.choice([5, 7, 9, 12, 16, 20]), blocks_per_cu=rng.choice([3, 4, 6, 8]), cus=1,
+                     slice=rng.choice([2, 3, 5]), window=rng.choice([0, 50, 1000]), max_iter=rng.choice([20, 40]), kind="solve", solve_type=0,
+                     scenario=rng.choice(["three_bend", "two_borrow"]))
         env = dict(os.environ)
-        env.update({"CILQR_AMD_LIB": a.lib, "CILQR_AMD_LIB_DEV": a.lib, "CILQR_EMU_SCHED_SEED": str(c["sched_seed"]),
+        env.update({"CILQR_AMD_LIB": a.lib, "CILQR_AMD_LIB_DEV": a.lib, "CILQR_EMU_SCHED_SEED": str(c["sched_seed"]), "CILQR_EMU_PREEMPT": str(a.preempt),
                     "CILQR_EMU_BLOCKS_PER_CU": str(c["blocks_per_cu"]), "CILQR_EMU_CUS": str(c["cus"]),
                     "CILQR_TUNE": "group_slice=%d,group_slice_long=%d,group_slice_window=%d" % (c["slice"], c["slice"], c["window"])})
         r = subprocess.run([sys.executable, "-c", CASE, ROOT, json.dumps(c)], capture_output=True, text=True, timeout=1800, env=env)

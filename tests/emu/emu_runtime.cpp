@@ -44,7 +44,7 @@ __asm__(
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
     ".size emu_swap, .-emu_swap\n");
 
-enum St { RUN, XWAIT, DONE };
+enum St { RUN, XWAIT, DONE, PREEMPTED };
 struct Block;
 struct Fiber {
     void* sp = nullptr;
@@ -82,7 +82,7 @@ static const size_t LDS_ARENA = 64u << 20, LDS_PER_BLOCK = 160u << 10;
 static Idx g_host_idx{0, 0, 0};
 
 struct Stats {
-    long long launches = 0, xops = 0, groups = 0, split_resolutions = 0, partial_barriers = 0, readlane_inactive = 0;
+    long long launches = 0, xops = 0, groups = 0, split_resolutions = 0, partial_barriers = 0, readlane_inactive = 0, preemptions = 0;
     std::map<std::pair<const void*, const void*>, long long> split_sites;
     std::map<const void*, long long> inactive_sites;
 } g_stats;
@@ -118,6 +118,16 @@ static inline void to_scheduler(Fiber* f, bool last) {
 #ifdef CILQR_EMU_SANITIZE
     __sanitizer_finish_switch_fiber(f->asan_fake, &g_sched_stack_bottom, &g_sched_stack_size);
 #endif
+}
+
+static int g_preempt = 0;  // CILQR_EMU_PREEMPT (read per launch; only under adversarial scheduling)
+void preempt_point() {
+    Fiber* f = g_cur;
+    if (!f || !g_preempt || !g_sched_seed) return;
+    if (sched_rand() % (unsigned)g_preempt) return;   // one point in g_preempt, on average
+    ++g_stats.preemptions;
+    f->st = PREEMPTED;
+    to_scheduler(f, false);
 }
 
 __attribute__((noinline)) long long xlane(int kind, long long v, int p1, int p2, int p3, int p4, const void* tag) {
@@ -258,11 +268,16 @@ static bool visit_wave(Block& b, int w) {
     bool any = false;
     g_dbg_lanes = lanes; g_dbg_nl = nl;
     for (int l = 0; l < nl; ++l)
+        if (lanes[l]->st == PREEMPTED) lanes[l]->st = RUN;  // (a lane that lost the processor at a preemption point goes on now)
+    bool preempted = false;
+    for (int l = 0; l < nl; ++l)
         if (lanes[l]->st == RUN) {
             run_fiber(lanes[l]);
             if (lanes[l]->st == DONE) --b.live;
+            preempted |= lanes[l]->st == PREEMPTED;
             any = true;
         }
+    if (preempted) return true;  // (the wavefront is in mid-stretch: nothing of it is resolved before that lane has arrived)
     // every lane is now blocked or done
     std::vector<Fiber*> waiting;
     for (int l = 0; l < nl; ++l)
@@ -352,6 +367,7 @@ void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body) {
     {
         const int seed = env_int("CILQR_EMU_SCHED_SEED", 0);
         g_sched_seed = seed ? (0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)g_stats.launches) | 1ULL : 0ULL;
+        g_preempt = env_int("CILQR_EMU_PREEMPT", 0);
     }
     const int threads = (int)(block.x * block.y * block.z);
     const long long n_blocks = (long long)grid.x * grid.y * grid.z;
@@ -527,7 +543,7 @@ extern "C" int cilqr_emu_hazards(const void** a, const void** b, long long* n, i
 extern "C" void cilqr_emu_stats(long long out[8]) {
     out[0] = emu::g_stats.launches; out[1] = emu::g_stats.xops; out[2] = emu::g_stats.groups;
     out[3] = emu::g_stats.split_resolutions; out[4] = emu::g_stats.partial_barriers; out[5] = emu::g_stats.readlane_inactive;
-    out[6] = (long long)emu::g_stats.split_sites.size(); out[7] = 0;
+    out[6] = (long long)emu::g_stats.split_sites.size(); out[7] = emu::g_stats.preemptions;
 }
 extern "C" int cilqr_emu_inactive_sites(const void** a, long long* n, int cap) {
     int i = 0;

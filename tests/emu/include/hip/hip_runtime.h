@@ -52,6 +52,11 @@ enum XKind { X_READFIRSTLANE, X_READLANE, X_BPERMUTE, X_DPP, X_BALLOT, X_WAVE_BA
 long long xlane(int kind, long long v, int p1, int p2, int p3, int p4, const void* tag);
 #define EMU_TAG() ({ static const char emu_tag_ = 0; (const void*)&emu_tag_; })
 long long clock_ticks();
+// PREEMPTION POINT (adversarial scheduling with CILQR_EMU_PREEMPT=1): a wavefront can lose the SIMD between any two instructions;
+// what that can break are the protocols BETWEEN wavefronts, whose steps are atomic operations on global memory.  Before every such
+// operation the executing lane may hand the processor back (its wavefront resumes at a later visit), so that other blocks run
+// inside windows like the one between rq_push's reservation and the store of its entry.
+void preempt_point();
 void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body);
 
 struct BufferRsrc { char* base; unsigned num_records; };
@@ -74,6 +79,11 @@ struct BufferRsrc { char* base; unsigned num_records; };
 #define __builtin_amdgcn_wave_barrier() ((void)emu::xlane(emu::X_WAVE_BARRIER, 0, 0, 0, 0, 0, EMU_TAG()))
 #define __syncthreads() ((void)emu::xlane(emu::X_BLOCK_BARRIER, 0, 0, 0, 0, 0, EMU_TAG()))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __hip_atomic_fetch_add(p, v, order, scope) (emu::preempt_point(), __atomic_fetch_add((p), (v), (order)))
+#define __hip_atomic_fetch_or(p, v, order, scope) (emu::preempt_point(), __atomic_fetch_or((p), (v), (order)))
+#define __hip_atomic_load(p, order, scope) (emu::preempt_point(), __atomic_load_n((p), (order)))
+#define __hip_atomic_store(p, v, order, scope) (emu::preempt_point(), __atomic_store_n((p), (v), (order)))
+#define __hip_atomic_compare_exchange_strong(p, e, d, so, fo, scope) (emu::preempt_point(), __atomic_compare_exchange_n((p), (e), (d), false, (so), (fo)))
 // s_sleep n: the wavefront stays off the scheduler for about n / 4 of its turns (64 n cycles on the device) — a spin wait that polls
 // with s_sleep in its loop then burns its bounded poll count as slowly, relative to working wavefronts, as it does on the GPU
 #define __builtin_amdgcn_s_sleep(n) ((void)emu::xlane(emu::X_SLEEP, 0, (int)(n), 0, 0, 0, EMU_TAG()))

@@ -550,3 +550,20 @@ OUT["ticks"] = ticks; OUT["equal"] = equal
         assert t == dict(launches=1, malloc=0, free=0, memcpy_sync=0, memcpy_async=2, memset=0, sync=1, event_record=1, stream_wait=0,
                          bytes_copied=t["bytes_copied"]), t
         assert t["bytes_copied"] < 4096, t
+
+
+def test_places_held_in_the_queue_with_preemption_inside_the_protocol(emu_libs):
+    """The hand-over protocol's rarest branch: a slot that CLAIMS a place in the queue of parked trajectories beyond the pushes so far
+    keeps it (GP_CLAIMED) and an idle wavefront waits with its place (grp_take_parked's -2, grp_wait_for_work's `claim` arm;
+    ADVICE r05 low is about this branch).  It needs two takers racing for the last unclaimed push — a window between two atomic
+    operations.  The emulator's adversarial scheduler can take the processor away from a lane BEFORE any atomic operation
+    (CILQR_EMU_PREEMPT), so other blocks run inside such windows; until that existed no emulator run ever reached the branch
+    (block coverage).  A seeded run of scripts/emu_stress.py --focus places: every launch == oracle, no bounded wait expired, no
+    trajectory left marked NOT_SOLVED.  That these shapes take the branch is what scripts/emu_coverage.py shows (it runs the same
+    command on the coverage build: profiles/r06_emulator_coverage.json, cilqr_group.hpp)."""
+    e = dict(os.environ)
+    e.pop("CILQR_TUNE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "emu_stress.py"), "--cases", "60", "--seed", "2", "--focus", "places", "--preempt", "2",
+                        "--lib", str(emu_libs["dev"])], capture_output=True, text=True, timeout=1200, env=e)
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and last["failed"] == 0 and last["hand_overs"] > 100, r.stdout[-2000:] + r.stderr[-1000:]
