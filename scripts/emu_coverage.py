@@ -31,11 +31,12 @@ def run_tests():
                    cwd=ROOT, check=False, stdout=subprocess.DEVNULL)
     # ... and the GPU suite's own test bodies that fit the emulator's speed (stage-by-stage entry points, failure paths, edge cases,
     # the single-ego entry point): the same assertions, the library swapped
-    env2 = dict(env, CILQR_AMD_LIB=LIB, CILQR_AMD_LIB_DEV=LIB)
+    env2 = dict(env, CILQR_AMD_LIB=LIB, CILQR_AMD_LIB_DEV=LIB, CILQR_TEST_SHRINK="600")
+    env2["PYTHONPATH"] = os.path.join(ROOT, "tests", "emu", "fake_torch") + os.pathsep + env2.get("PYTHONPATH", "")  # (the torch-based ones)
     subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-p", "no:cacheprovider",
                     "--timeout=300", "-k", "stages_bitexact or backward_pass_failure or error_codes or api_contract or edge_no_obstacles or "
                     "edge_start or irregular_lane or single_ego_entry_keeps or solver_class_mirror or solve_yaml_start or "
-                    "solve_ticks_and_warm or production_library_refuses or alm_state_follows"], env=env2, cwd=ROOT, check=False)
+                    "solve_ticks_and_warm or production_library_refuses or alm_state_follows or device_pointer_entry"], env=env2, cwd=ROOT, check=False)
 
 
 def main():

@@ -67,6 +67,12 @@ else:
     r.update(ok=not bad, mismatching=bad[:8], not_solved=int((out["res"]["end_reason"] == 4).sum()), parked=eng.resume_stats(),
              launch_error=eng.work_sharing_stats()["error"], blocks=eng.last_launch_info()["blocks"], iters_max=int(out["res"]["iters"].max()))
     r["ok"] = r["ok"] and r["not_solved"] == 0 and r["launch_error"] == 0
+try:
+    import ctypes
+    pc = (ctypes.c_longlong * 16)(); ctypes.CDLL(str(pkg._lib.LIB_PATH)).cilqr_emu_probe_counts(pc)
+    r["waits_with_a_place"], r["places_kept"] = int(pc[0]), int(pc[1])   # (tests/emu/build_emu.py PROBES)
+except (OSError, AttributeError):
+    pass
 print("CASE " + json.dumps(r))
 """
 
@@ -82,11 +88,19 @@ def main():
                     "holding a place in the queue (with --preempt)")
     ap.add_argument("--preempt", type=int, default=0, help="n > 0: a lane hands the processor back before one atomic operation in n (CILQR_EMU_PREEMPT): "
                     "other blocks run INSIDE the protocols' windows, e.g. between a push's reservation and the store of its entry")
+    ap.add_argument("--replay", default="", help="a JSON list of case dictionaries (as printed) to run instead of random ones: the schedule is a function of "
+                    "the case and of the library's code, so a case that reached a rare branch reaches it again")
+    ap.add_argument("--hits-out", default="", dest="hits_out", help="write the cases that reached the claimed-place branch (probes of the emulator build) here")
     ap.add_argument("--kinds", default="solve", help="comma list of solve (barrier), alm (augmented Lagrangian in pairs), loop (closed loop in one launch)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     bad = 0
     tot_parked = 0
+    tot_places = [0, 0]
+    replay = json.load(open(a.replay)) if a.replay else None
+    if replay is not None:
+        a.cases = len(replay)
+    hits = []
     for i in range(a.cases):
         N = rng.choice([20, 30, 37, 50] + ([70, 100, 130] if a.long else []))
         kind = rng.choice(a.kinds.split(","))
@@ -105,6 +119,8 @@ def main():
             c.update(N=rng.choice([12, 20]), B=rng.choice([5, 7, 9, 12, 16, 20]), blocks_per_cu=rng.choice([3, 4, 6, 8]), cus=1,
                      slice=rng.choice([2, 3, 5]), window=rng.choice([0, 50, 1000]), max_iter=rng.choice([20, 40]), kind="solve", solve_type=0,
                      scenario=rng.choice(["three_bend", "two_borrow"]))
+        if replay is not None:
+            c = {k: v for k, v in replay[i].items() if k in c}
         env = dict(os.environ)
         env.update({"CILQR_AMD_LIB": a.lib, "CILQR_AMD_LIB_DEV": a.lib, "CILQR_EMU_SCHED_SEED": str(c["sched_seed"]), "CILQR_EMU_PREEMPT": str(a.preempt),
                     "CILQR_EMU_BLOCKS_PER_CU": str(c["blocks_per_cu"]), "CILQR_EMU_CUS": str(c["cus"]),
@@ -117,9 +133,14 @@ def main():
             continue
         res = json.loads(line[-1][5:])
         tot_parked += res.get("parked", 0)
+        tot_places[0] += res.get("waits_with_a_place", 0); tot_places[1] += res.get("places_kept", 0)
         print(json.dumps(res), flush=True)
         bad += 0 if res["ok"] else 1
-    print(json.dumps({"cases": a.cases, "failed": bad, "hand_overs": tot_parked}))
+        if res.get("waits_with_a_place") or res.get("places_kept"):
+            hits.append(c)
+    if a.hits_out:
+        json.dump(hits, open(a.hits_out, "w"), indent=0)
+    print(json.dumps({"cases": a.cases, "failed": bad, "hand_overs": tot_parked, "waits_with_a_place": tot_places[0], "places_kept": tot_places[1]}))
     sys.exit(1 if bad else 0)
 
 

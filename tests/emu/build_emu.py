@@ -40,6 +40,14 @@ LOCKSTEP_POINTS = [
      "k_solve_grp: lane 0 stores the trajectory's scalars into GrpSt, which every lane has read as wave-uniform values in the same stretch"),
 ]
 
+# PROBES.  Counters planted in the scratch copy (never in csrc/): how often did a run reach a branch that is too rare to assume?
+# emu_runtime.cpp counts one per wavefront (lane 0); cilqr_emu_probe_counts() returns them in this order.  (file, text the probe
+# goes in FRONT of, occurrences expected, name)
+PROBES = [
+    ("cilqr_group.hpp", "        h = (unsigned)claim;\n", 1, "waits_with_a_place"),   # grp_wait_for_work entered holding a place in the queue
+    ("cilqr_group.hpp", "    *claim = (int)h;\n    return -2;\n", 1, "places_kept"),   # grp_take_parked: claimed beyond the pushes, entry not there after four looks
+]
+
 ASM_RE = re.compile(r"__asm__\s*(?:volatile)?\s*\((?:[^()]|\([^()]*\))*\)\s*;")
 
 
@@ -67,6 +75,10 @@ def rewrite(text, name):
         if fname == name:
             assert text.count(anchor) == count, (name, anchor, text.count(anchor))
             text = text.replace(anchor, "EMU_LOCKSTEP();\n" + anchor)
+    for i, (fname, anchor, count, _name) in enumerate(PROBES):
+        if fname == name:
+            assert text.count(anchor) == count, (name, anchor, text.count(anchor))
+            text = text.replace(anchor, f"EMU_PROBE({i});\n" + anchor)
     return text, n_asm
 
 

@@ -55,6 +55,7 @@ struct Fiber {
     Idx tidx{0, 0, 0};
     // the pending cross-lane operation
     int kind = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+    int stall = 0;  // PREEMPTED: visits of its wavefront still to sit out
     long long v = 0, result = 0;
     const void* site = nullptr;
     const void* ret = nullptr;
@@ -120,12 +121,18 @@ static inline void to_scheduler(Fiber* f, bool last) {
 #endif
 }
 
+static long long g_probes[16];
+void probe(int id) { if (g_cur && g_cur->lane == 0 && id >= 0 && id < 16) ++g_probes[id]; }
 static int g_preempt = 0;  // CILQR_EMU_PREEMPT (read per launch; only under adversarial scheduling)
 void preempt_point() {
     Fiber* f = g_cur;
     if (!f || !g_preempt || !g_sched_seed) return;
     if (sched_rand() % (unsigned)g_preempt) return;   // one point in g_preempt, on average
     ++g_stats.preemptions;
+    // two times in three the wavefront is back at its next visit; otherwise it stays away for up to 400 visits — long enough for
+    // other wavefronts to complete whole protocol steps inside the window (measured on the claimed-place branch of the grouped
+    // kernel's queue, build_emu.py PROBES: reached by 1 launch in 2 400 without the long stalls, by 1 in 30 with them)
+    f->stall = (sched_rand() % 3 == 0) ? (int)(sched_rand() % 400) : 0;
     f->st = PREEMPTED;
     to_scheduler(f, false);
 }
@@ -268,8 +275,9 @@ static bool visit_wave(Block& b, int w) {
     bool any = false;
     g_dbg_lanes = lanes; g_dbg_nl = nl;
     for (int l = 0; l < nl; ++l)
-        if (lanes[l]->st == PREEMPTED) lanes[l]->st = RUN;  // (a lane that lost the processor at a preemption point goes on now)
+        if (lanes[l]->st == PREEMPTED && lanes[l]->stall-- <= 0) lanes[l]->st = RUN;  // (a lane that lost the processor at a preemption point goes on)
     bool preempted = false;
+    for (int l = 0; l < nl; ++l) preempted |= lanes[l]->st == PREEMPTED;
     for (int l = 0; l < nl; ++l)
         if (lanes[l]->st == RUN) {
             run_fiber(lanes[l]);
@@ -545,6 +553,7 @@ extern "C" void cilqr_emu_stats(long long out[8]) {
     out[3] = emu::g_stats.split_resolutions; out[4] = emu::g_stats.partial_barriers; out[5] = emu::g_stats.readlane_inactive;
     out[6] = (long long)emu::g_stats.split_sites.size(); out[7] = emu::g_stats.preemptions;
 }
+extern "C" void cilqr_emu_probe_counts(long long out[16]) { for (int i = 0; i < 16; ++i) out[i] = emu::g_probes[i]; }
 extern "C" int cilqr_emu_inactive_sites(const void** a, long long* n, int cap) {
     int i = 0;
     for (const auto& kv : emu::g_stats.inactive_sites) { if (i >= cap) break; a[i] = kv.first; n[i] = kv.second; ++i; }

@@ -57,6 +57,8 @@ long long clock_ticks();
 // operation the executing lane may hand the processor back (its wavefront resumes at a later visit), so that other blocks run
 // inside windows like the one between rq_push's reservation and the store of its entry.
 void preempt_point();
+void probe(int id);  // build_emu.py PROBES
+#define EMU_PROBE(id) emu::probe(id)
 void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body);
 
 struct BufferRsrc { char* base; unsigned num_records; };

@@ -554,16 +554,20 @@ OUT["ticks"] = ticks; OUT["equal"] = equal
 
 def test_places_held_in_the_queue_with_preemption_inside_the_protocol(emu_libs):
     """The hand-over protocol's rarest branch: a slot that CLAIMS a place in the queue of parked trajectories beyond the pushes so far
-    keeps it (GP_CLAIMED) and an idle wavefront waits with its place (grp_take_parked's -2, grp_wait_for_work's `claim` arm;
-    ADVICE r05 low is about this branch).  It needs two takers racing for the last unclaimed push — a window between two atomic
-    operations.  The emulator's adversarial scheduler can take the processor away from a lane BEFORE any atomic operation
-    (CILQR_EMU_PREEMPT), so other blocks run inside such windows; until that existed no emulator run ever reached the branch
-    (block coverage).  A seeded run of scripts/emu_stress.py --focus places: every launch == oracle, no bounded wait expired, no
-    trajectory left marked NOT_SOLVED.  That these shapes take the branch is what scripts/emu_coverage.py shows (it runs the same
-    command on the coverage build: profiles/r06_emulator_coverage.json, cilqr_group.hpp)."""
+    keeps it (GP_CLAIMED: grp_take_parked's -2) and an idle wavefront waits WITH its place (grp_wait_for_work's `claim` arm; ADVICE
+    r05 low is about this branch).  It needs two takers racing for the last unclaimed push — a window between two atomic operations.
+    The emulator's adversarial scheduler can take the processor away from a lane BEFORE any atomic operation, for one visit or for
+    hundreds (CILQR_EMU_PREEMPT), so other blocks run inside such windows; before that existed no emulator run had ever executed
+    the branch (block coverage).  Counters planted in the emulator's scratch copy of the sources (build_emu.py PROBES, not in csrc/)
+    tell whether a run got there.  A seeded run of scripts/emu_stress.py --focus places: every launch == oracle, no bounded wait
+    expired, no trajectory left marked NOT_SOLVED — AND the branch was taken."""
     e = dict(os.environ)
     e.pop("CILQR_TUNE", None)
-    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "emu_stress.py"), "--cases", "60", "--seed", "2", "--focus", "places", "--preempt", "2",
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "emu_stress.py"), "--cases", "100", "--seed", "506", "--focus", "places", "--preempt", "2",
                         "--lib", str(emu_libs["dev"])], capture_output=True, text=True, timeout=1200, env=e)
     last = json.loads(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0 and last["failed"] == 0 and last["hand_overs"] > 100, r.stdout[-2000:] + r.stderr[-1000:]
+    if os.environ.get("CILQR_EMU_SANITIZE_ALL") != "1" and os.environ.get("CILQR_EMU_COVERAGE") != "1":  # (other builds, other schedules)
+        assert last["places_kept"] > 0 and last["waits_with_a_place"] > 0, \
+            (last, "the seeded run no longer reaches the claimed-place branch (the schedule follows the code): pick another seed with "
+                   "scripts/emu_stress.py --focus places --preempt 2 --cases 100 --seed N")
