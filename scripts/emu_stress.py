@@ -70,7 +70,7 @@ else:
 try:
     import ctypes
     pc = (ctypes.c_longlong * 16)(); ctypes.CDLL(str(pkg._lib.LIB_PATH)).cilqr_emu_probe_counts(pc)
-    r["waits_with_a_place"], r["places_kept"] = int(pc[0]), int(pc[1])   # (tests/emu/build_emu.py PROBES)
+    r["waits_with_a_place"], r["places_kept"], r["idle_with_two_places"] = int(pc[0]), int(pc[1]), int(pc[2])   # (tests/emu/build_emu.py PROBES)
 except (OSError, AttributeError):
     pass
 print("CASE " + json.dumps(r))
@@ -96,7 +96,7 @@ def main():
     rng = random.Random(a.seed)
     bad = 0
     tot_parked = 0
-    tot_places = [0, 0]
+    tot_places = [0, 0, 0]
     replay = json.load(open(a.replay)) if a.replay else None
     if replay is not None:
         a.cases = len(replay)
@@ -133,14 +133,14 @@ def main():
             continue
         res = json.loads(line[-1][5:])
         tot_parked += res.get("parked", 0)
-        tot_places[0] += res.get("waits_with_a_place", 0); tot_places[1] += res.get("places_kept", 0)
+        tot_places[0] += res.get("waits_with_a_place", 0); tot_places[1] += res.get("places_kept", 0); tot_places[2] += res.get("idle_with_two_places", 0)
         print(json.dumps(res), flush=True)
         bad += 0 if res["ok"] else 1
         if res.get("waits_with_a_place") or res.get("places_kept"):
             hits.append(c)
     if a.hits_out:
         json.dump(hits, open(a.hits_out, "w"), indent=0)
-    print(json.dumps({"cases": a.cases, "failed": bad, "hand_overs": tot_parked, "waits_with_a_place": tot_places[0], "places_kept": tot_places[1]}))
+    print(json.dumps({"cases": a.cases, "failed": bad, "hand_overs": tot_parked, "waits_with_a_place": tot_places[0], "places_kept": tot_places[1], "idle_with_two_places": tot_places[2]}))
     sys.exit(1 if bad else 0)
 
 

@@ -46,6 +46,9 @@ LOCKSTEP_POINTS = [
 PROBES = [
     ("cilqr_group.hpp", "        h = (unsigned)claim;\n", 1, "waits_with_a_place"),   # grp_wait_for_work entered holding a place in the queue
     ("cilqr_group.hpp", "    *claim = (int)h;\n    return -2;\n", 1, "places_kept"),   # grp_take_parked: claimed beyond the pushes, entry not there after four looks
+    # k_solve_grp, a wavefront with nothing to do: do BOTH its slots hold a place (the state ADVICE r05's low finding starts from)?
+    ("cilqr_kernels.hpp", "            if (claim < 0 && !LOOP && slice) {\n", 1, "idle_with_two_places",
+     "if (G == 2 && grp_state(g_lds, N, 0)->phase == GP_CLAIMED && grp_state(g_lds, N, 1)->phase == GP_CLAIMED) "),
 ]
 
 ASM_RE = re.compile(r"__asm__\s*(?:volatile)?\s*\((?:[^()]|\([^()]*\))*\)\s*;")
@@ -75,10 +78,10 @@ def rewrite(text, name):
         if fname == name:
             assert text.count(anchor) == count, (name, anchor, text.count(anchor))
             text = text.replace(anchor, "EMU_LOCKSTEP();\n" + anchor)
-    for i, (fname, anchor, count, _name) in enumerate(PROBES):
+    for i, (fname, anchor, count, _name, *cond) in enumerate(PROBES):
         if fname == name:
             assert text.count(anchor) == count, (name, anchor, text.count(anchor))
-            text = text.replace(anchor, f"EMU_PROBE({i});\n" + anchor)
+            text = text.replace(anchor, (cond[0] if cond else "") + f"EMU_PROBE({i});\n" + anchor)
     return text, n_asm
 
 
