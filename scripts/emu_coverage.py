@@ -36,7 +36,7 @@ def run_tests():
     subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-p", "no:cacheprovider",
                     "--timeout=300", "-k", "stages_bitexact or backward_pass_failure or error_codes or api_contract or edge_no_obstacles or "
                     "edge_start or irregular_lane or single_ego_entry_keeps or solver_class_mirror or solve_yaml_start or "
-                    "solve_ticks_and_warm or production_library_refuses or alm_state_follows or device_pointer_entry"], env=env2, cwd=ROOT, check=False)
+                    "solve_ticks_and_warm or alm_state_follows or device_pointer_entry"], env=env2, cwd=ROOT, check=False)
 
 
 def main():
